@@ -1,0 +1,43 @@
+# Builds the product libraries in-tree (they travel to the GPU box with the snapshot):
+#   gpufluidsimulation_amd/libbimocq_hip.so   C-ABI: gpu_* operators + fl_* runtime   (HIP, gfx950)
+#   gpufluidsimulation_amd/libbimocq_host.so  C++ host solver (advance/outputResult) + bq_solver_* C API
+# and, for tests only, the CPU oracle (oracle/Makefile).
+#
+# -ffp-contract=off is part of the numerics contract (bit parity with the oracle), not a tuning knob.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+PKG      := gpufluidsimulation_amd
+CSRC     := $(PKG)/csrc
+OBJDIR   := build/obj
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
+RCCL_LIB ?= -L/opt/rocm/lib -lrccl
+
+KERNEL_SRCS := $(sort $(wildcard $(CSRC)/*.hip))
+KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(KERNEL_SRCS))
+HOST_SRCS   := $(wildcard $(CSRC)/host/*.cpp)
+HOST_OBJS   := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(HOST_SRCS))
+
+all: $(PKG)/libbimocq_hip.so $(PKG)/libbimocq_host.so oracle
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(PKG)/libbimocq_hip.so: $(KERNEL_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(KERNEL_OBJS) $(RCCL_LIB)
+
+$(OBJDIR)/host_%.o: $(CSRC)/host/%.cpp $(wildcard $(CSRC)/host/*.hpp) include/bimocq_gpu.h include/bimocq_solver.h
+	@mkdir -p $(OBJDIR)
+	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -c $< -o $@
+
+# the host solver only speaks the C-ABI: it links against libbimocq_hip.so by name ($$ORIGIN rpath)
+$(PKG)/libbimocq_host.so: $(HOST_OBJS) $(PKG)/libbimocq_hip.so
+	g++ -shared -fPIC -o $@ $(HOST_OBJS) -L$(PKG) -lbimocq_hip -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf build $(PKG)/*.so oracle/_build tests/_build
+
+.PHONY: all oracle clean

@@ -1,0 +1,110 @@
+"""ctypes view of the C-ABI (include/bimocq_gpu.h, include/bimocq_solver.h).
+
+There is no CPU fallback: if the HIP library is missing this raises, and every operator
+latches FL_ERR_NO_DEVICE when no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(HERE, "libbimocq_hip.so")
+HOST_SO = os.path.join(HERE, "libbimocq_host.so")
+
+VP = C.c_void_p          # device pointers travel as plain addresses
+c_f, c_i, c_b, c_d = C.c_float, C.c_int, C.c_bool, C.c_double
+
+_G = [c_f, c_i, c_i, c_i]            # h, ni, nj, nk
+
+HIP_SIGS = {
+    # 1. reference operators
+    "gpu_solve_forward": (None, [VP] * 6 + _G + [c_f, c_f]),
+    "gpu_solve_backwardDMC": (None, [VP] * 9 + _G + [c_f]),
+    "gpu_advect_velocity": (None, [VP] * 9 + _G + [c_b]),
+    "gpu_advect_vel_double": (None, [VP] * 12 + _G + [c_b, c_f]),
+    "gpu_advect_field": (None, [VP] * 5 + _G + [c_b]),
+    "gpu_advect_field_double": (None, [VP] * 8 + _G + [c_b, c_f]),
+    "gpu_accumulate_velocity": (None, [VP] * 9 + _G + [c_b, c_f]),
+    "gpu_accumulate_field": (None, [VP] * 5 + _G + [c_b, c_f]),
+    "gpu_estimate_distortion": (None, [VP] * 7 + _G),
+    "gpu_add": (None, [VP, VP, c_f, c_i]),
+    "gpu_compensate_velocity": (None, [VP] * 15 + _G + [c_b]),
+    "gpu_compensate_field": (None, [VP] * 9 + _G + [c_b]),
+    "gpu_semilag": (None, [VP] * 5 + [c_i, c_i, c_i] + _G + [c_f, c_f]),
+    "gpu_emit_smoke": (None, [VP] * 5 + _G + [c_f] * 7),
+    "gpu_add_buoyancy": (None, [VP] * 3 + [c_i, c_i, c_i, c_f, c_f, c_f]),
+    "gpu_diffuse_field": (None, [VP] * 3 + [c_i, c_i, c_i, c_i, c_f]),
+    "gpu_add_field": (None, [VP, VP, VP, c_f, c_i]),
+    "gpu_projection_jacobi": (None, [VP] * 7 + [c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
+    "gpu_clamp_extrema": (None, [VP] * 5 + [c_i] * 6 + [c_f] * 5),
+    "gpu_mad": (None, [VP, VP, VP, c_f, c_f, c_i]),
+    "gpu_conjugate_gradient": (None, [VP] * 8 + [c_i, c_i, c_i, c_i, c_f]),
+    "gpu_multi_grid_conjugate_gradient": (None, [VP] * 11 + [c_i, c_i, c_d]),
+    # 2. runtime
+    "fl_init": (c_i, [c_i]),
+    "fl_shutdown": (None, []),
+    "fl_malloc": (VP, [C.c_size_t]),
+    "fl_free": (None, [VP]),
+    "fl_memset": (None, [VP, c_i, C.c_size_t]),
+    "fl_memcpy_h2d": (None, [VP, VP, C.c_size_t]),
+    "fl_memcpy_d2h": (None, [VP, VP, C.c_size_t]),
+    "fl_memcpy_d2d": (None, [VP, VP, C.c_size_t]),
+    "fl_sync": (None, []),
+    "fl_event_create": (VP, []),
+    "fl_event_record": (None, [VP]),
+    "fl_event_elapsed_ms": (c_f, [VP, VP]),
+    "fl_event_destroy": (None, [VP]),
+    "fl_last_error": (c_i, []),
+    "fl_last_error_string": (C.c_char_p, []),
+    "fl_clear_error": (None, []),
+    "fl_compute_stream": (VP, []),
+    "fl_set_option": (None, [c_i, c_i]),
+    "fl_get_option": (c_i, [c_i]),
+    # 3. additive
+    "gpu_init_maps": (None, [VP, VP, VP] + _G),
+    "gpu_max_abs3": (c_f, [VP, VP, VP, c_i, c_i, c_i]),
+    "gpu_divergence": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
+    "gpu_jacobi_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "gpu_gradient": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
+    "gpu_residual_norms": (None, [VP, VP, c_i, c_i, c_i, C.POINTER(c_d), C.POINTER(c_f)]),
+    "gpu_clamp_extrema_box": (None, [VP, VP, c_i, c_i, c_i]),
+}
+
+FL_OK, FL_ERR_NO_DEVICE, FL_ERR_HIP, FL_ERR_BAD_ARGUMENT, FL_ERR_UNSUPPORTED, FL_ERR_COMM = range(6)
+FL_OPT_RESIDUAL_STRIDE, FL_OPT_SKIP_UNIT_BLEND, FL_OPT_JACOBI_VARIANT = 1, 2, 3
+
+
+class BimocqLibraryMissing(RuntimeError):
+    pass
+
+
+_hip = None
+
+
+def hip_lib():
+    """Load libbimocq_hip.so (the HIP kernels + runtime).  Raises if it has not been built."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise BimocqLibraryMissing(
+                f"{HIP_SO} not found: build it with `make` (or __graft_entry__.build()); "
+                "there is no CPU fallback for the product path")
+        lib = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in HIP_SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _hip = lib
+    return _hip
+
+
+class BimocqError(RuntimeError):
+    pass
+
+
+def check(lib=None):
+    """Raise if the library has latched an error (and clear it)."""
+    lib = lib or hip_lib()
+    code = lib.fl_last_error()
+    if code != FL_OK:
+        text = lib.fl_last_error_string().decode(errors="replace")
+        lib.fl_clear_error()
+        raise BimocqError(f"bimocq error {code}: {text}")

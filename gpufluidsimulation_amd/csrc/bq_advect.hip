@@ -1,0 +1,521 @@
+// bq_advect.hip -- characteristic-map kernels and their
+// extern "C" launchers.  One thread per buffer element, block = 64 (x) x 4 (y) so a wavefront
+// owns 64 consecutive i of one row (coalesced stores, spatially coherent gathers).
+//
+// Every kernel restates one reference kernel with identical arithmetic (see bq_device.hip.h);
+// the launch geometry, the buffer-descriptor loads and the fusion are ours.
+#include "bq_device.hip.h"
+#include "bq_host.h"
+
+namespace bq {
+
+#define BQ_IJK(nbi, nbj, nbk)                                   \
+    const int i = blockIdx.x * 64 + threadIdx.x;                \
+    const int j = blockIdx.y * 4 + threadIdx.y;                 \
+    const int k = blockIdx.z;                                   \
+    if (i >= (nbi) || j >= (nbj) || k >= (nbk)) return;
+
+static inline dim3 grid_for(int nbi, int nbj, int nbk) { return dim3((nbi + 63) / 64, (nbj + 3) / 4, nbk); }
+static const dim3 kBlock(64, 4, 1);
+
+struct Grid { int ni, nj, nk; };     // CELL dims
+
+// ---- 9-point stencil of sub-voxel sample positions (GPU_kernel.cu:317-348) ---------------
+struct Nine {
+    float q, mq;        // +-0.25f*h
+    f3 org;             // buffer origin (-dim*0.5f*h)
+    float h;
+};
+__device__ __forceinline__ Nine nine_setup(float h, int dx, int dy, int dz)
+{
+    Nine n;
+    n.q = 0.25f * h; n.mq = -0.25f * h; n.h = h;
+    n.org = mk3(-(float)dx * 0.5f * h, -(float)dy * 0.5f * h, -(float)dz * 0.5f * h);
+    return n;
+}
+__device__ __forceinline__ f3 nine_centre(const Nine &n, int i, int j, int k)
+{
+    return mk3((float)i * n.h + n.org.x, (float)j * n.h + n.org.y, (float)k * n.h + n.org.z);
+}
+// corner ii in the reference's order: bit2 -> x sign, bit1 -> y sign, bit0 -> z sign (0 = +)
+__device__ __forceinline__ f3 nine_corner(const Nine &n, f3 c, int ii)
+{
+    return mk3(c.x + ((ii & 4) ? n.mq : n.q), c.y + ((ii & 2) ? n.mq : n.q), c.z + ((ii & 1) ? n.mq : n.q));
+}
+
+// ---- A3: forward_kernel (GPU_kernel.cu:127-144) -------------------------------------------
+template <bool P2>
+__global__ __launch_bounds__(256) void forward_kernel(const float *u, const float *v, const float *w,
+                                                      float *xf, float *yf, float *zf,
+                                                      Spacing sp, Grid g, float cfldt, float dt)
+{
+    BQ_IJK(g.ni, g.nj, g.nk)
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && k > 1 && k < g.nk - 2)) return;
+    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk), make_field(v, g.ni, g.nj + 1, g.nk), make_field(w, g.ni, g.nj, g.nk + 1)};
+    f3 hi = mk3((float)g.ni * sp.h - sp.h, (float)g.nj * sp.h - sp.h, (float)g.nk * sp.h - sp.h);
+    size_t id = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
+    f3 q = trace<P2>(vel, sp, hi, cfldt, dt, mk3(xf[id], yf[id], zf[id]));
+    xf[id] = q.x; yf[id] = q.y; zf[id] = q.z;
+}
+
+// ---- A4: DMC_backward_kernel (GPU_kernel.cu:169-204) --------------------------------------
+__device__ __forceinline__ float dmc_axis(float p, float vel, float a, float s)
+{
+    if ((double)fabsf(a) > 1e-4) return p - (1.0f - exp_portable(-a * s)) * vel / a;
+    return p - vel * s;
+}
+
+template <bool P2>
+__global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v, const float *w,
+                                                  const float *xi, const float *yi, const float *zi,
+                                                  float *xo, float *yo, float *zo,
+                                                  Spacing sp, Grid g, float substep)
+{
+    BQ_IJK(g.ni, g.nj, g.nk)
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && k > 1 && k < g.nk - 2)) return;
+    const float h = sp.h;
+    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk), make_field(v, g.ni, g.nj + 1, g.nk), make_field(w, g.ni, g.nj, g.nk + 1)};
+    Map3 in{make_field(xi, g.ni, g.nj, g.nk), make_field(yi, g.ni, g.nj, g.nk), make_field(zi, g.ni, g.nj, g.nk)};
+    f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+    f3 vl = get_velocity<P2>(vel, sp, pt);
+    f3 tp = mk3((vl.x > 0) ? pt.x - h : pt.x + h, (vl.y > 0) ? pt.y - h : pt.y + h, (vl.z > 0) ? pt.z - h : pt.z + h);
+    f3 tv = get_velocity<P2>(vel, sp, tp);
+    float ax = (vl.x - tv.x) / (pt.x - tp.x);
+    float ay = (vl.y - tv.y) / (pt.y - tp.y);
+    float az = (vl.z - tv.z) / (pt.z - tp.z);
+    f3 pn = mk3(dmc_axis(pt.x, vl.x, ax, substep), dmc_axis(pt.y, vl.y, ay, substep), dmc_axis(pt.z, vl.z, az, substep));
+    f3 r = map_at<P2>(in, sp, pn);
+    size_t id = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
+    xo[id] = r.x; yo[id] = r.y; zo[id] = r.z;
+}
+
+// ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
+template <bool P2, bool PT>
+__global__ __launch_bounds__(256) void advect_kernel(float *field, const float *field_init,
+                                                     const float *bx, const float *by, const float *bz,
+                                                     Spacing sp, Grid g, int dx, int dy, int dz)
+{
+    const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
+    BQ_IJK(nbi, nbj, nbk)
+    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < k && k < nbk - 3)) return;
+    const float h = sp.h;
+    Map3 back{make_field(bx, g.ni, g.nj, g.nk), make_field(by, g.ni, g.nj, g.nk), make_field(bz, g.ni, g.nj, g.nk)};
+    Field src = make_field(field_init, nbi, nbj, nbk);
+    Nine n = nine_setup(h, dx, dy, dz);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nk - h);
+    f3 c = nine_centre(n, i, j, k);
+    float sum = 0.f;
+    if (PT) {
+        f3 p0 = clamp3(map_at<P2>(back, sp, c), lo, hi);
+        sum += 1.0f * sample<P2>(src, sp, n.org, p0);
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            f3 p0 = clamp3(map_at<P2>(back, sp, nine_corner(n, c, ii)), lo, hi);
+            sum += 0.125f * sample<P2>(src, sp, n.org, p0);
+        }
+    }
+    f3 pc = clamp3(map_at<P2>(back, sp, c), lo, hi);
+    float value = sample<P2>(src, sp, n.org, pc);
+    field[(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum + 0.5f * value;
+}
+
+// ---- A7: doubleAdvect_kernel (GPU_kernel.cu:236-310) --------------------------------------
+template <bool P2, bool PT>
+__global__ __launch_bounds__(256) void double_advect_kernel(float *field, const float *prev,
+                                                            const float *bx, const float *by, const float *bz,
+                                                            const float *px, const float *py, const float *pz,
+                                                            Spacing sp, Grid g, int dx, int dy, int dz, float blend)
+{
+    const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
+    BQ_IJK(nbi, nbj, nbk)
+    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < k && k < nbk - 3)) return;
+    const float h = sp.h;
+    Map3 back{make_field(bx, g.ni, g.nj, g.nk), make_field(by, g.ni, g.nj, g.nk), make_field(bz, g.ni, g.nj, g.nk)};
+    Map3 bprev{make_field(px, g.ni, g.nj, g.nk), make_field(py, g.ni, g.nj, g.nk), make_field(pz, g.ni, g.nj, g.nk)};
+    Field src = make_field(prev, nbi, nbj, nbk);
+    Nine n = nine_setup(h, dx, dy, dz);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nk - h);
+    f3 c = nine_centre(n, i, j, k);
+    float sum = 0.f;
+    if (PT) {
+        f3 mid = clamp3(map_at<P2>(back, sp, c), lo, hi);
+        f3 fin = clamp3(map_at<P2>(bprev, sp, mid), lo, hi);
+        sum += 1.0f * sample<P2>(src, sp, n.org, fin);
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            f3 mid = clamp3(map_at<P2>(back, sp, nine_corner(n, c, ii)), lo, hi);
+            f3 fin = clamp3(map_at<P2>(bprev, sp, mid), lo, hi);
+            sum += 0.125f * sample<P2>(src, sp, n.org, fin);
+        }
+    }
+    f3 mid = clamp3(map_at<P2>(back, sp, c), lo, hi);
+    f3 fin = clamp3(map_at<P2>(bprev, sp, mid), lo, hi);
+    float value = sample<P2>(src, sp, n.org, fin);
+    float prev_value = 0.5f * (sum + value);
+    size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    field[id] = field[id] * blend + (1.0f - blend) * prev_value;
+}
+
+// blend == 1 fast path: field*1 + 0*prev == field + (+-0) for finite prev; same window.
+__global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, int dx, int dy, int dz)
+{
+    const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
+    BQ_IJK(nbi, nbj, nbk)
+    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < k && k < nbk - 3)) return;
+    size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    field[id] = field[id] + 0.0f;
+}
+
+// ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
+template <bool P2, bool PT>
+__global__ __launch_bounds__(256) void cumulate_kernel(const float *srcp, float *dst,
+                                                       const float *mx, const float *my, const float *mz,
+                                                       Spacing sp, Grid g, int dx, int dy, int dz, float coeff)
+{
+    const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
+    BQ_IJK(nbi, nbj, nbk)
+    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < k && k < nbk - 2)) return;
+    const float h = sp.h;
+    Map3 m{make_field(mx, g.ni, g.nj, g.nk), make_field(my, g.ni, g.nj, g.nk), make_field(mz, g.ni, g.nj, g.nk)};
+    Field src = make_field(srcp, nbi, nbj, nbk);
+    Nine n = nine_setup(h, dx, dy, dz);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nk);
+    f3 c = nine_centre(n, i, j, k);
+    float sum = 0.f;
+    if (PT) {
+        f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
+        sum += 1.0f * coeff * sample<P2>(src, sp, n.org, mp);
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            f3 mp = clamp3(map_at<P2>(m, sp, nine_corner(n, c, ii)), lo, hi);
+            sum += 0.125f * coeff * sample<P2>(src, sp, n.org, mp);
+        }
+    }
+    f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
+    float value = coeff * sample<P2>(src, sp, n.org, mp);
+    sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+    size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    dst[id] += sum;
+}
+
+// ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
+template <bool P2, bool PT>
+__global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, const float *init, float *err,
+                                                         const float *mx, const float *my, const float *mz,
+                                                         Spacing sp, Grid g, int dx, int dy, int dz)
+{
+    const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
+    BQ_IJK(nbi, nbj, nbk)
+    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < k && k < nbk - 2)) return;
+    const float h = sp.h;
+    Map3 m{make_field(mx, g.ni, g.nj, g.nk), make_field(my, g.ni, g.nj, g.nk), make_field(mz, g.ni, g.nj, g.nk)};
+    Field src = make_field(srcp, nbi, nbj, nbk);
+    Nine n = nine_setup(h, dx, dy, dz);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nk);
+    f3 c = nine_centre(n, i, j, k);
+    float sum = 0.f;
+    if (PT) {
+        f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
+        sum += 1.0f * sample<P2>(src, sp, n.org, mp);
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            f3 mp = clamp3(map_at<P2>(m, sp, nine_corner(n, c, ii)), lo, hi);
+            sum += 0.125f * sample<P2>(src, sp, n.org, mp);
+        }
+    }
+    f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
+    float value = sample<P2>(src, sp, n.org, mp);
+    sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+    size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    err[id] = sum - init[id];
+}
+
+// ---- A6: clampExtrema_kernel (GPU_kernel.cu:146-167) --------------------------------------
+__global__ __launch_bounds__(256) void clamp_box_kernel(const float *before, float *after, int ni, int nj, int nk)
+{
+    BQ_IJK(ni, nj, nk)
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1)) return;
+    const size_t sj = ni, sk = (size_t)ni * nj;
+    const size_t id = (size_t)i + sj * j + sk * k;
+    float mx = before[id], mn = mx;
+#pragma unroll
+    for (int kk = -1; kk <= 1; kk++)
+#pragma unroll
+        for (int jj = -1; jj <= 1; jj++)
+#pragma unroll
+            for (int ii = -1; ii <= 1; ii++) {
+                float b = before[id + (ptrdiff_t)ii + (ptrdiff_t)jj * (ptrdiff_t)sj + (ptrdiff_t)kk * (ptrdiff_t)sk];
+                if (b > mx) mx = b;
+                if (b < mn) mn = b;
+            }
+    after[id] = fminf(fmaxf(mn, after[id]), mx);
+}
+
+// ---- N2: estimate_kernel (GPU_kernel.cu:501-537) ------------------------------------------
+template <bool P2>
+__global__ __launch_bounds__(256) void estimate_kernel(float *dist,
+                                                       const float *xb, const float *yb, const float *zb,
+                                                       const float *xf, const float *yf, const float *zf,
+                                                       Spacing sp, Grid g)
+{
+    BQ_IJK(g.ni, g.nj, g.nk)
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && k > 1 && k < g.nk - 2)) return;
+    const float h = sp.h;
+    Map3 first{make_field(xb, g.ni, g.nj, g.nk), make_field(yb, g.ni, g.nj, g.nk), make_field(zb, g.ni, g.nj, g.nk)};
+    Map3 second{make_field(xf, g.ni, g.nj, g.nk), make_field(yf, g.ni, g.nj, g.nk), make_field(zf, g.ni, g.nj, g.nk)};
+    f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+    f3 back = map_at<P2>(first, sp, pt);
+    f3 fwd = map_at<P2>(second, sp, back);
+    float d_bf = (pt.x - fwd.x) * (pt.x - fwd.x) + (pt.y - fwd.y) * (pt.y - fwd.y) + (pt.z - fwd.z) * (pt.z - fwd.z);
+    f3 f2 = map_at<P2>(second, sp, pt);
+    f3 b2 = map_at<P2>(first, sp, f2);
+    float d_fb = (pt.x - b2.x) * (pt.x - b2.x) + (pt.y - b2.y) * (pt.y - b2.y) + (pt.z - b2.z) * (pt.z - b2.z);
+    dist[(size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k] = fmaxf(d_bf, d_fb);
+}
+
+// ---- N3: semilag_kernel (GPU_kernel.cu:206-233) -------------------------------------------
+template <bool P2>
+__global__ __launch_bounds__(256) void semilag_kernel(float *field, const float *field_src,
+                                                      const float *u, const float *v, const float *w,
+                                                      Spacing sp, Grid g, int dx, int dy, int dz, float cfldt, float dt)
+{
+    const int bi = g.ni + dx, bj = g.nj + dy, bk = g.nk + dz;
+    BQ_IJK(bi, bj, bk)
+    if (!(i > 1 && i < bi - 2 - dx && j > 1 && j < bj - 2 - dy && k > 1 && k < bk - 2 - dz)) return;
+    const float h = sp.h;
+    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk), make_field(v, g.ni, g.nj + 1, g.nk), make_field(w, g.ni, g.nj, g.nk + 1)};
+    Field src = make_field(field_src, bi, bj, bk);
+    f3 org = mk3(-(float)dx * 0.5f * h, -(float)dy * 0.5f * h, -(float)dz * 0.5f * h);
+    f3 hi = mk3((float)g.ni * h - h, (float)g.nj * h - h, (float)g.nk * h - h);
+    f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+    f3 pn = trace<P2>(vel, sp, hi, cfldt, dt, pt);
+    field[(size_t)i + (size_t)bi * j + (size_t)bi * bj * k] = sample<P2>(src, sp, org, pn);
+}
+
+// ---- host-side dispatch helpers -----------------------------------------------------------
+static bool dims_ok(int ni, int nj, int nk, const char *op)
+{
+    if (ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, op, "non-positive grid dims"); return false; }
+    // byte offsets are 32-bit in the buffer descriptors: (ni+1)*(nj+1)*(nk+1)*4 must fit
+    double bytes = 4.0 * (double)(ni + 1) * (double)(nj + 1) * (double)(nk + 1);
+    if (bytes >= 4294967296.0) { latch(FL_ERR_BAD_ARGUMENT, op, "field larger than 4 GiB"); return false; }
+    if (nk + 1 > 65535) { latch(FL_ERR_BAD_ARGUMENT, op, "nk too large for grid.z"); return false; }
+    return true;
+}
+
+#define BQ_DISPATCH2(KERNEL, P2V, PTV, GRID, ...)                                                           \
+    do {                                                                                                    \
+        hipStream_t st_ = rt().compute;                                                                     \
+        if (P2V) { if (PTV) KERNEL<true, true><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);                      \
+                   else     KERNEL<true, false><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); }                   \
+        else     { if (PTV) KERNEL<false, true><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);                     \
+                   else     KERNEL<false, false><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); }                  \
+        BQ_LAUNCH_CHECK(#KERNEL);                                                                           \
+    } while (0)
+
+#define BQ_DISPATCH1(KERNEL, P2V, GRID, ...)                                                                \
+    do {                                                                                                    \
+        hipStream_t st_ = rt().compute;                                                                     \
+        if (P2V) KERNEL<true><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);                                       \
+        else     KERNEL<false><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);                                      \
+        BQ_LAUNCH_CHECK(#KERNEL);                                                                           \
+    } while (0)
+
+static void advect_comp(float *f, const float *init, const float *bx, const float *by, const float *bz,
+                        Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
+{
+    BQ_DISPATCH2(advect_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, init, bx, by, bz, sp, g, dx, dy, dz);
+}
+static void cumulate_comp(const float *src, float *dst, const float *mx, const float *my, const float *mz,
+                          Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float coeff)
+{
+    BQ_DISPATCH2(cumulate_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, dst, mx, my, mz, sp, g, dx, dy, dz, coeff);
+}
+static void compensate_comp(const float *src, const float *init, float *err, const float *mx, const float *my, const float *mz,
+                            Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
+{
+    BQ_DISPATCH2(compensate_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, init, err, mx, my, mz, sp, g, dx, dy, dz);
+}
+static void double_comp(float *f, const float *prev, const float *bx, const float *by, const float *bz,
+                        const float *px, const float *py, const float *pz,
+                        Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float blend)
+{
+    if (blend == 1.0f && rt().opt_skip_unit_blend) {
+        unit_blend_kernel<<<grid_for(g.ni + dx, g.nj + dy, g.nk + dz), kBlock, 0, rt().compute>>>(f, g, dx, dy, dz);
+        BQ_LAUNCH_CHECK("unit_blend_kernel");
+        return;
+    }
+    BQ_DISPATCH2(double_advect_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, prev, bx, by, bz, px, py, pz, sp, g, dx, dy, dz, blend);
+}
+static void clamp_box(const float *before, float *after, int ni, int nj, int nk)
+{
+    clamp_box_kernel<<<grid_for(ni, nj, nk), kBlock, 0, rt().compute>>>(before, after, ni, nj, nk);
+    BQ_LAUNCH_CHECK("clamp_box_kernel");
+}
+
+} // namespace bq
+
+using namespace bq;
+
+#define BQ_ENTER(op, ...)                                                  \
+    if (!ensure_ready(op)) return;                                         \
+    if (!dims_ok(ni, nj, nk, op)) return;                                  \
+    {                                                                      \
+        const void *ptrs_[] = { __VA_ARGS__ };                             \
+        for (const void *p_ : ptrs_)                                       \
+            if (!p_) { latch(FL_ERR_BAD_ARGUMENT, op, "null device pointer"); return; } \
+    }
+
+extern "C" {
+
+void gpu_solve_forward(float *u, float *v, float *w, float *x_fwd, float *y_fwd, float *z_fwd,
+                       float h, int ni, int nj, int nk, float cfldt, float dt)
+{
+    BQ_ENTER("gpu_solve_forward", u, v, w, x_fwd, y_fwd, z_fwd)
+    BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_solve_forward");     // cfldt <= 0 would never terminate
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt);
+}
+
+void gpu_solve_backwardDMC(float *u, float *v, float *w, float *x_in, float *y_in, float *z_in,
+                           float *x_out, float *y_out, float *z_out,
+                           float h, int ni, int nj, int nk, float substep)
+{
+    BQ_ENTER("gpu_solve_backwardDMC", u, v, w, x_in, y_in, z_in, x_out, y_out, z_out)
+    BQ_REQUIRE(x_in != x_out && y_in != y_out && z_in != z_out, "gpu_solve_backwardDMC");
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep);
+}
+
+void gpu_advect_velocity(float *u, float *v, float *w, float *u_init, float *v_init, float *w_init,
+                         float *backward_x, float *backward_y, float *backward_z,
+                         float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_advect_velocity", u, v, w, u_init, v_init, w_init, backward_x, backward_y, backward_z)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    advect_comp(u, u_init, backward_x, backward_y, backward_z, sp, g, 1, 0, 0, is_point);
+    advect_comp(v, v_init, backward_x, backward_y, backward_z, sp, g, 0, 1, 0, is_point);
+    advect_comp(w, w_init, backward_x, backward_y, backward_z, sp, g, 0, 0, 1, is_point);
+}
+
+void gpu_advect_vel_double(float *u, float *v, float *w, float *utemp, float *vtemp, float *wtemp,
+                           float *backward_x, float *backward_y, float *backward_z,
+                           float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                           float h, int ni, int nj, int nk, bool is_point, float blend_coeff)
+{
+    BQ_ENTER("gpu_advect_vel_double", u, v, w, utemp, vtemp, wtemp, backward_x, backward_y, backward_z,
+             backward_xprev, backward_yprev, backward_zprev)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    double_comp(u, utemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 1, 0, 0, is_point, blend_coeff);
+    double_comp(v, vtemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 1, 0, is_point, blend_coeff);
+    double_comp(w, wtemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 1, is_point, blend_coeff);
+}
+
+void gpu_advect_field(float *field, float *field_init, float *backward_x, float *backward_y, float *backward_z,
+                      float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_advect_field", field, field_init, backward_x, backward_y, backward_z)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    advect_comp(field, field_init, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point);
+}
+
+void gpu_advect_field_double(float *field, float *field_prev, float *backward_x, float *backward_y, float *backward_z,
+                             float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                             float h, int ni, int nj, int nk, bool is_point, float blend_coeff)
+{
+    BQ_ENTER("gpu_advect_field_double", field, field_prev, backward_x, backward_y, backward_z,
+             backward_xprev, backward_yprev, backward_zprev)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    double_comp(field, field_prev, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 0, is_point, blend_coeff);
+}
+
+void gpu_accumulate_velocity(float *u_change, float *v_change, float *w_change,
+                             float *du_init, float *dv_init, float *dw_init,
+                             float *forward_x, float *forward_y, float *forward_z,
+                             float h, int ni, int nj, int nk, bool is_point, float coeff)
+{
+    BQ_ENTER("gpu_accumulate_velocity", u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    cumulate_comp(u_change, du_init, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point, coeff);
+    cumulate_comp(v_change, dv_init, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point, coeff);
+    cumulate_comp(w_change, dw_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, coeff);
+}
+
+void gpu_accumulate_field(float *field_change, float *dfield_init, float *forward_x, float *forward_y, float *forward_z,
+                          float h, int ni, int nj, int nk, bool is_point, float coeff)
+{
+    BQ_ENTER("gpu_accumulate_field", field_change, dfield_init, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    cumulate_comp(field_change, dfield_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point, coeff);
+}
+
+void gpu_estimate_distortion(float *du, float *x_init, float *y_init, float *z_init,
+                             float *x_fwd, float *y_fwd, float *z_fwd, float h, int ni, int nj, int nk)
+{
+    BQ_ENTER("gpu_estimate_distortion", du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    BQ_DISPATCH1(estimate_kernel, sp.pow2, grid_for(ni, nj, nk), du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd, sp, g);
+}
+
+void gpu_compensate_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+                             float *u_src, float *v_src, float *w_src,
+                             float *forward_x, float *forward_y, float *forward_z,
+                             float *backward_x, float *backward_y, float *backward_z,
+                             float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_compensate_velocity", u, v, w, du, dv, dw, u_src, v_src, w_src,
+             forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    const size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
+    // error at time 0 into *_src (GPU_kernel.cu:652-654)
+    compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point);
+    compensate_comp(v, dv, v_src, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point);
+    compensate_comp(w, dw, w_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point);
+    // d* <- uncompensated field (:656-658; clobbers the caller's `init`)
+    fl_memcpy_d2d(du, u, nu * sizeof(float));
+    fl_memcpy_d2d(dv, v, nv * sizeof(float));
+    fl_memcpy_d2d(dw, w, nw * sizeof(float));
+    // subtract half the back-mapped error (:659-661)
+    cumulate_comp(u_src, u, backward_x, backward_y, backward_z, sp, g, 1, 0, 0, is_point, -0.5f);
+    cumulate_comp(v_src, v, backward_x, backward_y, backward_z, sp, g, 0, 1, 0, is_point, -0.5f);
+    cumulate_comp(w_src, w, backward_x, backward_y, backward_z, sp, g, 0, 0, 1, is_point, -0.5f);
+    // limiter (:663-665)
+    clamp_box(du, u, ni + 1, nj, nk);
+    clamp_box(dv, v, ni, nj + 1, nk);
+    clamp_box(dw, w, ni, nj, nk + 1);
+}
+
+void gpu_compensate_field(float *u, float *du, float *u_src,
+                          float *forward_x, float *forward_y, float *forward_z,
+                          float *backward_x, float *backward_y, float *backward_z,
+                          float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_compensate_field", u, du, u_src, forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point);
+    fl_memcpy_d2d(du, u, (size_t)ni * nj * nk * sizeof(float));
+    cumulate_comp(u_src, u, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point, -0.5f);
+    clamp_box(du, u, ni, nj, nk);
+}
+
+void gpu_semilag(float *field, float *field_src, float *u, float *v, float *w,
+                 int dim_x, int dim_y, int dim_z, float h, int ni, int nj, int nk, float cfldt, float dt)
+{
+    BQ_ENTER("gpu_semilag", field, field_src, u, v, w)
+    BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_semilag");
+    BQ_REQUIRE((dim_x | dim_y | dim_z) == 0 || (dim_x + dim_y + dim_z) == 1, "gpu_semilag");
+    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    BQ_DISPATCH1(semilag_kernel, sp.pow2, grid_for(ni + dim_x, nj + dim_y, nk + dim_z), field, field_src, u, v, w, sp, g, dim_x, dim_y, dim_z, cfldt, dt);
+}
+
+void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
+{
+    BQ_ENTER("gpu_clamp_extrema_box", before, after)
+    clamp_box(before, after, ni, nj, nk);
+}
+
+} // extern "C"

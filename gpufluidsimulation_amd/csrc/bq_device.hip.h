@@ -1,0 +1,234 @@
+// bq_device.hip.h -- device-side building blocks of the gather ("semi-Lagrangian") family.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): every expression keeps the operand types and
+// association of the reference source (src/bimocq3D/GPU_kernel.cu:9-125) so that results are
+// bit-identical to oracle/bimocq_oracle.c.  The file is compiled with -ffp-contract=off; the
+// double-typed pieces of the reference (lerp, RK3 stage points) stay double here.
+//
+// gfx950 has no image/sampler hardware (__HIP_NO_IMAGE_SUPPORT), so "trilinear sampling" is
+// eight raw buffer loads + seven lerps.  Loads go through a buffer resource descriptor whose
+// num_records is the field's byte size: the hardware range check returns 0 for any corner that
+// falls outside the allocation (the oracle's `ld`), per dword, with no compare in the shader.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+
+namespace bq {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+
+// A dense x-fastest fp32 field as the kernels see it.
+struct Field {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int nx, ny;            // row pitch and slab pitch factor (elements)
+};
+
+__device__ __forceinline__ Field make_field(const float *p, int nx, int ny, int nz)
+{
+    Field f;
+    unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 4u;
+    f.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+    f.nx = nx; f.ny = ny;
+    return f;
+}
+
+__device__ __forceinline__ float ldf(const Field &f, unsigned byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(f.rsrc, byte_off, 0, 0));
+}
+
+// Grid spacing.  When h is a power of two (every BASELINE config: L=1, N=2^k) x/h == x*(1/h)
+// bit for bit, which removes three IEEE divisions (~11 VALU each) from every sample.
+struct Spacing {
+    float h, inv_h;
+    int pow2;
+};
+
+inline Spacing make_spacing(float h)
+{
+    int e = 0;
+    float m = frexpf(h, &e);
+    Spacing sp;
+    sp.h = h;
+    sp.inv_h = 1.0f / h;
+    sp.pow2 = (m == 0.5f) && (e > -100) && (e < 100);
+    return sp;
+}
+
+template <bool P2>
+__device__ __forceinline__ float div_h(float s, const Spacing &sp)
+{
+    if (P2) return s * sp.inv_h;
+    return s / sp.h;
+}
+
+// GPU_kernel.cu:9-12
+__device__ __forceinline__ float clampf(float a, float lo, float hi) { return fminf(fmaxf(lo, a), hi); }
+__device__ __forceinline__ f3 clamp3(f3 p, f3 lo, f3 hi)
+{
+    return mk3(clampf(p.x, lo.x, hi.x), clampf(p.y, lo.y, hi.y), clampf(p.z, lo.z, hi.z));
+}
+
+// GPU_kernel.cu:22-25 with the (1.0 - c) factor hoisted (it is exact to hoist: same value)
+__device__ __forceinline__ float lerp_w(float a, float b, float c, double omc)
+{
+    float cb = c * b;
+    return (float)(omc * (double)a + (double)cb);
+}
+
+// Cell + weights of one sample position (GPU_kernel.cu:45-51)
+struct Cell {
+    unsigned base;          // byte offset of corner 000 (wraps for negative indices -> out of range)
+    float fx, fy, fz;
+};
+
+template <bool P2>
+__device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off, f3 pos)
+{
+    float qx = div_h<P2>(pos.x - off.x, sp);
+    float qy = div_h<P2>(pos.y - off.y, sp);
+    float qz = div_h<P2>(pos.z - off.z, sp);
+    float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+    int i = (int)flx, j = (int)fly, k = (int)flz;
+    Cell c;
+    c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k;
+    int idx = i + f.nx * j + f.nx * f.ny * k;
+    c.base = (unsigned)idx * 4u;
+    return c;
+}
+
+// GPU_kernel.cu:27-41 + :53-61
+__device__ __forceinline__ float gather(const Field &f, const Cell &c)
+{
+    unsigned sj = (unsigned)f.nx * 4u, sk = (unsigned)f.nx * (unsigned)f.ny * 4u;
+    float v000 = ldf(f, c.base),           v001 = ldf(f, c.base + 4u);
+    float v010 = ldf(f, c.base + sj),      v011 = ldf(f, c.base + sj + 4u);
+    float v100 = ldf(f, c.base + sk),      v101 = ldf(f, c.base + sk + 4u);
+    float v110 = ldf(f, c.base + sk + sj), v111 = ldf(f, c.base + sk + sj + 4u);
+    double ox = 1.0 - (double)c.fx, oy = 1.0 - (double)c.fy, oz = 1.0 - (double)c.fz;
+    float l00 = lerp_w(v000, v001, c.fx, ox);
+    float l01 = lerp_w(v010, v011, c.fx, ox);
+    float l10 = lerp_w(v100, v101, c.fx, ox);
+    float l11 = lerp_w(v110, v111, c.fx, ox);
+    float m0 = lerp_w(l00, l01, c.fy, oy);
+    float m1 = lerp_w(l10, l11, c.fy, oy);
+    return lerp_w(m0, m1, c.fz, oz);
+}
+
+// GPU_kernel.cu:43-62 sample_buffer
+template <bool P2>
+__device__ __forceinline__ float sample(const Field &f, const Spacing &sp, f3 off, f3 pos)
+{
+    return gather(f, locate<P2>(f, sp, off, pos));
+}
+
+// three co-located fields (the x/y/z maps share cell and weights: GPU_kernel.cu:350-352 etc.)
+struct Map3 { Field x, y, z; };
+
+template <bool P2>
+__device__ __forceinline__ f3 map_at(const Map3 &m, const Spacing &sp, f3 pos)
+{
+    Cell c = locate<P2>(m.x, sp, mk3(0.f, 0.f, 0.f), pos);
+    return mk3(gather(m.x, c), gather(m.y, c), gather(m.z, c));
+}
+
+// MAC velocity (GPU_kernel.cu:64-72)
+struct Vel3 { Field u, v, w; };
+
+template <bool P2>
+__device__ __forceinline__ f3 get_velocity(const Vel3 &vel, const Spacing &sp, f3 pos)
+{
+    float mh = (float)(-0.5 * (double)sp.h);
+    return mk3(sample<P2>(vel.u, sp, mk3(mh, 0.f, 0.f), pos),
+               sample<P2>(vel.v, sp, mk3(0.f, mh, 0.f), pos),
+               sample<P2>(vel.w, sp, mk3(0.f, 0.f, mh), pos));
+}
+
+// GPU_kernel.cu:74-90 traceRK3
+template <bool P2>
+__device__ __forceinline__ f3 trace_rk3(const Vel3 &vel, const Spacing &sp, f3 hi, float dt, f3 pos)
+{
+    float c1 = (float)(2.0 / 9.0 * (double)dt);
+    float c2 = (float)(3.0 / 9.0 * (double)dt);
+    float c3 = (float)(4.0 / 9.0 * (double)dt);
+    f3 v1 = get_velocity<P2>(vel, sp, pos);
+    double hdt = 0.5 * (double)dt;
+    f3 m1 = mk3((float)((double)pos.x + hdt * (double)v1.x),
+                (float)((double)pos.y + hdt * (double)v1.y),
+                (float)((double)pos.z + hdt * (double)v1.z));
+    f3 v2 = get_velocity<P2>(vel, sp, m1);
+    double qdt = 0.75 * (double)dt;
+    f3 m2 = mk3((float)((double)pos.x + qdt * (double)v2.x),
+                (float)((double)pos.y + qdt * (double)v2.y),
+                (float)((double)pos.z + qdt * (double)v2.z));
+    f3 v3 = get_velocity<P2>(vel, sp, m2);
+    f3 out = mk3(pos.x + c1 * v1.x + c2 * v2.x + c3 * v3.x,
+                 pos.y + c1 * v1.y + c2 * v2.y + c3 * v3.y,
+                 pos.z + c1 * v1.z + c2 * v2.z + c3 * v3.z);
+    return clamp3(out, mk3(sp.h, sp.h, sp.h), hi);
+}
+
+// GPU_kernel.cu:92-125 trace
+template <bool P2>
+__device__ __forceinline__ f3 trace(const Vel3 &vel, const Spacing &sp, f3 hi, float cfldt, float dt, f3 pos)
+{
+    const bool fwd = dt > 0;
+    float T = fwd ? dt : -dt;
+    float t = 0.f, substep = cfldt;
+    f3 p = pos;
+    while (t < T) {
+        if (t + substep > T) substep = T - t;
+        p = trace_rk3<P2>(vel, sp, hi, fwd ? substep : -substep, p);
+        t += substep;
+    }
+    return p;
+}
+
+// expf of the DMC integrator: the oracle's orc_expf, operation for operation.
+__device__ __forceinline__ float exp_portable(float xf)
+{
+    double x = (double)xf;
+    if (!(x == x)) return xf;
+    if (x > 90.0) x = 90.0;
+    if (x < -110.0) x = -110.0;
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2HI = 6.93147180369123816490e-01;
+    const double LN2LO = 1.90821492927058770002e-10;
+    double kd = floor(x * LOG2E + 0.5);
+    double r = (x - kd * LN2HI) - kd * LN2LO;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    long long k = (long long)kd;
+    unsigned long long bits = (unsigned long long)(k + 1023) << 52;
+    double scale = __builtin_bit_cast(double, bits);
+    return (float)(p * scale);
+}
+
+// wave64 reductions (DPP/bpermute via __shfl_xor; 64 lanes)
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+} // namespace bq

@@ -1,0 +1,50 @@
+// bq_host.h -- host-side state shared by the C-ABI translation units (runtime, launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include "../../include/bimocq_gpu.h"
+
+namespace bq {
+
+struct Runtime {
+    bool        ready = false;
+    int         device = -1;
+    hipStream_t compute = nullptr;      // every operator launches here
+    hipStream_t halo = nullptr;         // ghost-plane exchange (multi-GPU), overlapped with interior work
+    int         err = FL_OK;
+    char        err_text[256] = {0};
+    int         opt_residual_stride = 0;
+    int         opt_skip_unit_blend = 1;
+    int         opt_jacobi_variant = 0;
+    // persistent workspace (replaces the cudaMalloc/cudaFree pair inside the reference's
+    // gpu_projection_jacobi, GPU_kernel.cu:1847-1850,1893-1894)
+    void  *scratch = nullptr;           // device: reduction partials
+    size_t scratch_bytes = 0;
+    void  *pinned = nullptr;            // host-pinned mirror for blocking reductions
+    size_t pinned_bytes = 0;
+};
+
+Runtime &rt();
+void latch(int code, const char *what, const char *detail);
+bool ensure_ready(const char *op);      // lazily fl_init(current device); false -> latched
+void *scratch(size_t bytes);            // device scratch of at least `bytes` (grows, never shrinks)
+void *pinned(size_t bytes);
+
+inline bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    latch(FL_ERR_HIP, what, hipGetErrorString(e));
+    return false;
+}
+
+} // namespace bq
+
+#define BQ_HIP(call) ::bq::hip_ok((call), #call)
+#define BQ_LAUNCH_CHECK(name) ::bq::hip_ok(hipGetLastError(), name)
+
+// argument validation shared by the launchers: positive dims, non-null pointers
+#define BQ_REQUIRE(cond, op)                                                        \
+    do {                                                                            \
+        if (!(cond)) { ::bq::latch(FL_ERR_BAD_ARGUMENT, op, #cond); return; }       \
+    } while (0)

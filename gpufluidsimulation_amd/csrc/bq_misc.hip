@@ -1,0 +1,206 @@
+// bq_misc.hip -- streaming operators: smoke source, buoyancy,
+// axpy-style helpers, identity-map initialisation and the device CFL max-reduction.
+#include "bq_device.hip.h"
+#include "bq_host.h"
+
+namespace bq {
+
+static const dim3 kBlock3(64, 4, 1);
+static inline dim3 grid3(int a, int b, int c) { return dim3((a + 63) / 64, (b + 3) / 4, c); }
+
+// norm3df restated as the correctly rounded sqrt of the double sum of squares (oracle: norm3)
+__device__ __forceinline__ float norm3(float x, float y, float z)
+{
+    return (float)sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);
+}
+
+// emit_smoke_velocity_kernel (GPU_kernel.cu:736-758); the u-face offset is used for all three
+// components, as in the reference
+__global__ __launch_bounds__(256) void emit_velocity_kernel(float *field, float h, int ni, int nj, int nk,
+                                                            float cx, float cy, float cz, float radius, float emiter)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (!(i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && k > 1 && k < nk - 2)) return;
+    float dx = (float)(((double)(float)i - 0.5) * (double)h - (double)cx);
+    float dy = (float)j * h - cy;
+    float dz = (float)k * h - cz;
+    if (norm3(dx, dy, dz) < radius) {
+        float theta = acosf(dy / hypotf(dy, dz));
+        float c8 = cosf((float)(8.0 * (double)theta));
+        field[(size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k)] = (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));
+    }
+}
+
+// emit_smoke_field_kernel (GPU_kernel.cu:760-780)
+__global__ __launch_bounds__(256) void emit_field_kernel(float *rho, float *T, float h, int ni, int nj, int nk,
+                                                         float cx, float cy, float cz, float radius, float density, float temperature)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (!(i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && k > 1 && k < nk - 2)) return;
+    float dx = (float)i * h - cx, dy = (float)j * h - cy, dz = (float)k * h - cz;
+    if (norm3(dx, dy, dz) < radius) {
+        size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+        rho[id] = density;
+        T[id] = temperature;
+    }
+}
+
+// add_buoyancy_kernel (GPU_kernel.cu:804-823) with the intended rho/T indexing
+__global__ __launch_bounds__(256) void buoyancy_kernel(float *__restrict__ v, const float *__restrict__ rho, const float *__restrict__ T,
+                                                       int ni, int nj, int nk, float alpha, float beta, float dt)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= ni || j < 1 || j >= nj) return;
+    const size_t c0 = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k), c1 = c0 - ni;
+    float d0 = rho[c0], T0 = T[c0], d1 = rho[c1], T1 = T[c1];
+    float f = (float)(0.5 * (double)dt * (double)(beta * (T0 + T1) - alpha * (d0 + d1)));
+    v[(size_t)i + (size_t)ni * ((size_t)j + (size_t)(nj + 1) * k)] += f;
+}
+
+// add_kernel / add_field_kernel / mad_kernel (GPU_kernel.cu:560-565, 878-883, 952-957), bounded
+__global__ __launch_bounds__(256) void add_kernel(float *__restrict__ f1, const float *__restrict__ f2, float coeff, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) f1[i] += coeff * f2[i];
+}
+__global__ __launch_bounds__(256) void add_field_kernel(float *out, const float *f1, const float *f2, float coeff, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f1[i] + coeff * f2[i];
+}
+__global__ __launch_bounds__(256) void mad_kernel(float *out, const float *f1, const float *f2, float c1, float c2, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = c1 * f1[i] + c2 * f2[i];
+}
+
+// MapperBaseGPU::init host loop (Mapping.cpp:310-324) on the device
+__global__ __launch_bounds__(256) void init_maps_kernel(float *x, float *y, float *z, float h, int ni, int nj, int nk)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= ni || j >= nj) return;
+    size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+    x[id] = (float)i * h; y[id] = (float)j * h; z[id] = (float)k * h;
+}
+
+// getCFL (BimocqGPUSolver.cpp:348-373) as a wave64 max-reduction over the three components
+__global__ __launch_bounds__(256) void max_abs3_partial_kernel(const float *__restrict__ u, size_t nu,
+                                                               const float *__restrict__ v, size_t nv,
+                                                               const float *__restrict__ w, size_t nw,
+                                                               float *__restrict__ part)
+{
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < nu; i += stride) m = fmaxf(m, fabsf(u[i]));
+    for (size_t i = t0; i < nv; i += stride) m = fmaxf(m, fabsf(v[i]));
+    for (size_t i = t0; i < nw; i += stride) m = fmaxf(m, fabsf(w[i]));
+    __shared__ float smax[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+}
+
+__global__ __launch_bounds__(256) void max_final_kernel(const float *__restrict__ part, int n, float floor_value, float *out)
+{
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+    __shared__ float smax[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        *out = (r > floor_value) ? r : floor_value;     // `if (fabs(x) > MaxVelocity)` starting from 1e-4
+    }
+}
+
+static inline int stream_blocks(size_t n)
+{
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+} // namespace bq
+
+using namespace bq;
+
+extern "C" {
+
+void gpu_emit_smoke(float *u, float *v, float *w, float *rho, float *T, float h, int ni, int nj, int nk,
+                    float centerX, float centerY, float centerZ, float radius, float density, float temperature, float emiter)
+{
+    if (!ensure_ready("gpu_emit_smoke")) return;
+    BQ_REQUIRE(u && v && w && rho && T && ni > 0 && nj > 0 && nk > 0 && nk < 65535, "gpu_emit_smoke");
+    hipStream_t st = rt().compute;
+    emit_velocity_kernel<<<grid3(ni + 1, nj, nk), kBlock3, 0, st>>>(u, h, ni + 1, nj, nk, centerX, centerY, centerZ, radius, emiter);
+    emit_velocity_kernel<<<grid3(ni, nj + 1, nk), kBlock3, 0, st>>>(v, h, ni, nj + 1, nk, centerX, centerY, centerZ, radius, 0.f);
+    emit_velocity_kernel<<<grid3(ni, nj, nk + 1), kBlock3, 0, st>>>(w, h, ni, nj, nk + 1, centerX, centerY, centerZ, radius, 0.f);
+    emit_field_kernel<<<grid3(ni, nj, nk), kBlock3, 0, st>>>(rho, T, h, ni, nj, nk, centerX, centerY, centerZ, radius, density, temperature);
+    BQ_LAUNCH_CHECK("gpu_emit_smoke");
+}
+
+void gpu_add_buoyancy(float *field, float *density, float *temperature, int ni, int nj, int nk, float alpha, float beta, float dt)
+{
+    if (!ensure_ready("gpu_add_buoyancy")) return;
+    BQ_REQUIRE(field && density && temperature && ni > 0 && nj > 0 && nk > 0 && nk < 65535, "gpu_add_buoyancy");
+    buoyancy_kernel<<<grid3(ni, nj, nk), kBlock3, 0, rt().compute>>>(field, density, temperature, ni, nj, nk, alpha, beta, dt);
+    BQ_LAUNCH_CHECK("buoyancy_kernel");
+}
+
+void gpu_add(float *field1, float *field2, float coeff, int number)
+{
+    if (!ensure_ready("gpu_add")) return;
+    BQ_REQUIRE(field1 && field2 && number >= 0, "gpu_add");
+    if (!number) return;
+    add_kernel<<<stream_blocks(number), 256, 0, rt().compute>>>(field1, field2, coeff, (size_t)number);
+    BQ_LAUNCH_CHECK("add_kernel");
+}
+
+void gpu_add_field(float *out, float *field1, float *field2, float coeff, int number)
+{
+    if (!ensure_ready("gpu_add_field")) return;
+    BQ_REQUIRE(out && field1 && field2 && number >= 0, "gpu_add_field");
+    if (!number) return;
+    add_field_kernel<<<stream_blocks(number), 256, 0, rt().compute>>>(out, field1, field2, coeff, (size_t)number);
+    BQ_LAUNCH_CHECK("add_field_kernel");
+}
+
+void gpu_mad(float *field, float *field1, float *field2, float coeff1, float coeff2, int number)
+{
+    if (!ensure_ready("gpu_mad")) return;
+    BQ_REQUIRE(field && field1 && field2 && number >= 0, "gpu_mad");
+    if (!number) return;
+    mad_kernel<<<stream_blocks(number), 256, 0, rt().compute>>>(field, field1, field2, coeff1, coeff2, (size_t)number);
+    BQ_LAUNCH_CHECK("mad_kernel");
+}
+
+void gpu_clamp_extrema(float *, float *, float *, float *, float *, int, int, int, int, int, int, float, float, float, float, float)
+{
+    latch(FL_ERR_UNSUPPORTED, "gpu_clamp_extrema", "out of scope: reflection-scheme limiter (buggy in the reference)");
+}
+
+void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk)
+{
+    if (!ensure_ready("gpu_init_maps")) return;
+    BQ_REQUIRE(x && y && z && ni > 0 && nj > 0 && nk > 0 && nk < 65535, "gpu_init_maps");
+    init_maps_kernel<<<grid3(ni, nj, nk), kBlock3, 0, rt().compute>>>(x, y, z, h, ni, nj, nk);
+    BQ_LAUNCH_CHECK("init_maps_kernel");
+}
+
+float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int nj, int nk)
+{
+    if (!ensure_ready("gpu_max_abs3")) return 0.f;
+    if (!u || !v || !w || ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, "gpu_max_abs3", "bad argument"); return 0.f; }
+    const int blocks = 1024;
+    float *part = (float *)scratch((blocks + 16) * sizeof(float));
+    float *host = (float *)pinned(64);
+    if (!part || !host) return 0.f;
+    hipStream_t st = rt().compute;
+    const size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
+    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(u, nu, v, nv, w, nw, part);
+    max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 1e-4f, part + blocks);
+    BQ_LAUNCH_CHECK("max_abs3");
+    BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipStreamSynchronize(st));
+    return host[0];
+}
+
+} // extern "C"

@@ -1,0 +1,429 @@
+// bq_project.hip -- pressure projection: divergence, Jacobi
+// sweeps, gradient subtraction, residual norms, viscous diffusion sweeps.
+//
+// The Jacobi sweep is THE roofline kernel of this path: 12 algorithmic bytes per voxel per
+// sweep (read p, read div, write p').  jacobi_tile_kernel stages each p plane once through
+// LDS (tile + one-deep halo), marches along k with the k-1 / k / k+1 centre values in
+// registers, and moves everything as 16-byte vectors; see DESIGN.md "Jacobi kernel".
+// Summation order is the reference's (GPU_kernel.cu:1834), so results are bit-identical.
+#include "bq_device.hip.h"
+#include "bq_host.h"
+
+namespace bq {
+
+// ---- divergence_kernel (GPU_kernel.cu:967-985) --------------------------------------------
+__global__ __launch_bounds__(256) void divergence_kernel(const float *__restrict__ u, const float *__restrict__ v,
+                                                         const float *__restrict__ w, float *__restrict__ div,
+                                                         int ni, int nj, int nk, float halfrdx)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= ni || j >= nj) return;
+    const size_t iu = (size_t)i + (size_t)(ni + 1) * ((size_t)j + (size_t)nj * k);
+    const size_t iv = (size_t)i + (size_t)ni * ((size_t)j + (size_t)(nj + 1) * k);
+    const size_t ic = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+    float ul = u[iu], ur = u[iu + 1];
+    float vf = v[iv], vb = v[iv + ni];
+    float wd = w[ic], wu = w[ic + (size_t)ni * nj];
+    div[ic] = halfrdx * ((ur - ul) + (vb - vf) + (wu - wd));
+}
+
+// ---- gradient_kernel x3 fused (GPU_kernel.cu:1024-1041, launches :1881-1891) -------------
+// All three components update the same cell window 2..n-1, so one pass reads p once.
+__global__ __launch_bounds__(256) void gradient_kernel(float *__restrict__ u, float *__restrict__ v, float *__restrict__ w,
+                                                       const float *__restrict__ p, int ni, int nj, int nk, float halfrdx)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i < 2 || i >= ni || j < 2 || j >= nj || k < 2) return;
+    const size_t ic = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+    const float p0 = p[ic];
+    const size_t iu = (size_t)i + (size_t)(ni + 1) * ((size_t)j + (size_t)nj * k);
+    const size_t iv = (size_t)i + (size_t)ni * ((size_t)j + (size_t)(nj + 1) * k);
+    u[iu] -= halfrdx * (p0 - p[ic - 1]);
+    v[iv] -= halfrdx * (p0 - p[ic - ni]);
+    w[ic] -= halfrdx * (p0 - p[ic - (size_t)ni * nj]);
+}
+
+// ---- generic Jacobi sweep: any dims, one thread per cell (GPU_kernel.cu:1819-1837) --------
+__global__ __launch_bounds__(256) void jacobi_generic_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                             float *__restrict__ out, int ni, int nj, int nk,
+                                                             float alpha, float beta)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1)) return;
+    const size_t sj = ni, sk = (size_t)ni * nj;
+    const size_t id = (size_t)i + sj * j + sk * k;
+    out[id] = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk] + alpha * div[id]) * beta;
+}
+
+// ---- LDS-tiled, k-marching Jacobi sweep -----------------------------------------------------
+// Block = 256 threads.  Tile = TX (= 4*TXV) floats in x by TY (= R*256/TXV) rows in y; the block
+// marches over `kchunk` planes.  Per plane each thread owns R float4 of the tile: it loads them
+// once from HBM (as plane k+1), keeps them in registers while they serve as k+1, k and k-1, and
+// publishes them to LDS when they are plane k so that neighbours can read x+-1 / y+-1.
+// LDS rows carry a 4-float pad on each side: the x halo column sits at pad[3] / pad'[0] and the
+// 16-byte alignment of the interior is kept.
+template <int TXV, int R>
+struct JTile {
+    static constexpr int RP = 256 / TXV;        // rows per pass
+    static constexpr int TY = RP * R;
+    static constexpr int TX = TXV * 4;
+    static constexpr int LW = TX + 8;           // LDS row pitch (floats)
+    static constexpr int PLANE = (TY + 2) * LW; // floats per LDS plane
+};
+
+template <int TXV, int R>
+__global__ __launch_bounds__(256) void jacobi_tile_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                          float *__restrict__ out, int nx, int ny, int nz,
+                                                          int kchunk, float alpha, float beta)
+{
+    using T = JTile<TXV, R>;
+    __shared__ __attribute__((aligned(16))) float lds[2][T::PLANE];
+
+    const int tid = threadIdx.x;
+    const int lx = tid % TXV, rp = tid / TXV;
+    const int x0 = blockIdx.x * T::TX, j0 = blockIdx.y * T::TY;
+    const int kbeg = max(1, (int)blockIdx.z * kchunk);
+    const int kend = min(nz - 1, (int)blockIdx.z * kchunk + kchunk);
+    if (kbeg >= kend) return;
+
+    const int x = x0 + 4 * lx;                  // first column of this thread's float4 (nx % 4 == 0)
+    const bool xin = x < nx;
+    const size_t sj = nx, sk = (size_t)nx * ny;
+
+    // halo assignments: two extra rows (j0-1, j0+TY) as float4, two extra columns as scalars
+    const bool hrow_thread = tid < 2 * TXV;
+    const int hr_row = (tid / TXV) ? T::TY : -1;
+    const int hr_j = j0 + hr_row;
+    const int hr_x = x0 + 4 * (tid % TXV);
+    const bool hr_ok = hrow_thread && hr_j >= 0 && hr_j < ny && hr_x < nx;
+    const int hc_id = tid - (256 - 2 * (T::TY + 2));           // >= 0 for the column-halo threads
+    const bool hcol_thread = hc_id >= 0;
+    const int hc_side = hcol_thread ? hc_id / (T::TY + 2) : 0;  // 0 = left, 1 = right
+    const int hc_row = hcol_thread ? hc_id % (T::TY + 2) - 1 : 0;
+    const int hc_j = j0 + hc_row;
+    const int hc_x = hc_side ? x0 + T::TX : x0 - 1;
+    const bool hc_ok = hcol_thread && hc_j >= 0 && hc_j < ny && hc_x >= 0 && hc_x < nx;
+
+    float4 pm[R], pc[R], pn[R];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // prologue: plane kbeg-1 -> pm (own only), plane kbeg -> pc + LDS[0] (own + halos)
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const int j = j0 + rp + m * T::RP;
+        const bool ok = xin && j < ny;
+        const size_t g = (size_t)x + sj * j;
+        pm[m] = ok ? *reinterpret_cast<const float4 *>(p + g + sk * (kbeg - 1)) : zero4;
+        pc[m] = ok ? *reinterpret_cast<const float4 *>(p + g + sk * kbeg) : zero4;
+    }
+    {
+        float4 hr = hr_ok ? *reinterpret_cast<const float4 *>(p + (size_t)hr_x + sj * hr_j + sk * kbeg) : zero4;
+        float hc = hc_ok ? p[(size_t)hc_x + sj * hc_j + sk * kbeg] : 0.f;
+        float *L = lds[0];
+#pragma unroll
+        for (int m = 0; m < R; m++)
+            *reinterpret_cast<float4 *>(L + (rp + m * T::RP + 1) * T::LW + 4 + 4 * lx) = pc[m];
+        if (hrow_thread) *reinterpret_cast<float4 *>(L + (hr_row + 1) * T::LW + 4 + 4 * (tid % TXV)) = hr;
+        if (hcol_thread) L[(hc_row + 1) * T::LW + (hc_side ? 4 + T::TX : 3)] = hc;
+    }
+
+    int cur = 0;
+    for (int k = kbeg; k < kend; k++) {
+        // (1) issue the loads of plane k+1 (own + halos) and div(k)
+        float4 dv[R];
+        const bool last = (k + 1 >= nz);       // never true (kend <= nz-1) but keeps loads in range
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int j = j0 + rp + m * T::RP;
+            const bool ok = xin && j < ny;
+            const size_t g = (size_t)x + sj * j;
+            pn[m] = (ok && !last) ? *reinterpret_cast<const float4 *>(p + g + sk * (k + 1)) : zero4;
+            dv[m] = ok ? *reinterpret_cast<const float4 *>(div + g + sk * k) : zero4;
+        }
+        float4 hr = (hr_ok && !last) ? *reinterpret_cast<const float4 *>(p + (size_t)hr_x + sj * hr_j + sk * (k + 1)) : zero4;
+        float hc = (hc_ok && !last) ? p[(size_t)hc_x + sj * hc_j + sk * (k + 1)] : 0.f;
+
+        // (2) plane k is complete in LDS[cur]
+        __syncthreads();
+        const float *L = lds[cur];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int row = rp + m * T::RP;
+            const int j = j0 + row;
+            const float *c = L + (row + 1) * T::LW + 4 + 4 * lx;
+            const float left = c[-1], right = c[4];
+            const float4 fr = *reinterpret_cast<const float4 *>(c - T::LW);   // j-1
+            const float4 bk = *reinterpret_cast<const float4 *>(c + T::LW);   // j+1
+            const float4 q = pc[m];
+            float4 o;
+            // ((((((l + r) + f) + b) + d) + u) + alpha*div) * beta   -- GPU_kernel.cu:1834
+            o.x = (left + q.y + fr.x + bk.x + pm[m].x + pn[m].x + alpha * dv[m].x) * beta;
+            o.y = (q.x + q.z + fr.y + bk.y + pm[m].y + pn[m].y + alpha * dv[m].y) * beta;
+            o.z = (q.y + q.w + fr.z + bk.z + pm[m].z + pn[m].z + alpha * dv[m].z) * beta;
+            o.w = (q.z + right + fr.w + bk.w + pm[m].w + pn[m].w + alpha * dv[m].w) * beta;
+            if (xin && j >= 1 && j < ny - 1) {
+                float *dst = out + (size_t)x + sj * j + sk * k;
+                if (x >= 4 && x + 4 < nx) {
+                    *reinterpret_cast<float4 *>(dst) = o;
+                } else {                        // the float4 touches the x boundary: interior lanes only
+                    if (x >= 1) dst[0] = o.x;
+                    dst[1] = o.y;
+                    dst[2] = o.z;
+                    if (x + 3 < nx - 1) dst[3] = o.w;
+                }
+            }
+        }
+
+        // (3) publish plane k+1 to the other LDS buffer, rotate registers
+        float *Ln = lds[cur ^ 1];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            *reinterpret_cast<float4 *>(Ln + (rp + m * T::RP + 1) * T::LW + 4 + 4 * lx) = pn[m];
+            pm[m] = pc[m];
+            pc[m] = pn[m];
+        }
+        if (hrow_thread) *reinterpret_cast<float4 *>(Ln + (hr_row + 1) * T::LW + 4 + 4 * (tid % TXV)) = hr;
+        if (hcol_thread) Ln[(hc_row + 1) * T::LW + (hc_side ? 4 + T::TX : 3)] = hc;
+        cur ^= 1;
+    }
+}
+
+// ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
+// update_residual_kernel / calc_poisson_value arithmetic (GPU_kernel.cu:1048-1060,1239-1249);
+// the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
+__global__ __launch_bounds__(256) void residual_partial_kernel(const float *__restrict__ div, const float *__restrict__ p,
+                                                               int ni, int nj, int nk,
+                                                               double *__restrict__ part_sum, float *__restrict__ part_max)
+{
+    const size_t sj = ni, sk = (size_t)ni * nj;
+    const size_t total = sk * nk;
+    double s = 0.0;
+    float mx = 0.f;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int i = (int)(id % sj), j = (int)((id / sj) % nj), k = (int)(id / sk);
+        if (i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1) {
+            float ax = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk]) - p[id] * 6;
+            float r = div[id] - ax;
+            s += (double)r * (double)r;
+            mx = fmaxf(mx, fabsf(r));
+        }
+    }
+    __shared__ double ssum[4];
+    __shared__ float smax[4];
+    s = wave_sum(s);
+    mx = wave_max(mx);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { ssum[wave] = s; smax[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = ((ssum[0] + ssum[1]) + ssum[2]) + ssum[3];
+        part_max[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void residual_final_kernel(const double *__restrict__ part_sum, const float *__restrict__ part_max,
+                                                             int nparts, double *out_sum, float *out_max,
+                                                             float *dbg_sum, float *dbg_max)
+{
+    double s = 0.0;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s += part_sum[i]; mx = fmaxf(mx, part_max[i]); }
+    __shared__ double ssum[4];
+    __shared__ float smax[4];
+    s = wave_sum(s);
+    mx = wave_max(mx);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { ssum[wave] = s; smax[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = ((ssum[0] + ssum[1]) + ssum[2]) + ssum[3];
+        float m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        if (out_sum) *out_sum = tot;
+        if (out_max) *out_max = m;
+        if (dbg_sum) *dbg_sum = (float)tot;
+        if (dbg_max) *dbg_max = m;
+    }
+}
+
+// ---- diffuse_field_kernel (GPU_kernel.cu:834-853) ------------------------------------------
+__global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ field, const float *__restrict__ in,
+                                                      float *__restrict__ out, int ni, int nj, int nk, float coef)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1)) return;
+    const size_t sj = ni, sk = (size_t)ni * nj;
+    const size_t id = (size_t)i + sj * j + sk * k;
+    float s = in[id - 1] + in[id + 1] + in[id - sj] + in[id + sj] + in[id - sk] + in[id + sk];
+    out[id] = (field[id] + coef * s) / (1.0f + 6.0f * coef);
+}
+
+static const dim3 kBlock2(64, 4, 1);
+static inline dim3 grid2(int a, int b, int c) { return dim3((a + 63) / 64, (b + 3) / 4, c); }
+
+static bool dims_ok(int ni, int nj, int nk, const char *op)
+{
+    if (ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, op, "non-positive grid dims"); return false; }
+    double bytes = 4.0 * (double)(ni + 1) * (double)(nj + 1) * (double)(nk + 1);
+    if (bytes >= 4294967296.0) { latch(FL_ERR_BAD_ARGUMENT, op, "field larger than 4 GiB"); return false; }
+    if (nk + 1 > 65535) { latch(FL_ERR_BAD_ARGUMENT, op, "nk too large for grid.z"); return false; }
+    return true;
+}
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// One Jacobi sweep in -> out on the compute stream.
+static void jacobi_sweep(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
+{
+    if (ni < 3 || nj < 3 || nk < 3) return;         // no interior
+    int variant = rt().opt_jacobi_variant;
+    const bool tile_ok = (ni % 4 == 0) && ni >= 32 && aligned16(in) && aligned16(div) && aligned16(out);
+    if (variant == 0) variant = tile_ok ? 2 : 1;
+    if (variant == 2 && !tile_ok) variant = 1;
+    hipStream_t st = rt().compute;
+    if (variant == 1) {
+        jacobi_generic_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(in, div, out, ni, nj, nk, alpha, beta);
+        BQ_LAUNCH_CHECK("jacobi_generic_kernel");
+        return;
+    }
+    // tile geometry: 256-wide rows when the row is long enough, else 128-wide
+    const bool wide = ni > 128;
+    const int TX = wide ? 256 : 128, TY = wide ? 16 : 32;
+    const int bx = (ni + TX - 1) / TX, by = (nj + TY - 1) / TY;
+    // k-chunks: enough blocks to fill 256 CUs x 2 resident blocks, at least 8 planes per chunk
+    int want = (1024 + bx * by - 1) / (bx * by);
+    int kchunk = (nk + want - 1) / want;
+    if (kchunk < 8) kchunk = 8;
+    const int bz = (nk + kchunk - 1) / kchunk;
+    dim3 grid(bx, by, bz);
+    if (wide) jacobi_tile_kernel<64, 4><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta);
+    else      jacobi_tile_kernel<32, 4><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta);
+    BQ_LAUNCH_CHECK("jacobi_tile_kernel");
+}
+
+static const int kResidualBlocks = 1024;
+
+static void residual_norms_async(const float *div, const float *p, int ni, int nj, int nk,
+                                 double *d_sum, float *d_max, float *dbg_sum, float *dbg_max)
+{
+    char *ws = (char *)scratch(kResidualBlocks * (sizeof(double) + sizeof(float)) + 64);
+    if (!ws) return;
+    double *ps = (double *)ws;
+    float *pm = (float *)(ws + kResidualBlocks * sizeof(double));
+    hipStream_t st = rt().compute;
+    residual_partial_kernel<<<kResidualBlocks, 256, 0, st>>>(div, p, ni, nj, nk, ps, pm);
+    BQ_LAUNCH_CHECK("residual_partial_kernel");
+    residual_final_kernel<<<1, 256, 0, st>>>(ps, pm, kResidualBlocks, d_sum, d_max, dbg_sum, dbg_max);
+    BQ_LAUNCH_CHECK("residual_final_kernel");
+}
+
+} // namespace bq
+
+using namespace bq;
+
+#define BQ_ENTER(op, ...)                                                  \
+    if (!ensure_ready(op)) return;                                         \
+    if (!dims_ok(ni, nj, nk, op)) return;                                  \
+    {                                                                      \
+        const void *ptrs_[] = { __VA_ARGS__ };                             \
+        for (const void *p_ : ptrs_)                                       \
+            if (!p_) { latch(FL_ERR_BAD_ARGUMENT, op, "null device pointer"); return; } \
+    }
+
+extern "C" {
+
+void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float halfrdx)
+{
+    BQ_ENTER("gpu_divergence", u, v, w, div)
+    divergence_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, div, ni, nj, nk, halfrdx);
+    BQ_LAUNCH_CHECK("divergence_kernel");
+}
+
+int gpu_jacobi_sweeps(float *p, const float *div, float *p_temp, int ni, int nj, int nk, int sweeps, float alpha, float beta)
+{
+    if (!ensure_ready("gpu_jacobi_sweeps")) return 0;
+    if (!dims_ok(ni, nj, nk, "gpu_jacobi_sweeps")) return 0;
+    if (!p || !div || !p_temp || p == p_temp) { latch(FL_ERR_BAD_ARGUMENT, "gpu_jacobi_sweeps", "null or aliased buffers"); return 0; }
+    float *in = p, *out = p_temp;
+    for (int s = 0; s < sweeps; s++) {
+        jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta);
+        float *t = in; in = out; out = t;
+    }
+    return in == p ? 0 : 1;
+}
+
+void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float halfrdx)
+{
+    BQ_ENTER("gpu_gradient", u, v, w, p)
+    gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, p, ni, nj, nk, halfrdx);
+    BQ_LAUNCH_CHECK("gradient_kernel");
+}
+
+void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk, double *sum_sq, float *max_abs)
+{
+    BQ_ENTER("gpu_residual_norms", div, p)
+    char *host = (char *)pinned(64);
+    char *dev = (char *)scratch(kResidualBlocks * 12 + 64 + 64);
+    if (!host || !dev) return;
+    double *d_sum = (double *)(dev + kResidualBlocks * 12 + 64);
+    float *d_max = (float *)(d_sum + 1);
+    residual_norms_async(div, p, ni, nj, nk, d_sum, d_max, nullptr, nullptr);
+    BQ_HIP(hipMemcpyAsync(host, d_sum, 16, hipMemcpyDeviceToHost, rt().compute));
+    BQ_HIP(hipStreamSynchronize(rt().compute));
+    if (sum_sq) *sum_sq = *(double *)host;
+    if (max_abs) *max_abs = *(float *)(host + 8);
+}
+
+// GPU_kernel.cu:1839-1895.  iter sweeps are specified, iterate iter-1 is what the reference
+// applies and leaves in p -> run iter-1 sweeps and make sure the result is in p.
+void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *p_temp, float *debugParam,
+                           int ni, int nj, int nk, int iter, float halfrdx, float alpha, float beta)
+{
+    BQ_ENTER("gpu_projection_jacobi", u, v, w, div, p, p_temp)
+    BQ_REQUIRE(p != p_temp && iter >= 0, "gpu_projection_jacobi");
+    hipStream_t st = rt().compute;
+    divergence_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(u, v, w, div, ni, nj, nk, halfrdx);
+    BQ_LAUNCH_CHECK("divergence_kernel");
+    const int stride = rt().opt_residual_stride;
+    const bool dbg = debugParam != nullptr && stride > 0;
+    float *in = p, *out = p_temp;
+    for (int it = 0; it + 1 < iter; it++) {
+        if (dbg && it % stride == 0 && it < 2000)
+            residual_norms_async(div, in, ni, nj, nk, nullptr, nullptr, debugParam + it, debugParam + 2000 + it);
+        jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta);
+        float *t = in; in = out; out = t;
+    }
+    if (dbg && iter > 0 && (iter - 1) % stride == 0 && iter - 1 < 2000)
+        residual_norms_async(div, in, ni, nj, nk, nullptr, nullptr, debugParam + iter - 1, debugParam + 2000 + iter - 1);
+    if (in != p) fl_memcpy_d2d(p, in, (size_t)ni * nj * nk * sizeof(float));
+    gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(u, v, w, p, ni, nj, nk, halfrdx);
+    BQ_LAUNCH_CHECK("gradient_kernel");
+}
+
+// GPU_kernel.cu:855-876
+void gpu_diffuse_field(float *field, float *fieldTemp0, float *filedTemp1, int ni, int nj, int nk, int iter, float coef)
+{
+    BQ_ENTER("gpu_diffuse_field", field, fieldTemp0, filedTemp1)
+    BQ_REQUIRE(field != fieldTemp0 && field != filedTemp1 && fieldTemp0 != filedTemp1 && iter >= 0, "gpu_diffuse_field");
+    const size_t bytes = (size_t)ni * nj * nk * sizeof(float);
+    float *in = fieldTemp0, *out = filedTemp1;
+    fl_memcpy_d2d(in, field, bytes);
+    for (int it = 0; it < iter; it++) {
+        diffuse_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(field, in, out, ni, nj, nk, coef);
+        BQ_LAUNCH_CHECK("diffuse_kernel");
+        float *t = out; out = in; in = t;
+    }
+    fl_memcpy_d2d(field, out, bytes);
+}
+
+void gpu_conjugate_gradient(float *, float *, float *, float *, float *, float *, float *, float *, int, int, int, int, float)
+{
+    latch(FL_ERR_UNSUPPORTED, "gpu_conjugate_gradient", "out of scope: alternative solver compiled out in the reference");
+}
+
+void gpu_multi_grid_conjugate_gradient(float *, float *, float *, double *, double *, double *, double *, double *, double *,
+                                       double *, struct SCoarseLevelInfo *, int, int, double)
+{
+    latch(FL_ERR_UNSUPPORTED, "gpu_multi_grid_conjugate_gradient", "not built yet (SURVEY 8f N1)");
+}
+
+} // extern "C"

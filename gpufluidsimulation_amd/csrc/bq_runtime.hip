@@ -1,0 +1,210 @@
+// bq_runtime.hip -- the fl_* runtime mini-ABI (include/bimocq_gpu.h, section 2).
+// Replaces the raw CUDA runtime calls of the reference's gpuMapper
+// (src/bimocq3D/GPU_Advection.h:214-326): device selection, zero-filled allocation,
+// copies, event timing -- plus the error latch the reference lacks.
+#include "bq_host.h"
+#include <cstring>
+#include <mutex>
+
+namespace bq {
+
+static Runtime g_rt;
+static std::mutex g_mu;
+
+Runtime &rt() { return g_rt; }
+
+void latch(int code, const char *what, const char *detail)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_rt.err != FL_OK) return;      // keep the FIRST failure
+    g_rt.err = code;
+    snprintf(g_rt.err_text, sizeof g_rt.err_text, "%s: %s", what ? what : "?", detail ? detail : "");
+}
+
+bool ensure_ready(const char *op)
+{
+    if (g_rt.ready) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (fl_init(dev) != FL_OK) { (void)op; return false; }
+    return true;
+}
+
+void *scratch(size_t bytes)
+{
+    if (g_rt.scratch_bytes >= bytes) return g_rt.scratch;
+    if (g_rt.scratch) { (void)hipStreamSynchronize(g_rt.compute); (void)hipFree(g_rt.scratch); g_rt.scratch = nullptr; }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (!BQ_HIP(hipMalloc(&g_rt.scratch, want))) { g_rt.scratch_bytes = 0; return nullptr; }
+    g_rt.scratch_bytes = want;
+    return g_rt.scratch;
+}
+
+void *pinned(size_t bytes)
+{
+    if (g_rt.pinned_bytes >= bytes) return g_rt.pinned;
+    if (g_rt.pinned) { (void)hipHostFree(g_rt.pinned); g_rt.pinned = nullptr; }
+    size_t want = bytes < (1u << 16) ? (1u << 16) : bytes;
+    if (!BQ_HIP(hipHostMalloc(&g_rt.pinned, want, hipHostMallocDefault))) { g_rt.pinned_bytes = 0; return nullptr; }
+    g_rt.pinned_bytes = want;
+    return g_rt.pinned;
+}
+
+} // namespace bq
+
+using bq::g_rt;
+
+extern "C" {
+
+int fl_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        bq::latch(FL_ERR_NO_DEVICE, "fl_init", "no HIP device visible (this library has no CPU fallback)");
+        return FL_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        bq::latch(FL_ERR_BAD_ARGUMENT, "fl_init", "device index out of range");
+        return FL_ERR_BAD_ARGUMENT;
+    }
+    if (g_rt.ready && g_rt.device == device) return FL_OK;
+    if (g_rt.ready) fl_shutdown();
+    if (!BQ_HIP(hipSetDevice(device))) return FL_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (!BQ_HIP(hipGetDeviceProperties(&prop, device))) return FL_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        bq::latch(FL_ERR_NO_DEVICE, "fl_init: kernels are built for gfx950 only, device is", prop.gcnArchName);
+        return FL_ERR_NO_DEVICE;
+    }
+    if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.compute, hipStreamNonBlocking))) return FL_ERR_HIP;
+    if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.halo, hipStreamNonBlocking))) return FL_ERR_HIP;
+    g_rt.device = device;
+    g_rt.ready = true;
+    return FL_OK;
+}
+
+void fl_shutdown(void)
+{
+    if (!g_rt.ready) return;
+    (void)hipStreamSynchronize(g_rt.compute);
+    (void)hipStreamSynchronize(g_rt.halo);
+    if (g_rt.scratch) (void)hipFree(g_rt.scratch);
+    if (g_rt.pinned) (void)hipHostFree(g_rt.pinned);
+    (void)hipStreamDestroy(g_rt.compute);
+    (void)hipStreamDestroy(g_rt.halo);
+    g_rt.scratch = nullptr; g_rt.scratch_bytes = 0;
+    g_rt.pinned = nullptr; g_rt.pinned_bytes = 0;
+    g_rt.compute = nullptr; g_rt.halo = nullptr;
+    g_rt.ready = false; g_rt.device = -1;
+}
+
+void *fl_malloc(size_t bytes)
+{
+    if (!bq::ensure_ready("fl_malloc")) return nullptr;
+    void *p = nullptr;
+    if (!BQ_HIP(hipMalloc(&p, bytes ? bytes : 4))) return nullptr;
+    if (!BQ_HIP(hipMemsetAsync(p, 0, bytes ? bytes : 4, g_rt.compute))) { (void)hipFree(p); return nullptr; }
+    return p;
+}
+
+void fl_free(void *p)
+{
+    if (!p) return;
+    if (g_rt.ready) (void)hipStreamSynchronize(g_rt.compute);
+    BQ_HIP(hipFree(p));
+}
+
+void fl_memset(void *dst, int value, size_t bytes)
+{
+    if (!bq::ensure_ready("fl_memset")) return;
+    BQ_REQUIRE(dst != nullptr || bytes == 0, "fl_memset");
+    if (bytes) BQ_HIP(hipMemsetAsync(dst, value, bytes, g_rt.compute));
+}
+
+void fl_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    if (!bq::ensure_ready("fl_memcpy_h2d")) return;
+    BQ_REQUIRE((dst && src) || bytes == 0, "fl_memcpy_h2d");
+    if (!bytes) return;
+    BQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_rt.compute));
+    BQ_HIP(hipStreamSynchronize(g_rt.compute));
+}
+
+void fl_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    if (!bq::ensure_ready("fl_memcpy_d2h")) return;
+    BQ_REQUIRE((dst && src) || bytes == 0, "fl_memcpy_d2h");
+    if (!bytes) return;
+    BQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_rt.compute));
+    BQ_HIP(hipStreamSynchronize(g_rt.compute));
+}
+
+void fl_memcpy_d2d(void *dst, const void *src, size_t bytes)
+{
+    if (!bq::ensure_ready("fl_memcpy_d2d")) return;
+    BQ_REQUIRE((dst && src) || bytes == 0, "fl_memcpy_d2d");
+    if (bytes && dst != src) BQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_rt.compute));
+}
+
+void fl_sync(void)
+{
+    if (!g_rt.ready) return;
+    BQ_HIP(hipStreamSynchronize(g_rt.compute));
+    BQ_HIP(hipStreamSynchronize(g_rt.halo));
+}
+
+void *fl_event_create(void)
+{
+    if (!bq::ensure_ready("fl_event_create")) return nullptr;
+    hipEvent_t ev = nullptr;
+    if (!BQ_HIP(hipEventCreate(&ev))) return nullptr;
+    return (void *)ev;
+}
+
+void fl_event_record(void *ev)
+{
+    if (!ev || !g_rt.ready) return;
+    BQ_HIP(hipEventRecord((hipEvent_t)ev, g_rt.compute));
+}
+
+float fl_event_elapsed_ms(void *start, void *stop)
+{
+    if (!start || !stop) return -1.f;
+    float ms = -1.f;
+    if (!BQ_HIP(hipEventSynchronize((hipEvent_t)stop))) return -1.f;
+    if (!BQ_HIP(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop))) return -1.f;
+    return ms;
+}
+
+void fl_event_destroy(void *ev)
+{
+    if (ev) BQ_HIP(hipEventDestroy((hipEvent_t)ev));
+}
+
+int fl_last_error(void) { return g_rt.err; }
+const char *fl_last_error_string(void) { return g_rt.err == FL_OK ? "" : g_rt.err_text; }
+void fl_clear_error(void) { g_rt.err = FL_OK; g_rt.err_text[0] = 0; }
+void *fl_compute_stream(void) { return bq::ensure_ready("fl_compute_stream") ? (void *)g_rt.compute : nullptr; }
+
+void fl_set_option(int option, int value)
+{
+    switch (option) {
+    case FL_OPT_RESIDUAL_STRIDE: g_rt.opt_residual_stride = value < 0 ? 0 : value; break;
+    case FL_OPT_SKIP_UNIT_BLEND: g_rt.opt_skip_unit_blend = value ? 1 : 0; break;
+    case FL_OPT_JACOBI_VARIANT:  g_rt.opt_jacobi_variant = value; break;
+    default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
+    }
+}
+
+int fl_get_option(int option)
+{
+    switch (option) {
+    case FL_OPT_RESIDUAL_STRIDE: return g_rt.opt_residual_stride;
+    case FL_OPT_SKIP_UNIT_BLEND: return g_rt.opt_skip_unit_blend;
+    case FL_OPT_JACOBI_VARIANT:  return g_rt.opt_jacobi_variant;
+    default: return -1;
+    }
+}
+
+} // extern "C"

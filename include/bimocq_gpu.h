@@ -1,0 +1,256 @@
+/*
+ * bimocq_gpu.h -- C-ABI of the MI355X (gfx950) bimocq3D hot path.
+ *
+ * Drop-in boundary: the 22 `extern "C" gpu_*` operators below carry exactly the
+ * signatures of the reference's CUDA launchers (reference: src/bimocq3D/GPU_Advection.h:26-108,
+ * implemented in src/bimocq3D/GPU_kernel.cu), so the reference's gpuMapper / MapperBaseGPU /
+ * BimocqGPUSolver link against libbimocq_hip.so unchanged.  All pointers are DEVICE pointers
+ * (hipMalloc / fl_malloc); fields are dense fp32, x fastest: index = i + nx*j + nx*ny*k.
+ * Staggered sizes: u (ni+1,nj,nk), v (ni,nj+1,nk), w (ni,nj,nk+1); scalars and maps (ni,nj,nk).
+ *
+ * The fl_* group replaces the raw CUDA runtime calls gpuMapper makes
+ * (GPU_Advection.h:214-326: findCudaDevice, cudaMalloc/Memset/Memcpy, cudaEvent*).
+ * The last group is additive (no reference counterpart).
+ *
+ * Error convention: the reference's operators return void and check nothing
+ * (SURVEY 8b).  Kept: every operator returns void, is asynchronous on the library's
+ * compute stream, and latches the first failure (bad argument, HIP error, unsupported
+ * operator) for fl_last_error().
+ */
+#ifndef BIMOCQ_GPU_H
+#define BIMOCQ_GPU_H
+
+#include <stddef.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GPU_Advection.h:14-24 */
+#define LEVEL_COUNT 6
+struct SCoarseLevelInfo {
+    int ni, nj, nk;
+    int number;
+    double alpha;
+    double beta;
+    double *b;
+    double *x;
+    double *r;
+};
+#ifndef __cplusplus
+typedef struct SCoarseLevelInfo SCoarseLevelInfo;
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Reference operators (same names, argument order and meaning)
+ * ---------------------------------------------------------------------------------------- */
+
+/* GPU_Advection.h:26-28 / GPU_kernel.cu:567-574.  In-place RK3 trace of the forward map,
+ * sub-stepped by cfldt, interior nodes 2..n-3. */
+void gpu_solve_forward(float *u, float *v, float *w,
+                       float *x_fwd, float *y_fwd, float *z_fwd,
+                       float h, int ni, int nj, int nk, float cfldt, float dt);
+
+/* GPU_Advection.h:30-33 / GPU_kernel.cu:576-584.  One DMC backward sub-step in -> out.
+ * out must not alias in; nodes outside 2..n-3 of out are left untouched. */
+void gpu_solve_backwardDMC(float *u, float *v, float *w,
+                           float *x_in, float *y_in, float *z_in,
+                           float *x_out, float *y_out, float *z_out,
+                           float h, int ni, int nj, int nk, float substep);
+
+/* GPU_Advection.h:35-38 / GPU_kernel.cu:586-598.  Caller zeroes u,v,w first
+ * (GPU_Advection.h:477-479): only the window 3+dim..nbuf-4 is written. */
+void gpu_advect_velocity(float *u, float *v, float *w,
+                         float *u_init, float *v_init, float *w_init,
+                         float *backward_x, float *backward_y, float *backward_z,
+                         float h, int ni, int nj, int nk, bool is_point);
+
+/* GPU_Advection.h:40-44 / GPU_kernel.cu:600-618.  u = u*b + (1-b)*prev(psi_prev(psi_back)). */
+void gpu_advect_vel_double(float *u, float *v, float *w,
+                           float *utemp, float *vtemp, float *wtemp,
+                           float *backward_x, float *backward_y, float *backward_z,
+                           float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                           float h, int ni, int nj, int nk, bool is_point, float blend_coeff);
+
+/* GPU_Advection.h:46-48 / GPU_kernel.cu:620-627 */
+void gpu_advect_field(float *field, float *field_init,
+                      float *backward_x, float *backward_y, float *backward_z,
+                      float h, int ni, int nj, int nk, bool is_point);
+
+/* GPU_Advection.h:50-53 / GPU_kernel.cu:629-638 */
+void gpu_advect_field_double(float *field, float *field_init,
+                             float *backward_x, float *backward_y, float *backward_z,
+                             float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                             float h, int ni, int nj, int nk, bool is_point, float blend_coeff);
+
+/* GPU_Advection.h:55-58 / GPU_kernel.cu:684-696.  d*_init += coeff * blend9(change(psi_fwd(x))). */
+void gpu_accumulate_velocity(float *u_change, float *v_change, float *w_change,
+                             float *du_init, float *dv_init, float *dw_init,
+                             float *forward_x, float *forward_y, float *forward_z,
+                             float h, int ni, int nj, int nk, bool is_point, float coeff);
+
+/* GPU_Advection.h:60-62 / GPU_kernel.cu:698-705 */
+void gpu_accumulate_field(float *field_change, float *dfield_init,
+                          float *forward_x, float *forward_y, float *forward_z,
+                          float h, int ni, int nj, int nk, bool is_point, float coeff);
+
+/* GPU_Advection.h:64-67 / GPU_kernel.cu:707-716.  du (ni*nj*nk floats) receives the squared
+ * round-trip distortion on nodes 2..n-3; caller zeroes it first (GPU_Advection.h:583). */
+void gpu_estimate_distortion(float *du,
+                             float *x_init, float *y_init, float *z_init,
+                             float *x_fwd, float *y_fwd, float *z_fwd,
+                             float h, int ni, int nj, int nk);
+
+/* GPU_Advection.h:69 / GPU_kernel.cu:729-734.  field1 += coeff*field2 over exactly `number`
+ * elements (the reference's grid overruns to the next multiple of 256; not replicated). */
+void gpu_add(float *field1, float *field2, float coeff, int number);
+
+/* GPU_Advection.h:71-76 / GPU_kernel.cu:640-666.  u,v,w: field in/out.  du,dv,dw: `init`, read,
+ * then OVERWRITTEN with the uncompensated field.  u_src..: scratch, zeroed by the caller
+ * (GPU_Advection.h:499-501). */
+void gpu_compensate_velocity(float *u, float *v, float *w,
+                             float *du, float *dv, float *dw,
+                             float *u_src, float *v_src, float *w_src,
+                             float *forward_x, float *forward_y, float *forward_z,
+                             float *backward_x, float *backward_y, float *backward_z,
+                             float h, int ni, int nj, int nk, bool is_point);
+
+/* GPU_Advection.h:78-81 / GPU_kernel.cu:668-682.  All three buffers hold ni*nj*nk floats
+ * (the reference's (ni+1)*nj*nk copy size is an overrun, not replicated). */
+void gpu_compensate_field(float *u, float *du, float *u_src,
+                          float *forward_x, float *forward_y, float *forward_z,
+                          float *backward_x, float *backward_y, float *backward_z,
+                          float h, int ni, int nj, int nk, bool is_point);
+
+/* GPU_Advection.h:83-86 / GPU_kernel.cu:718-727 */
+void gpu_semilag(float *field, float *field_src,
+                 float *u, float *v, float *w,
+                 int dim_x, int dim_y, int dim_z,
+                 float h, int ni, int nj, int nk, float cfldt, float dt);
+
+/* GPU_Advection.h:88-90 / GPU_kernel.cu:782-802.  ni,nj,nk are CELL dims. */
+void gpu_emit_smoke(float *u, float *v, float *w, float *rho, float *T,
+                    float h, int ni, int nj, int nk,
+                    float centerX, float centerY, float centerZ, float radius,
+                    float density, float temperature, float emiter);
+
+/* GPU_Advection.h:92-93 / GPU_kernel.cu:825-832.  field = v component; ni,nj,nk CELL dims.
+ * Implements the intended indexing (the reference mis-indexes rho/T for k>0):
+ * v(i,j,k) += 0.5*dt*(beta*(T(j)+T(j-1)) - alpha*(rho(j)+rho(j-1))), 1 <= j <= nj-1. */
+void gpu_add_buoyancy(float *field, float *density, float *temperature,
+                      int ni, int nj, int nk, float alpha, float beta, float dt);
+
+/* GPU_Advection.h:95 / GPU_kernel.cu:855-876.  ni,nj,nk are BUFFER dims.  fieldTemp0 receives a
+ * copy of field and is the first sweep's input; on return field holds iterate iter-1. */
+void gpu_diffuse_field(float *field, float *fieldTemp0, float *filedTemp1,
+                       int ni, int nj, int nk, int iter, float coef);
+
+/* GPU_Advection.h:97 / GPU_kernel.cu:885-890.  out = field1 + coeff*field2. */
+void gpu_add_field(float *out, float *field1, float *field2, float coeff, int number);
+
+/* GPU_Advection.h:99 / GPU_kernel.cu:1839-1895.  Caller zeroes div, p, p_temp
+ * (GPU_Advection.h:604-606).  On return u,v,w are projected with iterate iter-1, which is
+ * also what p holds (the reference's off-by-one, SURVEY Q1, kept).  debugParam may be NULL;
+ * otherwise it needs >= 2000+iter floats and receives, for it = 0..iter-1,
+ * debugParam[it] = sum r^2 and debugParam[2000+it] = max|r| of iterate `it`
+ * (exact norms; the reference's buggy reductions are re-specified),
+ * evaluated every fl_set_option(FL_OPT_RESIDUAL_STRIDE) iterates (0 = never). */
+void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *p_temp,
+                           float *debugParam, int ni, int nj, int nk, int iter,
+                           float halfrdx, float alpha, float beta);
+
+/* GPU_Advection.h:101 -- OUT OF SCOPE (MacCormack limiter of the reflection scheme; the
+ * reference kernel uses world coordinates as grid indices, GPU_kernel.cu:913-915).
+ * Latches FL_ERR_UNSUPPORTED. */
+void gpu_clamp_extrema(float *field, float *fieldTemp, float *u, float *v, float *w,
+                       int ni, int nj, int nk, int dimx, int dimy, int dimz,
+                       float ox, float oy, float oz, float h, float dt);
+
+/* GPU_Advection.h:103 / GPU_kernel.cu:959-964.  field = c1*field1 + c2*field2. */
+void gpu_mad(float *field, float *field1, float *field2, float coeff1, float coeff2, int number);
+
+/* GPU_Advection.h:105 -- OUT OF SCOPE (alternative solver, compiled out in the reference,
+ * BimocqGPUSolver.cpp:419).  Latches FL_ERR_UNSUPPORTED. */
+void gpu_conjugate_gradient(float *u, float *v, float *w, float *div, float *p,
+                            float *residual, float *dir, float *dotR,
+                            int ni, int nj, int nk, int iter, float halfrdx);
+
+/* GPU_Advection.h:107-108 -- NEXT, not built yet.  Latches FL_ERR_UNSUPPORTED. */
+void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div, double *p,
+                                       double *dir, double *residual, double *temp0, double *temp1,
+                                       double *tempResult, struct SCoarseLevelInfo *levels,
+                                       int levelNum, int iter, double halfrdx);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Runtime mini-ABI (replaces gpuMapper's direct CUDA runtime calls)
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    FL_OK = 0,
+    FL_ERR_NO_DEVICE = 1,       /* no HIP device / wrong architecture                         */
+    FL_ERR_HIP = 2,             /* a HIP runtime call failed (text in fl_last_error_string)   */
+    FL_ERR_BAD_ARGUMENT = 3,
+    FL_ERR_UNSUPPORTED = 4,
+    FL_ERR_COMM = 5             /* RCCL failure                                               */
+};
+
+/* Select device `device` (findCudaDevice, GPU_Advection.h:214-226), create the compute and
+ * halo streams.  Returns FL_OK or an error code (the reference exit()s; we report). */
+int   fl_init(int device);
+void  fl_shutdown(void);
+/* cudaMalloc + cudaMemset(0) (allocGPUBuffer, GPU_Advection.h:322-326).  NULL on failure. */
+void *fl_malloc(size_t bytes);
+void  fl_free(void *p);
+void  fl_memset(void *dst, int value, size_t bytes);                    /* async on the compute stream */
+void  fl_memcpy_h2d(void *dst, const void *src, size_t bytes);          /* blocking */
+void  fl_memcpy_d2h(void *dst, const void *src, size_t bytes);          /* blocking, after queued work */
+void  fl_memcpy_d2d(void *dst, const void *src, size_t bytes);          /* async on the compute stream */
+void  fl_sync(void);
+/* startEventRecord / endEventRecord (GPU_Advection.h:228-247) */
+void *fl_event_create(void);
+void  fl_event_record(void *ev);
+float fl_event_elapsed_ms(void *start, void *stop);                     /* synchronises on `stop` */
+void  fl_event_destroy(void *ev);
+int         fl_last_error(void);
+const char *fl_last_error_string(void);
+void        fl_clear_error(void);
+/* the hipStream_t the operators launch on (for timing / interop with other runtimes) */
+void *fl_compute_stream(void);
+
+enum {
+    FL_OPT_RESIDUAL_STRIDE = 1, /* evaluate Jacobi residual norms every k-th iterate (default 0)  */
+    FL_OPT_SKIP_UNIT_BLEND = 2, /* gpu_advect_*_double with blend==1: write field+0 instead of
+                                   evaluating prev (exact for finite prev; default 1)              */
+    FL_OPT_JACOBI_VARIANT  = 3  /* 0 = auto, 1 = generic scalar kernel, 2 = LDS-tiled kernel      */
+};
+void fl_set_option(int option, int value);
+int  fl_get_option(int option);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Additive entry points (no reference counterpart)
+ * ---------------------------------------------------------------------------------------- */
+/* maps <- (i*h, j*h, k*h): the host loop + H2D of MapperBaseGPU::init (Mapping.cpp:306-328) */
+void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk);
+/* device getCFL (BimocqGPUSolver.cpp:348-373): max(1e-4, max|u|,|v|,|w|); blocking */
+float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int nj, int nk);
+/* the three stages of gpu_projection_jacobi, separately launchable */
+void gpu_divergence(const float *u, const float *v, const float *w, float *div,
+                    int ni, int nj, int nk, float halfrdx);
+/* `sweeps` Jacobi sweeps ping-ponging p <-> p_temp starting from p; returns 0 if the newest
+ * iterate ends in p, 1 if it ends in p_temp.  Boundary cells are never written. */
+int  gpu_jacobi_sweeps(float *p, const float *div, float *p_temp,
+                       int ni, int nj, int nk, int sweeps, float alpha, float beta);
+void gpu_gradient(float *u, float *v, float *w, const float *p,
+                  int ni, int nj, int nk, float halfrdx);
+/* exact sum r^2 (double) and max|r| of r = div - (sum6 p - 6p) over interior cells; blocking */
+void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk,
+                        double *sum_sq, float *max_abs);
+/* clampExtrema_kernel (GPU_kernel.cu:146-167) on its own: after = clamp(after, min/max27(before)) */
+void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIMOCQ_GPU_H */

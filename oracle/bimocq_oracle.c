@@ -1,0 +1,1002 @@
+/*
+ * bimocq_oracle.c -- CPU restatement of the bimocq3D per-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see bimocq_oracle.h).  PARITY UNPINNED by reference
+ * fixtures (the reference has none); every function cites the reference lines it
+ * restates, relative to /root/reference/src/bimocq3D/.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -fPIC -shared (oracle/Makefile).
+ * OpenMP `parallel for` stands in for the reference's one-thread-per-voxel CUDA grid;
+ * every kernel below is a pure per-voxel map (reads never alias another voxel's
+ * writes inside one launch), so the loop order cannot change results.
+ */
+#include "bimocq_oracle.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float x, y, z; } f3;
+
+static inline f3 mk3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
+
+/* GPU_kernel.cu:9-12 */
+static inline float clampf(float a, float lo, float hi) { return fminf(fmaxf(lo, a), hi); }
+
+/* GPU_kernel.cu:14-20 */
+static inline f3 clamp3(f3 p, f3 lo, f3 hi)
+{
+    return mk3(clampf(p.x, lo.x, hi.x), clampf(p.y, lo.y, hi.y), clampf(p.z, lo.z, hi.z));
+}
+
+/* GPU_kernel.cu:22-25: `(1.0-c)*a + c*b` -- (1.0-c) and the first product are double,
+ * c*b is a float product, the sum is double, the return rounds to float. */
+float orc_lerp(float a, float b, float c)
+{
+    float cb = c * b;
+    return (float)((1.0 - (double)c) * (double)a + (double)cb);
+}
+
+/* GPU_kernel.cu:27-41 */
+static inline float trilerp(float v000, float v001, float v010, float v011,
+                            float v100, float v101, float v110, float v111,
+                            float a, float b, float c)
+{
+    float l00 = orc_lerp(v000, v001, a);
+    float l01 = orc_lerp(v010, v011, a);
+    float l10 = orc_lerp(v100, v101, a);
+    float l11 = orc_lerp(v110, v111, a);
+    return orc_lerp(orc_lerp(l00, l01, b), orc_lerp(l10, l11, b), c);
+}
+
+static inline float ld(const float *b, long idx, long count)
+{
+    return (idx >= 0 && idx < count) ? b[idx] : 0.0f;
+}
+
+/* GPU_kernel.cu:43-62 sample_buffer: no index clamping, flat index arithmetic kept;
+ * reads outside the allocation return 0 (header, arithmetic contract). */
+static inline float sample(const float *b, int nx, int ny, int nz, float h, f3 off, f3 pos)
+{
+    float sx = pos.x - off.x, sy = pos.y - off.y, sz = pos.z - off.z;
+    float qx = sx / h, qy = sy / h, qz = sz / h;
+    int i = (int)floorf(qx), j = (int)floorf(qy), k = (int)floorf(qz);
+    float fx = qx - (float)i, fy = qy - (float)j, fz = qz - (float)k;
+    long sj = nx, sk = (long)nx * ny, count = (long)nx * ny * nz;
+    long base = (long)i + sj * j + sk * k;
+    return trilerp(ld(b, base, count),           ld(b, base + 1, count),
+                   ld(b, base + sj, count),      ld(b, base + sj + 1, count),
+                   ld(b, base + sk, count),      ld(b, base + sk + 1, count),
+                   ld(b, base + sk + sj, count), ld(b, base + sk + sj + 1, count),
+                   fx, fy, fz);
+}
+
+float orc_sample(const float *b, int nx, int ny, int nz, float h,
+                 float ox, float oy, float oz, float px, float py, float pz)
+{
+    return sample(b, nx, ny, nz, h, mk3(ox, oy, oz), mk3(px, py, pz));
+}
+
+/* GPU_kernel.cu:64-72 getVelocity: MAC-staggered components, origins (-h/2,0,0) etc.
+ * (-0.5*h is a double product rounded to float: exact). */
+static inline f3 get_velocity(const float *u, const float *v, const float *w,
+                              float h, int nx, int ny, int nz, f3 pos)
+{
+    float mh = (float)(-0.5 * (double)h);
+    float _u = sample(u, nx + 1, ny, nz, h, mk3(mh, 0.f, 0.f), pos);
+    float _v = sample(v, nx, ny + 1, nz, h, mk3(0.f, mh, 0.f), pos);
+    float _w = sample(w, nx, ny, nz + 1, h, mk3(0.f, 0.f, mh), pos);
+    return mk3(_u, _v, _w);
+}
+
+/* GPU_kernel.cu:74-90 traceRK3 (Ralston RK3; stage points evaluated in double) */
+static inline f3 trace_rk3(const float *u, const float *v, const float *w,
+                           float h, int ni, int nj, int nk, float dt, f3 pos)
+{
+    float c1 = (float)(2.0 / 9.0 * (double)dt);
+    float c2 = (float)(3.0 / 9.0 * (double)dt);
+    float c3 = (float)(4.0 / 9.0 * (double)dt);
+    f3 v1 = get_velocity(u, v, w, h, ni, nj, nk, pos);
+    double hdt = 0.5 * (double)dt;
+    f3 m1 = mk3((float)((double)pos.x + hdt * (double)v1.x),
+                (float)((double)pos.y + hdt * (double)v1.y),
+                (float)((double)pos.z + hdt * (double)v1.z));
+    f3 v2 = get_velocity(u, v, w, h, ni, nj, nk, m1);
+    double qdt = 0.75 * (double)dt;
+    f3 m2 = mk3((float)((double)pos.x + qdt * (double)v2.x),
+                (float)((double)pos.y + qdt * (double)v2.y),
+                (float)((double)pos.z + qdt * (double)v2.z));
+    f3 v3 = get_velocity(u, v, w, h, ni, nj, nk, m2);
+    f3 out = mk3(pos.x + c1 * v1.x + c2 * v2.x + c3 * v3.x,
+                 pos.y + c1 * v1.y + c2 * v2.y + c3 * v3.y,
+                 pos.z + c1 * v1.z + c2 * v2.z + c3 * v3.z);
+    return clamp3(out, mk3(h, h, h),
+                  mk3((float)ni * h - h, (float)nj * h - h, (float)nk * h - h));
+}
+
+/* GPU_kernel.cu:92-125 trace: sub-step by cfldt until |dt| is consumed */
+static inline f3 trace(const float *u, const float *v, const float *w,
+                       float h, int ni, int nj, int nk, float cfldt, float dt, f3 pos)
+{
+    float sgn = (dt > 0) ? 1.0f : -1.0f;
+    float T = (dt > 0) ? dt : -dt;
+    float t = 0.f, substep = cfldt;
+    f3 p = pos;
+    while (t < T) {
+        if (t + substep > T) substep = T - t;
+        p = trace_rk3(u, v, w, h, ni, nj, nk, (sgn > 0) ? substep : -substep, p);
+        t += substep;
+    }
+    return p;
+}
+
+/* expf of the DMC integrator: fixed double polynomial, identical in the HIP path. */
+float orc_expf(float xf)
+{
+    double x = (double)xf;
+    if (!(x == x)) return xf;
+    if (x > 90.0) x = 90.0;
+    if (x < -110.0) x = -110.0;
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2HI = 6.93147180369123816490e-01;
+    const double LN2LO = 1.90821492927058770002e-10;
+    double kd = floor(x * LOG2E + 0.5);
+    double r = (x - kd * LN2HI) - kd * LN2LO;
+    /* Taylor/Horner degree 13 on |r| <= 0.3466: truncation < 1e-17 */
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    int64_t k = (int64_t)kd;
+    uint64_t bits = (uint64_t)(k + 1023) << 52;
+    double scale;
+    memcpy(&scale, &bits, sizeof scale);
+    return (float)(p * scale);
+}
+
+#define IDX3(i, j, k, nx, ny) ((long)(i) + (long)(nx) * (j) + (long)(nx) * (ny) * (k))
+
+/* GPU_kernel.cu:127-144 forward_kernel + :567-574 launcher */
+void orc_solve_forward(const float *u, const float *v, const float *w,
+                       float *x_fwd, float *y_fwd, float *z_fwd,
+                       float h, int ni, int nj, int nk, float cfldt, float dt)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < nk - 2; k++)
+        for (int j = 2; j < nj - 2; j++)
+            for (int i = 2; i < ni - 2; i++) {
+                long id = IDX3(i, j, k, ni, nj);
+                f3 q = trace(u, v, w, h, ni, nj, nk, cfldt, dt, mk3(x_fwd[id], y_fwd[id], z_fwd[id]));
+                x_fwd[id] = q.x; y_fwd[id] = q.y; z_fwd[id] = q.z;
+            }
+}
+
+/* GPU_kernel.cu:169-204 DMC_backward_kernel + :576-584 launcher */
+static inline float dmc_axis(float p, float vel, float a, float s)
+{
+    if ((double)fabsf(a) > 1e-4)
+        return p - (1.0f - orc_expf(-a * s)) * vel / a;
+    return p - vel * s;
+}
+
+void orc_solve_backwardDMC(const float *u, const float *v, const float *w,
+                           const float *x_in, const float *y_in, const float *z_in,
+                           float *x_out, float *y_out, float *z_out,
+                           float h, int ni, int nj, int nk, float substep)
+{
+    const f3 zero = mk3(0.f, 0.f, 0.f);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < nk - 2; k++)
+        for (int j = 2; j < nj - 2; j++)
+            for (int i = 2; i < ni - 2; i++) {
+                long id = IDX3(i, j, k, ni, nj);
+                f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+                f3 vel = get_velocity(u, v, w, h, ni, nj, nk, pt);
+                f3 tp = mk3((vel.x > 0) ? pt.x - h : pt.x + h,
+                            (vel.y > 0) ? pt.y - h : pt.y + h,
+                            (vel.z > 0) ? pt.z - h : pt.z + h);
+                f3 tv = get_velocity(u, v, w, h, ni, nj, nk, tp);
+                float ax = (vel.x - tv.x) / (pt.x - tp.x);
+                float ay = (vel.y - tv.y) / (pt.y - tp.y);
+                float az = (vel.z - tv.z) / (pt.z - tp.z);
+                f3 pn = mk3(dmc_axis(pt.x, vel.x, ax, substep),
+                            dmc_axis(pt.y, vel.y, ay, substep),
+                            dmc_axis(pt.z, vel.z, az, substep));
+                x_out[id] = sample(x_in, ni, nj, nk, h, zero, pn);
+                y_out[id] = sample(y_in, ni, nj, nk, h, zero, pn);
+                z_out[id] = sample(z_in, ni, nj, nk, h, zero, pn);
+            }
+}
+
+/* ---- the 9-point (8 sub-voxel corners + centre) gather family ------------------
+ * Offsets in the reference's order, GPU_kernel.cu:317-327 (identical in all five
+ * kernels); is_point collapses to one evaluation at the centre with weight 1.     */
+typedef struct { const float *x, *y, *z; } map3;
+
+static inline f3 map_at(map3 m, int ni, int nj, int nk, float h, f3 pos)
+{
+    const f3 zero = mk3(0.f, 0.f, 0.f);
+    return mk3(sample(m.x, ni, nj, nk, h, zero, pos),
+               sample(m.y, ni, nj, nk, h, zero, pos),
+               sample(m.z, ni, nj, nk, h, zero, pos));
+}
+
+typedef struct {
+    f3 vol[8];
+    int evals;
+    float weight;
+    f3 origin;
+    int nbi, nbj, nbk;
+} nine_t;
+
+static nine_t nine_setup(float h, int ni, int nj, int nk, int dx, int dy, int dz, int is_point)
+{
+    nine_t n;
+    float q = 0.25f * h, mq = -0.25f * h;
+    n.vol[0] = mk3(q, q, q);   n.vol[1] = mk3(q, q, mq);
+    n.vol[2] = mk3(q, mq, q);  n.vol[3] = mk3(q, mq, mq);
+    n.vol[4] = mk3(mq, q, q);  n.vol[5] = mk3(mq, q, mq);
+    n.vol[6] = mk3(mq, mq, q); n.vol[7] = mk3(mq, mq, mq);
+    n.evals = 8;
+    if (is_point) { n.vol[0] = mk3(0.f, 0.f, 0.f); n.evals = 1; }
+    n.weight = (float)(1.0 / (double)(float)n.evals);
+    n.origin = mk3(-(float)dx * 0.5f * h, -(float)dy * 0.5f * h, -(float)dz * 0.5f * h);
+    n.nbi = ni + dx; n.nbj = nj + dy; n.nbk = nk + dz;
+    return n;
+}
+
+static inline f3 nine_pos(const nine_t *n, float h, int i, int j, int k, int ii)
+{
+    f3 c = mk3((float)i * h + n->origin.x, (float)j * h + n->origin.y, (float)k * h + n->origin.z);
+    if (ii < 0) return c;
+    return mk3(c.x + n->vol[ii].x, c.y + n->vol[ii].y, c.z + n->vol[ii].z);
+}
+
+/* GPU_kernel.cu:312-374 advect_kernel */
+static void advect_comp(float *field, const float *field_init, map3 back,
+                        float h, int ni, int nj, int nk, int dx, int dy, int dz, int is_point)
+{
+    nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)nk - h);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 3 + dz; k < n.nbk - 3; k++)
+        for (int j = 3 + dy; j < n.nbj - 3; j++)
+            for (int i = 3 + dx; i < n.nbi - 3; i++) {
+                float sum = 0.f;
+                for (int ii = 0; ii < n.evals; ii++) {
+                    f3 p0 = clamp3(map_at(back, ni, nj, nk, h, nine_pos(&n, h, i, j, k, ii)), lo, hi);
+                    sum += n.weight * sample(field_init, n.nbi, n.nbj, n.nbk, h, n.origin, p0);
+                }
+                f3 pc = clamp3(map_at(back, ni, nj, nk, h, nine_pos(&n, h, i, j, k, -1)), lo, hi);
+                float value = sample(field_init, n.nbi, n.nbj, n.nbk, h, n.origin, pc);
+                field[IDX3(i, j, k, n.nbi, n.nbj)] = 0.5f * sum + 0.5f * value;
+            }
+}
+
+/* GPU_kernel.cu:236-310 doubleAdvect_kernel */
+static void double_advect_comp(float *field, const float *temp_field, map3 back, map3 backprev,
+                               float h, int ni, int nj, int nk, int dx, int dy, int dz,
+                               int is_point, float blend)
+{
+    nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)nk - h);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 3 + dz; k < n.nbk - 3; k++)
+        for (int j = 3 + dy; j < n.nbj - 3; j++)
+            for (int i = 3 + dx; i < n.nbi - 3; i++) {
+                float sum = 0.f;
+                for (int ii = 0; ii < n.evals; ii++) {
+                    f3 mid = clamp3(map_at(back, ni, nj, nk, h, nine_pos(&n, h, i, j, k, ii)), lo, hi);
+                    f3 fin = clamp3(map_at(backprev, ni, nj, nk, h, mid), lo, hi);
+                    sum += n.weight * sample(temp_field, n.nbi, n.nbj, n.nbk, h, n.origin, fin);
+                }
+                f3 mid = clamp3(map_at(back, ni, nj, nk, h, nine_pos(&n, h, i, j, k, -1)), lo, hi);
+                f3 fin = clamp3(map_at(backprev, ni, nj, nk, h, mid), lo, hi);
+                float value = sample(temp_field, n.nbi, n.nbj, n.nbk, h, n.origin, fin);
+                float prev_value = 0.5f * (sum + value);
+                long id = IDX3(i, j, k, n.nbi, n.nbj);
+                field[id] = field[id] * blend + (1.0f - blend) * prev_value;
+            }
+}
+
+/* GPU_kernel.cu:376-436 cumulate_kernel: dst += blend9(coeff * src(map(x))) */
+static void cumulate_comp(const float *src, float *dst, map3 m,
+                          float h, int ni, int nj, int nk, int dx, int dy, int dz,
+                          int is_point, float coeff)
+{
+    nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)nk);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2 + dz; k < n.nbk - 2; k++)
+        for (int j = 2 + dy; j < n.nbj - 2; j++)
+            for (int i = 2 + dx; i < n.nbi - 2; i++) {
+                float sum = 0.f;
+                for (int ii = 0; ii < n.evals; ii++) {
+                    f3 mp = clamp3(map_at(m, ni, nj, nk, h, nine_pos(&n, h, i, j, k, ii)), lo, hi);
+                    sum += n.weight * coeff * sample(src, n.nbi, n.nbj, n.nbk, h, n.origin, mp);
+                }
+                f3 mp = clamp3(map_at(m, ni, nj, nk, h, nine_pos(&n, h, i, j, k, -1)), lo, hi);
+                float value = coeff * sample(src, n.nbi, n.nbj, n.nbk, h, n.origin, mp);
+                sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+                dst[IDX3(i, j, k, n.nbi, n.nbj)] += sum;
+            }
+}
+
+/* GPU_kernel.cu:438-499 compensate_kernel: err = blend9(src(map(x))) - init(x) */
+static void compensate_comp(const float *src, const float *init, float *err, map3 m,
+                            float h, int ni, int nj, int nk, int dx, int dy, int dz, int is_point)
+{
+    nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)nk);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2 + dz; k < n.nbk - 2; k++)
+        for (int j = 2 + dy; j < n.nbj - 2; j++)
+            for (int i = 2 + dx; i < n.nbi - 2; i++) {
+                float sum = 0.f;
+                for (int ii = 0; ii < n.evals; ii++) {
+                    f3 mp = clamp3(map_at(m, ni, nj, nk, h, nine_pos(&n, h, i, j, k, ii)), lo, hi);
+                    sum += n.weight * sample(src, n.nbi, n.nbj, n.nbk, h, n.origin, mp);
+                }
+                f3 mp = clamp3(map_at(m, ni, nj, nk, h, nine_pos(&n, h, i, j, k, -1)), lo, hi);
+                float value = sample(src, n.nbi, n.nbj, n.nbk, h, n.origin, mp);
+                sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+                long id = IDX3(i, j, k, n.nbi, n.nbj);
+                err[id] = sum - init[id];
+            }
+}
+
+/* GPU_kernel.cu:146-167 clampExtrema_kernel (3x3x3 box limiter, interior only) */
+void orc_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k < nk - 1; k++)
+        for (int j = 1; j < nj - 1; j++)
+            for (int i = 1; i < ni - 1; i++) {
+                long id = IDX3(i, j, k, ni, nj);
+                float mx = before[id], mn = before[id];
+                for (int kk = k - 1; kk <= k + 1; kk++)
+                    for (int jj = j - 1; jj <= j + 1; jj++)
+                        for (int ii = i - 1; ii <= i + 1; ii++) {
+                            float b = before[IDX3(ii, jj, kk, ni, nj)];
+                            if (b > mx) mx = b;
+                            if (b < mn) mn = b;
+                        }
+                after[id] = fminf(fmaxf(mn, after[id]), mx);
+            }
+}
+
+/* GPU_kernel.cu:586-598 */
+void orc_advect_velocity(float *u, float *v, float *w,
+                         const float *u_init, const float *v_init, const float *w_init,
+                         const float *bx, const float *by, const float *bz,
+                         float h, int ni, int nj, int nk, int is_point)
+{
+    map3 b = { bx, by, bz };
+    advect_comp(u, u_init, b, h, ni, nj, nk, 1, 0, 0, is_point);
+    advect_comp(v, v_init, b, h, ni, nj, nk, 0, 1, 0, is_point);
+    advect_comp(w, w_init, b, h, ni, nj, nk, 0, 0, 1, is_point);
+}
+
+/* GPU_kernel.cu:600-618 */
+void orc_advect_vel_double(float *u, float *v, float *w,
+                           const float *utemp, const float *vtemp, const float *wtemp,
+                           const float *bx, const float *by, const float *bz,
+                           const float *bxp, const float *byp, const float *bzp,
+                           float h, int ni, int nj, int nk, int is_point, float blend)
+{
+    map3 b = { bx, by, bz }, bp = { bxp, byp, bzp };
+    double_advect_comp(u, utemp, b, bp, h, ni, nj, nk, 1, 0, 0, is_point, blend);
+    double_advect_comp(v, vtemp, b, bp, h, ni, nj, nk, 0, 1, 0, is_point, blend);
+    double_advect_comp(w, wtemp, b, bp, h, ni, nj, nk, 0, 0, 1, is_point, blend);
+}
+
+/* GPU_kernel.cu:620-627 */
+void orc_advect_field(float *field, const float *field_init,
+                      const float *bx, const float *by, const float *bz,
+                      float h, int ni, int nj, int nk, int is_point)
+{
+    map3 b = { bx, by, bz };
+    advect_comp(field, field_init, b, h, ni, nj, nk, 0, 0, 0, is_point);
+}
+
+/* GPU_kernel.cu:629-638 */
+void orc_advect_field_double(float *field, const float *field_prev,
+                             const float *bx, const float *by, const float *bz,
+                             const float *bxp, const float *byp, const float *bzp,
+                             float h, int ni, int nj, int nk, int is_point, float blend)
+{
+    map3 b = { bx, by, bz }, bp = { bxp, byp, bzp };
+    double_advect_comp(field, field_prev, b, bp, h, ni, nj, nk, 0, 0, 0, is_point, blend);
+}
+
+/* GPU_kernel.cu:640-666.  du/dv/dw are read as `init` and then overwritten with the
+ * uncompensated field; u_src.. must be zeroed by the caller
+ * (GPU_Advection.h:499-501). */
+void orc_compensate_velocity(float *u, float *v, float *w,
+                             float *du, float *dv, float *dw,
+                             float *u_src, float *v_src, float *w_src,
+                             const float *fx, const float *fy, const float *fz,
+                             const float *bx, const float *by, const float *bz,
+                             float h, int ni, int nj, int nk, int is_point)
+{
+    map3 f = { fx, fy, fz }, b = { bx, by, bz };
+    compensate_comp(u, du, u_src, f, h, ni, nj, nk, 1, 0, 0, is_point);
+    compensate_comp(v, dv, v_src, f, h, ni, nj, nk, 0, 1, 0, is_point);
+    compensate_comp(w, dw, w_src, f, h, ni, nj, nk, 0, 0, 1, is_point);
+    memcpy(du, u, sizeof(float) * (size_t)(ni + 1) * nj * nk);
+    memcpy(dv, v, sizeof(float) * (size_t)ni * (nj + 1) * nk);
+    memcpy(dw, w, sizeof(float) * (size_t)ni * nj * (nk + 1));
+    cumulate_comp(u_src, u, b, h, ni, nj, nk, 1, 0, 0, is_point, -0.5f);
+    cumulate_comp(v_src, v, b, h, ni, nj, nk, 0, 1, 0, is_point, -0.5f);
+    cumulate_comp(w_src, w, b, h, ni, nj, nk, 0, 0, 1, is_point, -0.5f);
+    orc_clamp_extrema_box(du, u, ni + 1, nj, nk);
+    orc_clamp_extrema_box(dv, v, ni, nj + 1, nk);
+    orc_clamp_extrema_box(dw, w, ni, nj, nk + 1);
+}
+
+/* GPU_kernel.cu:668-682; the (ni+1)*nj*nk-sized copy of the reference (Q4) is not
+ * replicated: the scalar buffers hold ni*nj*nk floats. */
+void orc_compensate_field(float *u, float *du, float *u_src,
+                          const float *fx, const float *fy, const float *fz,
+                          const float *bx, const float *by, const float *bz,
+                          float h, int ni, int nj, int nk, int is_point)
+{
+    map3 f = { fx, fy, fz }, b = { bx, by, bz };
+    compensate_comp(u, du, u_src, f, h, ni, nj, nk, 0, 0, 0, is_point);
+    memcpy(du, u, sizeof(float) * (size_t)ni * nj * nk);
+    cumulate_comp(u_src, u, b, h, ni, nj, nk, 0, 0, 0, is_point, -0.5f);
+    orc_clamp_extrema_box(du, u, ni, nj, nk);
+}
+
+/* GPU_kernel.cu:684-696 */
+void orc_accumulate_velocity(const float *uc, const float *vc, const float *wc,
+                             float *du_init, float *dv_init, float *dw_init,
+                             const float *fx, const float *fy, const float *fz,
+                             float h, int ni, int nj, int nk, int is_point, float coeff)
+{
+    map3 f = { fx, fy, fz };
+    cumulate_comp(uc, du_init, f, h, ni, nj, nk, 1, 0, 0, is_point, coeff);
+    cumulate_comp(vc, dv_init, f, h, ni, nj, nk, 0, 1, 0, is_point, coeff);
+    cumulate_comp(wc, dw_init, f, h, ni, nj, nk, 0, 0, 1, is_point, coeff);
+}
+
+/* GPU_kernel.cu:698-705 */
+void orc_accumulate_field(const float *change, float *dfield_init,
+                          const float *fx, const float *fy, const float *fz,
+                          float h, int ni, int nj, int nk, int is_point, float coeff)
+{
+    map3 f = { fx, fy, fz };
+    cumulate_comp(change, dfield_init, f, h, ni, nj, nk, 0, 0, 0, is_point, coeff);
+}
+
+/* GPU_kernel.cu:501-537 estimate_kernel + :707-716 */
+void orc_estimate_distortion(float *dist,
+                             const float *xb, const float *yb, const float *zb,
+                             const float *xf, const float *yf, const float *zf,
+                             float h, int ni, int nj, int nk)
+{
+    map3 first = { xb, yb, zb }, second = { xf, yf, zf };
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < nk - 2; k++)
+        for (int j = 2; j < nj - 2; j++)
+            for (int i = 2; i < ni - 2; i++) {
+                f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+                f3 back = map_at(first, ni, nj, nk, h, pt);
+                f3 fwd = map_at(second, ni, nj, nk, h, back);
+                float d_bf = (pt.x - fwd.x) * (pt.x - fwd.x) + (pt.y - fwd.y) * (pt.y - fwd.y)
+                           + (pt.z - fwd.z) * (pt.z - fwd.z);
+                f3 f2 = map_at(second, ni, nj, nk, h, pt);
+                f3 b2 = map_at(first, ni, nj, nk, h, f2);
+                float d_fb = (pt.x - b2.x) * (pt.x - b2.x) + (pt.y - b2.y) * (pt.y - b2.y)
+                           + (pt.z - b2.z) * (pt.z - b2.z);
+                dist[IDX3(i, j, k, ni, nj)] = fmaxf(d_bf, d_fb);
+            }
+}
+
+/* GPU_kernel.cu:206-233 semilag_kernel + :718-727 */
+void orc_semilag(float *field, const float *field_src,
+                 const float *u, const float *v, const float *w,
+                 int dx, int dy, int dz,
+                 float h, int ni, int nj, int nk, float cfldt, float dt)
+{
+    f3 org = mk3(-(float)dx * 0.5f * h, -(float)dy * 0.5f * h, -(float)dz * 0.5f * h);
+    int bi = ni + dx, bj = nj + dy, bk = nk + dz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < bk - 2 - dz; k++)
+        for (int j = 2; j < bj - 2 - dy; j++)
+            for (int i = 2; i < bi - 2 - dx; i++) {
+                f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+                f3 pn = trace(u, v, w, h, ni, nj, nk, cfldt, dt, pt);
+                field[IDX3(i, j, k, bi, bj)] = sample(field_src, bi, bj, bk, h, org, pn);
+            }
+}
+
+/* GPU_kernel.cu:560-565 + :729-734 (exactly `number` elements; the reference's
+ * rounded-up grid overrun is not replicated) */
+void orc_add(float *f1, const float *f2, float coeff, int number)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < number; i++) f1[i] += coeff * f2[i];
+}
+
+/* GPU_kernel.cu:878-890 */
+void orc_add_field(float *out, const float *f1, const float *f2, float coeff, int number)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < number; i++) out[i] = f1[i] + coeff * f2[i];
+}
+
+/* GPU_kernel.cu:952-964 */
+void orc_mad(float *out, const float *f1, const float *f2, float c1, float c2, int number)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < number; i++) out[i] = c1 * f1[i] + c2 * f2[i];
+}
+
+/* GPU_kernel.cu:736-758 emit_smoke_velocity_kernel.  norm3df is taken as the
+ * correctly-rounded sqrt of the double sum of squares (identical in the HIP path);
+ * note the u-face offset (i-1/2)h is used for every component. */
+static inline float norm3(float x, float y, float z)
+{
+    return (float)sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);
+}
+
+static void emit_velocity(float *field, float h, int ni, int nj, int nk,
+                          float cx, float cy, float cz, float radius, float emiter)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < nk - 2; k++)
+        for (int j = 2; j < nj - 2; j++)
+            for (int i = 2; i < ni - 2; i++) {
+                float dxp = (float)(((double)(float)i - 0.5) * (double)h - (double)cx);
+                float dyp = (float)j * h - cy;
+                float dzp = (float)k * h - cz;
+                if (norm3(dxp, dyp, dzp) < radius) {
+                    float theta = acosf(dyp / hypotf(dyp, dzp));
+                    float c8 = cosf((float)(8.0 * (double)theta));
+                    field[IDX3(i, j, k, ni, nj)] =
+                        (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));
+                }
+            }
+}
+
+/* GPU_kernel.cu:760-780 emit_smoke_field_kernel */
+static void emit_field(float *rho, float *T, float h, int ni, int nj, int nk,
+                       float cx, float cy, float cz, float radius, float density, float temperature)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < nk - 2; k++)
+        for (int j = 2; j < nj - 2; j++)
+            for (int i = 2; i < ni - 2; i++) {
+                float dxp = (float)i * h - cx, dyp = (float)j * h - cy, dzp = (float)k * h - cz;
+                if (norm3(dxp, dyp, dzp) < radius) {
+                    long id = IDX3(i, j, k, ni, nj);
+                    rho[id] = density;
+                    T[id] = temperature;
+                }
+            }
+}
+
+/* GPU_kernel.cu:782-802 */
+void orc_emit_smoke(float *u, float *v, float *w, float *rho, float *T,
+                    float h, int ni, int nj, int nk,
+                    float cx, float cy, float cz, float radius,
+                    float density, float temperature, float emiter)
+{
+    emit_velocity(u, h, ni + 1, nj, nk, cx, cy, cz, radius, emiter);
+    emit_velocity(v, h, ni, nj + 1, nk, cx, cy, cz, radius, 0.f);
+    emit_velocity(w, h, ni, nj, nk + 1, cx, cy, cz, radius, 0.f);
+    emit_field(rho, T, h, ni, nj, nk, cx, cy, cz, radius, density, temperature);
+}
+
+/* GPU_kernel.cu:804-832 add_buoyancy with the INTENDED indexing (fixed not
+ * replicated): the reference reads rho/T with the v-buffer flat index, which is only
+ * right on the k=0 slab.  v(i,j,k) += 0.5*dt*(beta*(T(j)+T(j-1)) - alpha*(rho(j)+rho(j-1)))
+ * for 1 <= j <= nj-1 (the faces that have a cell on both sides). */
+void orc_add_buoyancy(float *v, const float *rho, const float *T,
+                      int ni, int nj, int nk, float alpha, float beta, float dt)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nk; k++)
+        for (int j = 1; j < nj; j++)
+            for (int i = 0; i < ni; i++) {
+                long c0 = IDX3(i, j, k, ni, nj), c1 = IDX3(i, j - 1, k, ni, nj);
+                float d0 = rho[c0], T0 = T[c0], d1 = rho[c1], T1 = T[c1];
+                float f = (float)(0.5 * (double)dt * (double)(beta * (T0 + T1) - alpha * (d0 + d1)));
+                v[IDX3(i, j, k, ni, nj + 1)] += f;
+            }
+}
+
+/* GPU_kernel.cu:834-876 gpu_diffuse_field: tmp0 <- field; iter ping-pong sweeps; field <-
+ * the buffer that was the INPUT of the last sweep (iterate iter-1). */
+void orc_diffuse_field(float *field, float *tmp0, float *tmp1,
+                       int ni, int nj, int nk, int iter, float coef)
+{
+    size_t number = (size_t)ni * nj * nk;
+    float *in = tmp0, *out = tmp1;
+    memcpy(in, field, number * sizeof(float));
+    for (int it = 0; it < iter; it++) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int k = 1; k < nk - 1; k++)
+            for (int j = 1; j < nj - 1; j++)
+                for (int i = 1; i < ni - 1; i++) {
+                    long id = IDX3(i, j, k, ni, nj);
+                    float s = in[id - 1] + in[id + 1] + in[id - ni] + in[id + ni]
+                            + in[id - (long)ni * nj] + in[id + (long)ni * nj];
+                    out[id] = (field[id] + coef * s) / (1.0f + 6.0f * coef);
+                }
+        float *t = out; out = in; in = t;
+    }
+    memcpy(field, out, number * sizeof(float));
+}
+
+/* GPU_kernel.cu:967-985 divergence_kernel (float) */
+void orc_divergence(const float *u, const float *v, const float *w, float *div,
+                    int ni, int nj, int nk, float halfrdx)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nk; k++)
+        for (int j = 0; j < nj; j++)
+            for (int i = 0; i < ni; i++) {
+                float ul = u[IDX3(i, j, k, ni + 1, nj)], ur = u[IDX3(i + 1, j, k, ni + 1, nj)];
+                float vf = v[IDX3(i, j, k, ni, nj + 1)], vb = v[IDX3(i, j + 1, k, ni, nj + 1)];
+                float wd = w[IDX3(i, j, k, ni, nj)],     wu = w[IDX3(i, j, k + 1, ni, nj)];
+                div[IDX3(i, j, k, ni, nj)] = halfrdx * ((ur - ul) + (vb - vf) + (wu - wd));
+            }
+}
+
+/* GPU_kernel.cu:1819-1837 jacobi_kernel: interior only, fixed summation order */
+void orc_jacobi_sweep(const float *p, const float *div, float *out,
+                      int ni, int nj, int nk, float alpha, float beta)
+{
+    long sj = ni, sk = (long)ni * nj;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k < nk - 1; k++)
+        for (int j = 1; j < nj - 1; j++)
+            for (int i = 1; i < ni - 1; i++) {
+                long id = IDX3(i, j, k, ni, nj);
+                out[id] = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk]
+                           + alpha * div[id]) * beta;
+            }
+}
+
+/* GPU_kernel.cu:1024-1041 gradient_kernel (float): nb* are BUFFER dims, window 2..cell-1 */
+void orc_gradient(float *field, const float *p, int nbi, int nbj, int nbk,
+                  int dx, int dy, int dz, float halfrdx)
+{
+    int pi = nbi - dx, pj = nbj - dy, pk = nbk - dz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 2; k < pk; k++)
+        for (int j = 2; j < pj; j++)
+            for (int i = 2; i < pi; i++) {
+                float p0 = p[IDX3(i, j, k, pi, pj)];
+                float p1 = p[IDX3(i - dx, j - dy, k - dz, pi, pj)];
+                field[IDX3(i, j, k, nbi, nbj)] -= halfrdx * (p0 - p1);
+            }
+}
+
+/* A15 re-specified: r = b - (sum6 x - 6x) as update_residual_kernel
+ * (GPU_kernel.cu:1239-1249, calc_poisson_value :1048-1060), exact sum r^2 and max |r|. */
+void orc_residual_norms(const float *div, const float *p, int ni, int nj, int nk,
+                        double *sum_sq, float *max_abs)
+{
+    long sj = ni, sk = (long)ni * nj;
+    double ss = 0.0;
+    float mx = 0.f;
+    for (int k = 1; k < nk - 1; k++)
+        for (int j = 1; j < nj - 1; j++)
+            for (int i = 1; i < ni - 1; i++) {
+                long id = IDX3(i, j, k, ni, nj);
+                float ax = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk])
+                         - p[id] * 6;
+                float r = div[id] - ax;
+                ss += (double)r * (double)r;
+                if (fabsf(r) > mx) mx = fabsf(r);
+            }
+    *sum_sq = ss;
+    *max_abs = mx;
+}
+
+/* GPU_kernel.cu:1839-1895 gpu_projection_jacobi.  The reference runs `iter` sweeps and
+ * then applies the OLDER buffer (iterate iter-1) in the gradient and leaves it in p
+ * (SURVEY Q1); restated directly: iter-1 sweeps, result in p. */
+void orc_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *p_temp,
+                           float *debug, int ni, int nj, int nk, int iter,
+                           float halfrdx, float alpha, float beta)
+{
+    size_t number = (size_t)ni * nj * nk;
+    orc_divergence(u, v, w, div, ni, nj, nk, halfrdx);
+    float *p_in = p, *p_out = p_temp;
+    for (int it = 0; it + 1 < iter; it++) {
+        if (debug) {
+            double ss; float mx;
+            orc_residual_norms(div, p_in, ni, nj, nk, &ss, &mx);
+            debug[it] = (float)ss; debug[2000 + it] = mx;
+        }
+        orc_jacobi_sweep(p_in, div, p_out, ni, nj, nk, alpha, beta);
+        float *t = p_in; p_in = p_out; p_out = t;
+    }
+    if (debug && iter > 0) {
+        double ss; float mx;
+        orc_residual_norms(div, p_in, ni, nj, nk, &ss, &mx);
+        debug[iter - 1] = (float)ss; debug[2000 + iter - 1] = mx;
+    }
+    if (p_in != p) memcpy(p, p_in, number * sizeof(float));
+    orc_gradient(u, p, ni + 1, nj, nk, 1, 0, 0, halfrdx);
+    orc_gradient(v, p, ni, nj + 1, nk, 0, 1, 0, halfrdx);
+    orc_gradient(w, p, ni, nj, nk + 1, 0, 0, 1, halfrdx);
+}
+
+/* BimocqGPUSolver.cpp:348-373 getCFL: max(1e-4, max|u|,|v|,|w|) */
+float orc_max_abs3(const float *u, const float *v, const float *w, int ni, int nj, int nk)
+{
+    float m = 1e-4f;
+    size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
+    for (size_t i = 0; i < nu; i++) if (fabsf(u[i]) > m) m = fabsf(u[i]);
+    for (size_t i = 0; i < nv; i++) if (fabsf(v[i]) > m) m = fabsf(v[i]);
+    for (size_t i = 0; i < nw; i++) if (fabsf(w[i]) > m) m = fabsf(w[i]);
+    return m;
+}
+
+/* =====================  step state machine  ===================================== */
+
+/* Mapping.h:92-96 MapperBaseGPU state */
+typedef struct {
+    float *fx, *fy, *fz, *bx, *by, *bz, *bpx, *bpy, *bpz, *ix, *iy, *iz;
+    unsigned total_reinit;
+} mapper_t;
+
+struct orc_solver {
+    int ni, nj, nk;
+    size_t n, nu, nv, nw;
+    float h, viscosity, blend, alpha, beta;
+    int jacobi_iters; float halfrdx;
+    /* BimocqGPUSolver.h:74-87 buffer roles */
+    float *U, *V, *W, *Ui, *Vi, *Wi, *Up, *Vp, *Wp, *Ut, *Vt, *Wt;
+    float *dUp, *dVp, *dWp, *dUe, *dVe, *dWe, *Su, *Sv, *Sw;
+    float *rho, *rhoi, *rhop, *rhot, *rhoe, *T, *Ti, *Tp, *Tt, *Te;
+    float *div, *p, *pt;
+    /* gpuMapper scratch: GPU_Advection.h:122-136 */
+    float *u_src, *v_src, *w_src, *xo, *yo, *zo;
+    mapper_t vel, scal;
+    int vel_last, scal_last;        /* BimocqGPUSolver.h:109-110 */
+    orc_emitter *em; int n_em;
+    float last_cfldt;
+};
+
+static float *zalloc(size_t n) { return (float *)calloc(n ? n : 1, sizeof(float)); }
+
+/* Mapping.cpp:276-345 MapperBaseGPU::init: maps start as (i*h, j*h, k*h) */
+static void mapper_init(mapper_t *m, int ni, int nj, int nk, float h)
+{
+    size_t n = (size_t)ni * nj * nk;
+    float **all[] = { &m->fx, &m->fy, &m->fz, &m->bx, &m->by, &m->bz,
+                      &m->bpx, &m->bpy, &m->bpz, &m->ix, &m->iy, &m->iz };
+    for (int a = 0; a < 12; a++) *all[a] = zalloc(n);
+    for (int k = 0; k < nk; k++)
+        for (int j = 0; j < nj; j++)
+            for (int i = 0; i < ni; i++) {
+                long id = IDX3(i, j, k, ni, nj);
+                m->ix[id] = (float)i * h; m->iy[id] = (float)j * h; m->iz[id] = (float)k * h;
+            }
+    float *dst[] = { m->fx, m->fy, m->fz, m->bx, m->by, m->bz, m->bpx, m->bpy, m->bpz };
+    float *src[] = { m->ix, m->iy, m->iz };
+    for (int a = 0; a < 9; a++) memcpy(dst[a], src[a % 3], n * sizeof(float));
+    m->total_reinit = 0;
+}
+
+static void mapper_free(mapper_t *m)
+{
+    float *all[] = { m->fx, m->fy, m->fz, m->bx, m->by, m->bz, m->bpx, m->bpy, m->bpz, m->ix, m->iy, m->iz };
+    for (int a = 0; a < 12; a++) free(all[a]);
+}
+
+orc_solver *orc_solver_create(int ni, int nj, int nk, float L, float viscosity, float blend)
+{
+    orc_solver *s = (orc_solver *)calloc(1, sizeof *s);
+    s->ni = ni; s->nj = nj; s->nk = nk;
+    s->h = L / (float)ni;                               /* BimocqGPUSolver.cpp:10 */
+    s->viscosity = viscosity; s->blend = blend;
+    s->n = (size_t)ni * nj * nk;
+    s->nu = (size_t)(ni + 1) * nj * nk; s->nv = (size_t)ni * (nj + 1) * nk; s->nw = (size_t)ni * nj * (nk + 1);
+    s->jacobi_iters = 100; s->halfrdx = 0.5f;           /* BimocqGPUSolver.cpp:409-410 */
+    float **ub[] = { &s->U, &s->Ui, &s->Up, &s->Ut, &s->dUp, &s->dUe, &s->Su, &s->u_src };
+    float **vb[] = { &s->V, &s->Vi, &s->Vp, &s->Vt, &s->dVp, &s->dVe, &s->Sv, &s->v_src };
+    float **wb[] = { &s->W, &s->Wi, &s->Wp, &s->Wt, &s->dWp, &s->dWe, &s->Sw, &s->w_src };
+    for (int a = 0; a < 8; a++) { *ub[a] = zalloc(s->nu); *vb[a] = zalloc(s->nv); *wb[a] = zalloc(s->nw); }
+    float **sb[] = { &s->rho, &s->rhoi, &s->rhop, &s->rhot, &s->rhoe, &s->T, &s->Ti, &s->Tp, &s->Tt, &s->Te,
+                     &s->div, &s->p, &s->pt, &s->xo, &s->yo, &s->zo };
+    for (int a = 0; a < 16; a++) *sb[a] = zalloc(s->n);
+    mapper_init(&s->vel, ni, nj, nk, s->h);
+    mapper_init(&s->scal, ni, nj, nk, s->h);
+    s->vel_last = -11; s->scal_last = -31;
+    return s;
+}
+
+void orc_solver_destroy(orc_solver *s)
+{
+    if (!s) return;
+    float *all[] = { s->U, s->V, s->W, s->Ui, s->Vi, s->Wi, s->Up, s->Vp, s->Wp, s->Ut, s->Vt, s->Wt,
+                     s->dUp, s->dVp, s->dWp, s->dUe, s->dVe, s->dWe, s->Su, s->Sv, s->Sw,
+                     s->rho, s->rhoi, s->rhop, s->rhot, s->rhoe, s->T, s->Ti, s->Tp, s->Tt, s->Te,
+                     s->div, s->p, s->pt, s->u_src, s->v_src, s->w_src, s->xo, s->yo, s->zo };
+    for (size_t a = 0; a < sizeof all / sizeof *all; a++) free(all[a]);
+    mapper_free(&s->vel); mapper_free(&s->scal);
+    free(s->em);
+    free(s);
+}
+
+/* BimocqGPUSolver.cpp:529-534: _alpha = drop (rho coefficient), _beta = raise (T coefficient) */
+void orc_solver_set_smoke(orc_solver *s, float drop_alpha, float rise_beta,
+                          const orc_emitter *emitters, int n_emitters)
+{
+    s->alpha = drop_alpha; s->beta = rise_beta;
+    free(s->em);
+    s->em = (orc_emitter *)malloc(sizeof(orc_emitter) * (size_t)(n_emitters > 0 ? n_emitters : 1));
+    if (n_emitters > 0) memcpy(s->em, emitters, sizeof(orc_emitter) * (size_t)n_emitters);
+    s->n_em = n_emitters;
+}
+
+void orc_solver_set_projection(orc_solver *s, int jacobi_iters, float halfrdx)
+{
+    s->jacobi_iters = jacobi_iters; s->halfrdx = halfrdx;
+}
+
+/* Mapping.cpp:347-373 updateMapping = updateBackward (host sub-step loop around the DMC
+ * kernel + 3 copies out->in, GPU_Advection.h:460-470) then updateForward */
+static void mapper_update(orc_solver *s, mapper_t *m, float cfldt, float dt)
+{
+    float T = 0.f, substep = cfldt;
+    while (T < dt) {
+        if (T + substep > dt) substep = dt - T;
+        orc_solve_backwardDMC(s->U, s->V, s->W, m->bx, m->by, m->bz, s->xo, s->yo, s->zo,
+                              s->h, s->ni, s->nj, s->nk, substep);
+        memcpy(m->bx, s->xo, s->n * sizeof(float));
+        memcpy(m->by, s->yo, s->n * sizeof(float));
+        memcpy(m->bz, s->zo, s->n * sizeof(float));
+        T += substep;
+    }
+    orc_solve_forward(s->U, s->V, s->W, m->fx, m->fy, m->fz, s->h, s->ni, s->nj, s->nk, cfldt, dt);
+}
+
+/* Mapping.cpp:430-447 */
+static void mapper_reinit(orc_solver *s, mapper_t *m)
+{
+    size_t b = s->n * sizeof(float);
+    m->total_reinit++;
+    memcpy(m->bpx, m->bx, b); memcpy(m->bpy, m->by, b); memcpy(m->bpz, m->bz, b);
+    memcpy(m->bx, m->ix, b);  memcpy(m->by, m->iy, b);  memcpy(m->bz, m->iz, b);
+    memcpy(m->fx, m->ix, b);  memcpy(m->fy, m->iy, b);  memcpy(m->fz, m->iz, b);
+}
+
+/* Mapping.cpp:393-407 + GPU_Advection.h:505-528 */
+static void advect_scalar(orc_solver *s, float *f, float *finit, const float *fprev)
+{
+    mapper_t *m = &s->scal;
+    memset(f, 0, s->n * sizeof(float));
+    orc_advect_field(f, finit, m->bx, m->by, m->bz, s->h, s->ni, s->nj, s->nk, 0);
+    memset(s->u_src, 0, s->n * sizeof(float));
+    orc_compensate_field(f, finit, s->u_src, m->fx, m->fy, m->fz, m->bx, m->by, m->bz,
+                         s->h, s->ni, s->nj, s->nk, 0);
+    float b = (m->total_reinit != 0) ? s->blend : 1.f;
+    orc_advect_field_double(f, fprev, m->bx, m->by, m->bz, m->bpx, m->bpy, m->bpz,
+                            s->h, s->ni, s->nj, s->nk, 0, b);
+}
+
+/* BimocqGPUSolver.cpp:129-230 advanceBimocq with the Jacobi projection branch
+ * (:408-410; div/p/p_temp get dedicated buffers -- the reference lends it DensityTemp,
+ * TemperatureTemp and TempSrcV, all dead at that point). */
+void orc_solver_advance(orc_solver *s, int framenum, float dt)
+{
+    const int ni = s->ni, nj = s->nj, nk = s->nk;
+    const float h = s->h;
+    size_t bu = s->nu * sizeof(float), bv = s->nv * sizeof(float), bw = s->nw * sizeof(float), bs = s->n * sizeof(float);
+    float proj_coeff = 2.f;
+
+    /* getCFL(): BimocqGPUSolver.cpp:348-373 (evaluated on the current device fields: equal
+     * to the reference's host copies when outputResult follows every advance) */
+    float cfldt = h / orc_max_abs3(s->U, s->V, s->W, ni, nj, nk);
+    s->last_cfldt = cfldt;
+
+    mapper_update(s, &s->vel, cfldt, dt);                               /* :138 */
+    mapper_update(s, &s->scal, cfldt, dt);                              /* :139 */
+
+    /* :143 VelocityAdvector.advectVelocity -> Mapping.cpp:375-391 */
+    {
+        mapper_t *m = &s->vel;
+        memset(s->U, 0, bu); memset(s->V, 0, bv); memset(s->W, 0, bw);  /* GPU_Advection.h:477-479 */
+        orc_advect_velocity(s->U, s->V, s->W, s->Ui, s->Vi, s->Wi, m->bx, m->by, m->bz, h, ni, nj, nk, 0);
+        memset(s->u_src, 0, bu); memset(s->v_src, 0, bv); memset(s->w_src, 0, bw);
+        orc_compensate_velocity(s->U, s->V, s->W, s->Ui, s->Vi, s->Wi, s->u_src, s->v_src, s->w_src,
+                                m->fx, m->fy, m->fz, m->bx, m->by, m->bz, h, ni, nj, nk, 0);
+        float b = (m->total_reinit != 0) ? s->blend : 1.f;
+        orc_advect_vel_double(s->U, s->V, s->W, s->Up, s->Vp, s->Wp, m->bx, m->by, m->bz,
+                              m->bpx, m->bpy, m->bpz, h, ni, nj, nk, 0, b);
+    }
+    advect_scalar(s, s->rho, s->rhoi, s->rhop);                         /* :144 */
+    advect_scalar(s, s->T, s->Ti, s->Tp);                               /* :145 */
+
+    memcpy(s->Ut, s->U, bu); memcpy(s->Vt, s->V, bv); memcpy(s->Wt, s->W, bw);   /* :157-159 */
+
+    for (int e = 0; e < s->n_em; e++)                                    /* :376-392 */
+        if (framenum < s->em[e].emit_frames)
+            orc_emit_smoke(s->U, s->V, s->W, s->rho, s->T, h, ni, nj, nk,
+                           s->em[e].cx, s->em[e].cy, s->em[e].cz, s->em[e].radius,
+                           s->em[e].density, s->em[e].temperature, s->em[e].emiter);
+    orc_add_buoyancy(s->V, s->rho, s->T, ni, nj, nk, s->alpha, s->beta, dt);  /* :394-397 */
+
+    if (s->viscosity != 0.f) {                                          /* :167-172 incl. the aliasing of Q7 */
+        float coef = s->viscosity * (dt / (h * h));                     /* :401 */
+        orc_diffuse_field(s->U, s->Ut, s->Su, ni + 1, nj, nk, 20, coef);
+        orc_diffuse_field(s->V, s->Vt, s->Sv, ni, nj + 1, nk, 20, coef);
+        orc_diffuse_field(s->W, s->Wt, s->Sw, ni, nj, nk + 1, 20, coef);
+    }
+
+    orc_add_field(s->dUe, s->U, s->Ut, -1.f, (int)s->nu);               /* :175-177 */
+    orc_add_field(s->dVe, s->V, s->Vt, -1.f, (int)s->nv);
+    orc_add_field(s->dWe, s->W, s->Wt, -1.f, (int)s->nw);
+    memcpy(s->Ut, s->U, bu); memcpy(s->Vt, s->V, bv); memcpy(s->Wt, s->W, bw);   /* :179-181 */
+
+    /* projection(): GPU_Advection.h:602-608 zeroes div, p, p_temp first */
+    memset(s->div, 0, bs); memset(s->p, 0, bs); memset(s->pt, 0, bs);
+    orc_projection_jacobi(s->U, s->V, s->W, s->div, s->p, s->pt, NULL, ni, nj, nk,
+                          s->jacobi_iters, s->halfrdx, -1.f, (float)(1.0 / 6.0));
+
+    memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs);               /* :185-186 */
+    memcpy(s->dUp, s->U, bu); memcpy(s->dVp, s->V, bv); memcpy(s->dWp, s->W, bw);  /* :188-190 */
+    orc_add(s->dUp, s->Ut, -1.f, (int)s->nu);                           /* :191-193 */
+    orc_add(s->dVp, s->Vt, -1.f, (int)s->nv);
+    orc_add(s->dWp, s->Wt, -1.f, (int)s->nw);
+    memcpy(s->rhoe, s->rho, bs); memcpy(s->Te, s->T, bs);               /* :195-198: identically 0 (Q8) */
+    orc_add(s->rhoe, s->rhot, -1.f, (int)s->n);
+    orc_add(s->Te, s->Tt, -1.f, (int)s->n);
+
+    if (framenum - s->vel_last > 10) { s->vel_last = framenum; proj_coeff = 1.f; }   /* :200-205 */
+    if (framenum - s->scal_last > 30) { s->scal_last = framenum; }                    /* :207-211 */
+
+    {   /* :213-216 */
+        mapper_t *m = &s->vel;
+        orc_accumulate_velocity(s->dUe, s->dVe, s->dWe, s->Ui, s->Vi, s->Wi, m->fx, m->fy, m->fz, h, ni, nj, nk, 0, 1.f);
+        orc_accumulate_velocity(s->dUp, s->dVp, s->dWp, s->Ui, s->Vi, s->Wi, m->fx, m->fy, m->fz, h, ni, nj, nk, 0, proj_coeff);
+        mapper_t *q = &s->scal;
+        orc_accumulate_field(s->rhoe, s->rhoi, q->fx, q->fy, q->fz, h, ni, nj, nk, 0, 1.f);
+        orc_accumulate_field(s->Te, s->Ti, q->fx, q->fy, q->fz, h, ni, nj, nk, 0, 1.f);
+    }
+
+    {   /* :218-223 `if (1)`: reinitialise every frame (Q5) */
+        mapper_t *m = &s->vel;
+        mapper_reinit(s, m);
+        memcpy(s->Up, s->Ui, bu); memcpy(s->Vp, s->Vi, bv); memcpy(s->Wp, s->Wi, bw);  /* :509-511 */
+        memcpy(s->Ui, s->U, bu);  memcpy(s->Vi, s->V, bv);  memcpy(s->Wi, s->W, bw);   /* :513-515 */
+        orc_accumulate_velocity(s->dUp, s->dVp, s->dWp, s->Ui, s->Vi, s->Wi, m->fx, m->fy, m->fz, h, ni, nj, nk, 0, 1.f);
+    }
+    {   /* :225-229 */
+        mapper_reinit(s, &s->scal);
+        memcpy(s->rhop, s->rhoi, bs); memcpy(s->Tp, s->Ti, bs);         /* :522-523 */
+        memcpy(s->rhoi, s->rho, bs);  memcpy(s->Ti, s->T, bs);          /* :525-526 */
+    }
+}
+
+const float *orc_solver_field(orc_solver *s, int which, long *count)
+{
+    const float *f[] = { s->rho, s->T, s->U, s->V, s->W, s->Ui, s->Vi, s->Wi, s->rhoi, s->Ti,
+                         s->vel.fx, s->vel.fy, s->vel.fz, s->vel.bx, s->vel.by, s->vel.bz, s->p };
+    size_t c[] = { s->n, s->n, s->nu, s->nv, s->nw, s->nu, s->nv, s->nw, s->n, s->n,
+                   s->n, s->n, s->n, s->n, s->n, s->n, s->n };
+    if (which < 0 || which > 16) { if (count) *count = 0; return NULL; }
+    if (count) *count = (long)c[which];
+    return f[which];
+}
+
+float orc_solver_last_cfldt(const orc_solver *s) { return s->last_cfldt; }

@@ -1,0 +1,134 @@
+"""ctypes binding of the CPU oracle (oracle/bimocq_oracle.c) -- test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+FP = C.POINTER(C.c_float)
+c_f, c_i = C.c_float, C.c_int
+
+
+def build(march="x86-64", out="_build"):
+    """(re)build liboracle.so with gcc; returns its path."""
+    so = os.path.join(ORACLE_DIR, out, "liboracle.so")
+    src = [os.path.join(ORACLE_DIR, f) for f in ("bimocq_oracle.c", "bimocq_oracle.h", "Makefile")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, f"MARCH={march}", f"OUT={out}"])
+    return so
+
+
+class Emitter(C.Structure):
+    _fields_ = [("cx", c_f), ("cy", c_f), ("cz", c_f), ("radius", c_f), ("density", c_f),
+                ("temperature", c_f), ("emiter", c_f), ("emit_frames", c_i)]
+
+
+_SIGS = {
+    "orc_expf": (c_f, [c_f]),
+    "orc_lerp": (c_f, [c_f, c_f, c_f]),
+    "orc_sample": (c_f, [FP, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "orc_solve_forward": (None, [FP] * 6 + [c_f, c_i, c_i, c_i, c_f, c_f]),
+    "orc_solve_backwardDMC": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_f]),
+    "orc_advect_velocity": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_advect_vel_double": (None, [FP] * 12 + [c_f, c_i, c_i, c_i, c_i, c_f]),
+    "orc_advect_field": (None, [FP] * 5 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_advect_field_double": (None, [FP] * 8 + [c_f, c_i, c_i, c_i, c_i, c_f]),
+    "orc_accumulate_velocity": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_i, c_f]),
+    "orc_accumulate_field": (None, [FP] * 5 + [c_f, c_i, c_i, c_i, c_i, c_f]),
+    "orc_estimate_distortion": (None, [FP] * 7 + [c_f, c_i, c_i, c_i]),
+    "orc_add": (None, [FP, FP, c_f, c_i]),
+    "orc_compensate_velocity": (None, [FP] * 15 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_compensate_field": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_semilag": (None, [FP] * 5 + [c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_f]),
+    "orc_emit_smoke": (None, [FP] * 5 + [c_f, c_i, c_i, c_i] + [c_f] * 7),
+    "orc_add_buoyancy": (None, [FP] * 3 + [c_i, c_i, c_i, c_f, c_f, c_f]),
+    "orc_diffuse_field": (None, [FP] * 3 + [c_i, c_i, c_i, c_i, c_f]),
+    "orc_add_field": (None, [FP, FP, FP, c_f, c_i]),
+    "orc_mad": (None, [FP, FP, FP, c_f, c_f, c_i]),
+    "orc_clamp_extrema_box": (None, [FP, FP, c_i, c_i, c_i]),
+    "orc_divergence": (None, [FP] * 4 + [c_i, c_i, c_i, c_f]),
+    "orc_jacobi_sweep": (None, [FP] * 3 + [c_i, c_i, c_i, c_f, c_f]),
+    "orc_gradient": (None, [FP, FP, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "orc_residual_norms": (None, [FP, FP, c_i, c_i, c_i, C.POINTER(C.c_double), FP]),
+    "orc_projection_jacobi": (None, [FP] * 7 + [c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
+    "orc_max_abs3": (c_f, [FP] * 3 + [c_i, c_i, c_i]),
+    "orc_solver_create": (C.c_void_p, [c_i, c_i, c_i, c_f, c_f, c_f]),
+    "orc_solver_destroy": (None, [C.c_void_p]),
+    "orc_solver_set_smoke": (None, [C.c_void_p, c_f, c_f, C.POINTER(Emitter), c_i]),
+    "orc_solver_set_projection": (None, [C.c_void_p, c_i, c_f]),
+    "orc_solver_advance": (None, [C.c_void_p, c_i, c_f]),
+    "orc_solver_field": (FP, [C.c_void_p, c_i, C.POINTER(C.c_long)]),
+    "orc_solver_last_cfldt": (c_f, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib(march="x86-64", out="_build"):
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build(march, out))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def fp(a):
+    """float32 C-contiguous ndarray -> float* (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(FP)
+
+
+FIELD_IDS = {"rho": 0, "T": 1, "u": 2, "v": 3, "w": 4, "uinit": 5, "vinit": 6, "winit": 7,
+             "rhoinit": 8, "Tinit": 9, "fx": 10, "fy": 11, "fz": 12, "bx": 13, "by": 14, "bz": 15, "p": 16}
+
+
+class OracleSolver:
+    """BimocqGPUSolver surface (advance + field access) on the CPU oracle."""
+
+    def __init__(self, ni, nj, nk, L=1.0, viscosity=0.0, blend=1.0):
+        self.l = lib()
+        self.ni, self.nj, self.nk = ni, nj, nk
+        self.h = np.float32(L) / np.float32(ni)
+        self.s = self.l.orc_solver_create(ni, nj, nk, L, viscosity, blend)
+
+    def set_smoke(self, drop, rise, emitters):
+        arr = (Emitter * max(1, len(emitters)))()
+        for i, e in enumerate(emitters):
+            arr[i] = Emitter(*e)
+        self.l.orc_solver_set_smoke(self.s, drop, rise, arr, len(emitters))
+
+    def set_projection(self, iters, halfrdx):
+        self.l.orc_solver_set_projection(self.s, iters, halfrdx)
+
+    def advance(self, frame, dt):
+        self.l.orc_solver_advance(self.s, frame, dt)
+
+    def field(self, name):
+        cnt = C.c_long(0)
+        p = self.l.orc_solver_field(self.s, FIELD_IDS[name], C.byref(cnt))
+        return np.ctypeslib.as_array(p, shape=(cnt.value,)).copy()
+
+    @property
+    def cfldt(self):
+        return self.l.orc_solver_last_cfldt(self.s)
+
+    def close(self):
+        if self.s:
+            self.l.orc_solver_destroy(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,301 @@
+"""GPU parity, operator by operator: HIP path (through the C-ABI) vs the CPU oracle on the same
+deterministic inputs.  Bar: bit-exact (value equality; the sign of zero is not compared), except
+the emitter's acosf/cosf/hypotf (<= 4 ulp of 0.06) and the summed residual norm (1e-6 relative).
+
+Grids: a non-cubic 24x20x16 with h = 1/24 (IEEE-division path, catches index-order errors) and
+32^3 with h = 1/32 (power-of-two spacing fast path).
+"""
+import numpy as np
+import pytest
+
+import fields as F
+from oracle_lib import fp, lib as oracle
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [(24, 20, 16, 1.0 / 24), (32, 32, 32, 1.0 / 32)]
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import gpufluidsimulation_amd as bq
+    cache = {}
+
+    def get(ni, nj, nk, h):
+        key = (ni, nj, nk, h)
+        if key not in cache:
+            cache[key] = bq.GpuMapper(ni, nj, nk, h)
+        return cache[key]
+    yield get
+    bq.check()
+
+
+def dev(*arrays):
+    from gpufluidsimulation_amd import DeviceBuffer
+    return [DeviceBuffer.from_numpy(a) for a in arrays]
+
+
+def setup(ni, nj, nk, h):
+    h = float(np.float32(h))
+    u, v, w = F.velocity(ni, nj, nk, h)
+    fwd = F.warped_maps(ni, nj, nk, h, 0.8, 0.3)
+    back = F.warped_maps(ni, nj, nk, h, -0.7, 1.1)
+    backp = F.warped_maps(ni, nj, nk, h, 0.5, 2.0)
+    return h, (u, v, w), fwd, back, backp
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+@pytest.mark.parametrize("dtscale", [1.0, -1.0, 2.7])
+def test_solve_forward(gm, ni, nj, nk, h, dtscale):
+    h, vel, fwd, _, _ = setup(ni, nj, nk, h)
+    cfldt, dt = 0.9 * h / 0.35, dtscale * 2 * h
+    ref = [a.copy() for a in fwd]
+    oracle().orc_solve_forward(*map(fp, vel), *map(fp, ref), h, ni, nj, nk, cfldt, dt)
+    m = gm(ni, nj, nk, h)
+    d = dev(*vel, *fwd)
+    m.solveForward(*d, cfldt, dt)
+    for r, g in zip(ref, d[3:]):
+        assert F.same(r, g.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_solve_backward_dmc(gm, ni, nj, nk, h):
+    h, vel, _, back, _ = setup(ni, nj, nk, h)
+    sub = 0.8 * h / 0.35
+    ref_out = [a.copy() for a in back]
+    oracle().orc_solve_backwardDMC(*map(fp, vel), *map(fp, back), *map(fp, ref_out), h, ni, nj, nk, sub)
+    m = gm(ni, nj, nk, h)
+    d = dev(*vel, *back)
+    for o, b in zip((m.x_out, m.y_out, m.z_out), back):
+        o.upload(b)                       # nodes outside 2..n-3 keep what the out buffer held
+    m.solveBackwardDMC(*d, sub)
+    for r, g in zip(ref_out, d[3:]):
+        assert F.same(r, g.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+@pytest.mark.parametrize("is_point", [False, True])
+def test_advect_velocity_and_field(gm, ni, nj, nk, h, is_point):
+    h, vel, _, back, _ = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    ref = [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+    oracle().orc_advect_velocity(*map(fp, ref), *map(fp, vel), *map(fp, back), h, ni, nj, nk, int(is_point))
+    m = gm(ni, nj, nk, h)
+    out = dev(*[np.full(c, 7.0, np.float32) for c in (nu, nv, nw)])      # advectVelocity must zero them
+    dv, db = dev(*vel), dev(*back)
+    m.advectVelocity(*out, *dv, *db, is_point)
+    for r, g in zip(ref, out):
+        assert F.same(r, g.numpy())
+    rho = F.scalar(ni, nj, nk, 0.4)
+    rref = np.zeros(n, np.float32)
+    oracle().orc_advect_field(fp(rref), fp(rho), *map(fp, back), h, ni, nj, nk, int(is_point))
+    (drho,), (dout,) = dev(rho), dev(np.ones(n, np.float32))
+    m.advectField(dout, drho, *db, is_point)
+    assert F.same(rref, dout.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+@pytest.mark.parametrize("blend", [1.0, 0.6])
+def test_advect_double(gm, ni, nj, nk, h, blend):
+    import gpufluidsimulation_amd as bq
+    h, vel, _, back, backp = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    cur = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    ref = [a.copy() for a in cur]
+    oracle().orc_advect_vel_double(*map(fp, ref), *map(fp, vel), *map(fp, back), *map(fp, backp),
+                                   h, ni, nj, nk, 0, blend)
+    m = gm(ni, nj, nk, h)
+    for skip in (1, 0):                    # unit-blend fast path and the full kernel must agree
+        bq.hip_lib().fl_set_option(bq._lib.FL_OPT_SKIP_UNIT_BLEND, skip)
+        d = dev(*cur)
+        m.advectVelocityDouble(*d, *dev(*vel), *dev(*back), *dev(*backp), False, blend)
+        for r, g in zip(ref, d):
+            assert F.same(r, g.numpy())
+    bq.hip_lib().fl_set_option(bq._lib.FL_OPT_SKIP_UNIT_BLEND, 1)
+    rho, prev = F.scalar(ni, nj, nk, 0.9), F.scalar(ni, nj, nk, 1.9)
+    rref = rho.copy()
+    oracle().orc_advect_field_double(fp(rref), fp(prev), *map(fp, back), *map(fp, backp), h, ni, nj, nk, 0, blend)
+    (dr, dp) = dev(rho, prev)
+    m.advectFieldDouble(dr, dp, *dev(*back), *dev(*backp), False, blend)
+    assert F.same(rref, dr.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_compensate_velocity_and_field(gm, ni, nj, nk, h):
+    h, vel, fwd, back, _ = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    cur = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    ru, ri = [a.copy() for a in cur], [a.copy() for a in vel]
+    rs = [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+    oracle().orc_compensate_velocity(*map(fp, ru), *map(fp, ri), *map(fp, rs), *map(fp, fwd), *map(fp, back),
+                                     h, ni, nj, nk, 0)
+    m = gm(ni, nj, nk, h)
+    du, di = dev(*cur), dev(*vel)
+    m.compensateVelocity(*du, *di, *dev(*fwd), *dev(*back), False)
+    for r, g in zip(ru + ri, du + di):          # compensated field AND the clobbered init (Q3)
+        assert F.same(r, g.numpy())
+    for r, g in zip(rs, (m.u_src, m.v_src, m.w_src)):
+        assert F.same(r, g.numpy())
+    rho, init = F.scalar(ni, nj, nk, 0.9), F.scalar(ni, nj, nk, 1.9)
+    rr, rin, rsrc = rho.copy(), init.copy(), np.zeros(n, np.float32)
+    oracle().orc_compensate_field(fp(rr), fp(rin), fp(rsrc), *map(fp, fwd), *map(fp, back), h, ni, nj, nk, 0)
+    dr, dinit = dev(rho, init)
+    m.compensateField(dr, dinit, *dev(*fwd), *dev(*back), False)
+    assert F.same(rr, dr.numpy()) and F.same(rin, dinit.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+@pytest.mark.parametrize("coeff", [1.0, 2.0, -0.5])
+def test_accumulate(gm, ni, nj, nk, h, coeff):
+    h, vel, fwd, _, _ = setup(ni, nj, nk, h)
+    init = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    ref = [a.copy() for a in init]
+    oracle().orc_accumulate_velocity(*map(fp, vel), *map(fp, ref), *map(fp, fwd), h, ni, nj, nk, 0, coeff)
+    m = gm(ni, nj, nk, h)
+    d = dev(*init)
+    m.accumulateVelocity(*dev(*vel), *d, *dev(*fwd), False, coeff)
+    for r, g in zip(ref, d):
+        assert F.same(r, g.numpy())
+    ch, ini = F.scalar(ni, nj, nk, 0.5), F.scalar(ni, nj, nk, 1.5)
+    rr = ini.copy()
+    oracle().orc_accumulate_field(fp(ch), fp(rr), *map(fp, fwd), h, ni, nj, nk, 0, coeff)
+    dch, dini = dev(ch, ini)
+    m.accumulateField(dch, dini, *dev(*fwd), False, coeff)
+    assert F.same(rr, dini.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_estimate_distortion_and_semilag(gm, ni, nj, nk, h):
+    h, vel, fwd, back, _ = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    ref = np.zeros(n, np.float32)
+    oracle().orc_estimate_distortion(fp(ref), *map(fp, back), *map(fp, fwd), h, ni, nj, nk)
+    m = gm(ni, nj, nk, h)
+    (dd,) = dev(np.ones(n, np.float32))
+    m.estimateDistortionCUDA(dd, *dev(*back), *dev(*fwd))
+    assert F.same(ref, dd.numpy())
+    cfldt, dt = 0.9 * h / 0.35, -1.5 * h
+    src = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    refs = [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+    for r, s, d3 in zip(refs, src, ((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+        oracle().orc_semilag(fp(r), fp(s), *map(fp, vel), *d3, h, ni, nj, nk, cfldt, dt)
+    outs = dev(*[np.ones(c, np.float32) for c in (nu, nv, nw)])
+    m.semilagAdvectVelocity(*outs, *dev(*src), *dev(*vel), cfldt, dt)
+    for r, g in zip(refs, outs):
+        assert F.same(r, g.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_streaming_ops(gm, ni, nj, nk, h):
+    h, vel, _, _, _ = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    m = gm(ni, nj, nk, h)
+    a, b = F.scalar(ni + 1, nj, nk, 0.3), F.scalar(ni + 1, nj, nk, 1.7)
+    number = nu - 5                              # not a multiple of 256: the tail must stay untouched
+    ra = a.copy(); oracle().orc_add(fp(ra), fp(b), -1.0, number)
+    da, db = dev(a, b); m.add(da, db, -1.0, number)
+    assert F.same(ra, da.numpy())
+    ro = np.full(nu, 3.0, np.float32); oracle().orc_add_field(fp(ro), fp(a), fp(b), -1.0, number)
+    (do,) = dev(np.full(nu, 3.0, np.float32)); m.addFields(do, da, db, -1.0, number)
+    a2 = da.numpy()
+    ro2 = np.full(nu, 3.0, np.float32); oracle().orc_add_field(fp(ro2), fp(a2), fp(b), -1.0, number)
+    assert F.same(ro2, do.numpy())
+    rm = np.full(nu, 3.0, np.float32); oracle().orc_mad(fp(rm), fp(a2), fp(b), 2.0, -1.0, number)
+    (dm,) = dev(np.full(nu, 3.0, np.float32)); m.mad(dm, da, db, 2.0, -1.0, number)
+    assert F.same(rm, dm.numpy())
+    # buoyancy (Q9-fixed semantics)
+    rho, T = F.scalar(ni, nj, nk, 0.2), F.scalar(ni, nj, nk, 2.2)
+    rv = vel[1].copy(); oracle().orc_add_buoyancy(fp(rv), fp(rho), fp(T), ni, nj, nk, 0.3, 1.1, 2 * h)
+    (dvv, dr, dT) = dev(vel[1], rho, T); m.add_buoyancy(dvv, dr, dT, 0.3, 1.1, 2 * h)
+    assert F.same(rv, dvv.numpy())
+    # device CFL
+    import gpufluidsimulation_amd as bq
+    d = dev(*vel)
+    got = bq.hip_lib().gpu_max_abs3(d[0].ptr, d[1].ptr, d[2].ptr, ni, nj, nk)
+    assert got == oracle().orc_max_abs3(*map(fp, vel), ni, nj, nk)
+    z = dev(*[np.zeros_like(x) for x in vel])
+    assert bq.hip_lib().gpu_max_abs3(z[0].ptr, z[1].ptr, z[2].ptr, ni, nj, nk) == np.float32(1e-4)
+    # identity maps
+    mx = dev(*[np.zeros(n, np.float32)] * 3)
+    bq.hip_lib().gpu_init_maps(mx[0].ptr, mx[1].ptr, mx[2].ptr, h, ni, nj, nk)
+    for r, g in zip(F.identity_maps(ni, nj, nk, h), mx):
+        assert F.same(r, g.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_emit_smoke(gm, ni, nj, nk, h):
+    h = float(np.float32(h))
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    L = ni * h
+    args = (0.45 * L, 0.41 * nj * h, 0.5 * nk * h, 0.22 * L, 1.0, 50.0)
+    m = gm(ni, nj, nk, h)
+    for emiter in (0.0, 1.0, -1.0):
+        ref = [np.full(c, 0.5, np.float32) for c in (nu, nv, nw, n, n)]
+        oracle().orc_emit_smoke(*map(fp, ref), h, ni, nj, nk, *args, emiter)
+        d = dev(*[np.full(c, 0.5, np.float32) for c in (nu, nv, nw, n, n)])
+        m.emitSmoke(*d, *args, emiter)
+        got = [g.numpy() for g in d]
+        assert (ref[3] == 1.0).sum() > 20                       # the sphere really hits voxels
+        for r, g in zip(ref[1:], got[1:]):
+            assert F.same(r, g)                                 # v, w, rho, T: exact
+        # u: acosf/cosf/hypotf come from two libms -> a few ulp of 0.06
+        assert np.array_equal(ref[0] == 0.5, got[0] == 0.5)
+        assert F.maxdiff(ref[0], got[0]) <= 4 * np.spacing(np.float32(0.06))
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+@pytest.mark.parametrize("iters", [1, 6, 7])
+def test_diffuse(gm, ni, nj, nk, h, iters):
+    h = float(np.float32(h))
+    m = gm(ni, nj, nk, h)
+    for nb in ((ni + 1, nj, nk), (ni, nj + 1, nk), (ni, nj, nk + 1)):
+        f = F.scalar(*nb, 0.6)
+        t0 = F.scalar(*nb, 1.6)
+        t1 = F.scalar(*nb, 2.6)                                 # stale border of tmp1 leaks into the result (Q7)
+        rf, r0, r1 = f.copy(), t0.copy(), t1.copy()
+        oracle().orc_diffuse_field(fp(rf), fp(r0), fp(r1), *nb, iters, 0.37)
+        df, d0, d1 = dev(f, t0, t1)
+        m.diffuseField(df, d0, d1, *nb, iters, 0.37)
+        assert F.same(rf, df.numpy()) and F.same(r0, d0.numpy()) and F.same(r1, d1.numpy())
+    m.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_clamp_extrema_box(gm, ni, nj, nk, h):
+    import gpufluidsimulation_amd as bq
+    before, after = F.scalar(ni + 1, nj, nk, 0.2), F.scalar(ni + 1, nj, nk, 0.45, amp=1.4)
+    ref = after.copy()
+    oracle().orc_clamp_extrema_box(fp(before), fp(ref), ni + 1, nj, nk)
+    db, da = dev(before, after)
+    bq.hip_lib().gpu_clamp_extrema_box(db.ptr, da.ptr, ni + 1, nj, nk)
+    assert F.same(ref, da.numpy())
+    assert not F.same(ref, after)
+    # idempotent and bounded by the neighbourhood (KAT 7)
+    bq.hip_lib().gpu_clamp_extrema_box(db.ptr, da.ptr, ni + 1, nj, nk)
+    assert F.same(ref, da.numpy())
+    bq.check()
+
+
+def test_unsupported_and_bad_arguments():
+    import gpufluidsimulation_amd as bq
+    lib = bq.hip_lib()
+    lib.fl_clear_error()
+    lib.gpu_clamp_extrema(None, None, None, None, None, 8, 8, 8, 0, 0, 0, 0.0, 0.0, 0.0, 0.1, 0.1)
+    assert lib.fl_last_error() == bq._lib.FL_ERR_UNSUPPORTED
+    with pytest.raises(bq.BimocqError):
+        bq.check()
+    lib.gpu_add(None, None, 1.0, 16)
+    assert lib.fl_last_error() == bq._lib.FL_ERR_BAD_ARGUMENT
+    lib.fl_clear_error()
+    lib.gpu_solve_forward(None, None, None, None, None, None, 0.1, 8, 8, 8, 0.1, 0.1)
+    assert lib.fl_last_error() == bq._lib.FL_ERR_BAD_ARGUMENT
+    lib.fl_clear_error()

@@ -1,0 +1,154 @@
+"""GPU parity of the pressure projection: divergence, Jacobi sweeps (generic and
+LDS-tiled kernels, every tile-edge case), gradient, the full gpu_projection_jacobi with its
+off-by-one (Q1) and quarter-strength (Q2) behaviour, residual norms.  Bit-exact vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fields as F
+from oracle_lib import fp, lib as oracle
+
+pytestmark = pytest.mark.gpu
+
+ALPHA, BETA = -1.0, float(np.float32(1.0 / 6.0))
+
+
+def dev(*arrays):
+    from gpufluidsimulation_amd import DeviceBuffer
+    return [DeviceBuffer.from_numpy(a) for a in arrays]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import gpufluidsimulation_amd as bq
+    lib = bq.hip_lib()
+    assert lib.fl_init(0) == 0, lib.fl_last_error_string()
+    yield lib
+    lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    lib.fl_set_option(bq._lib.FL_OPT_RESIDUAL_STRIDE, 0)
+    bq.check()
+
+
+# (ni, nj, nk): generic-only (ni%4 != 0 or small), 128-wide tile, 256-wide tile, two x tiles with a
+# 4-column remainder (x halo columns), ragged y (nj not a multiple of the tile), k chunks with remainder
+JACOBI_GRIDS = [(24, 20, 16), (30, 9, 7), (32, 32, 32), (64, 48, 40), (128, 37, 19), (256, 32, 24),
+                (260, 20, 12), (516, 18, 11), (36, 5, 3), (32, 3, 3)]
+
+
+@pytest.mark.parametrize("ni,nj,nk", JACOBI_GRIDS)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_jacobi_sweeps(hip, ni, nj, nk, variant):
+    import gpufluidsimulation_amd as bq
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, variant)
+    n = ni * nj * nk
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    t0 = F.scalar(ni, nj, nk, 2.9)          # p_temp's boundary layer must survive untouched
+    for sweeps in (1, 2, 5):
+        a, b = p0.copy(), t0.copy()
+        for _ in range(sweeps):
+            oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+            a, b = b, a
+        dp, dd, dt = dev(p0, div, t0)
+        where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, sweeps, ALPHA, BETA)
+        assert where == sweeps % 2
+        newest, older = (dt, dp) if where else (dp, dt)
+        assert F.same(a, newest.numpy()), (ni, nj, nk, sweeps)
+        assert F.same(b, older.numpy())
+    bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk", [(24, 20, 16), (32, 32, 32), (64, 33, 17)])
+def test_divergence_gradient(hip, ni, nj, nk):
+    import gpufluidsimulation_amd as bq
+    h = 1.0 / ni
+    u, v, w = F.velocity(ni, nj, nk, h)
+    n = ni * nj * nk
+    ref = np.zeros(n, np.float32)
+    oracle().orc_divergence(fp(u), fp(v), fp(w), fp(ref), ni, nj, nk, 0.5)
+    du, dv, dw, dd = dev(u, v, w, np.ones(n, np.float32))
+    hip.gpu_divergence(du.ptr, dv.ptr, dw.ptr, dd.ptr, ni, nj, nk, 0.5)
+    assert F.same(ref, dd.numpy())
+    p = F.scalar(ni, nj, nk, 0.8)
+    ru, rv, rw = u.copy(), v.copy(), w.copy()
+    oracle().orc_gradient(fp(ru), fp(p), ni + 1, nj, nk, 1, 0, 0, 0.5)
+    oracle().orc_gradient(fp(rv), fp(p), ni, nj + 1, nk, 0, 1, 0, 0.5)
+    oracle().orc_gradient(fp(rw), fp(p), ni, nj, nk + 1, 0, 0, 1, 0.5)
+    (dp,) = dev(p)
+    hip.gpu_gradient(du.ptr, dv.ptr, dw.ptr, dp.ptr, ni, nj, nk, 0.5)
+    assert F.same(ru, du.numpy()) and F.same(rv, dv.numpy()) and F.same(rw, dw.numpy())
+    # KAT 4: divergence of a discrete curl is zero to rounding
+    bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk", [(24, 20, 16), (32, 32, 32), (128, 24, 16)])
+@pytest.mark.parametrize("iters", [0, 1, 2, 9, 10])
+def test_projection_jacobi(hip, ni, nj, nk, iters):
+    import gpufluidsimulation_amd as bq
+    h = 1.0 / ni
+    u, v, w = F.velocity(ni, nj, nk, h)
+    n = ni * nj * nk
+    ru, rv, rw = u.copy(), v.copy(), w.copy()
+    rd, rp, rt = (np.zeros(n, np.float32) for _ in range(3))
+    rdbg = np.zeros(4096, np.float32)
+    oracle().orc_projection_jacobi(fp(ru), fp(rv), fp(rw), fp(rd), fp(rp), fp(rt), fp(rdbg),
+                                   ni, nj, nk, iters, 0.5, ALPHA, BETA)
+    m = bq.GpuMapper(ni, nj, nk, h)
+    hip.fl_set_option(bq._lib.FL_OPT_RESIDUAL_STRIDE, 1)
+    du, dv, dw = dev(u, v, w)
+    dd, dp, dt = dev(*(np.full(n, 9.0, np.float32) for _ in range(3)))      # projectionJacobi must zero them
+    (ddbg,) = dev(np.zeros(4096, np.float32))
+    m.projectionJacobi(du, dv, dw, dd, dp, dt, ddbg, iters, 0.5, ALPHA, BETA)
+    assert F.same(ru, du.numpy()) and F.same(rv, dv.numpy()) and F.same(rw, dw.numpy())
+    assert F.same(rd, dd.numpy())
+    assert F.same(rp, dp.numpy())                       # p holds iterate iters-1 (Q1)
+    g = ddbg.numpy()
+    np.testing.assert_allclose(g[:max(iters, 0)], rdbg[:max(iters, 0)], rtol=1e-6)
+    assert F.same(rdbg[2000:2000 + max(iters, 0)], g[2000:2000 + max(iters, 0)])     # max|r| is exact
+    hip.fl_set_option(bq._lib.FL_OPT_RESIDUAL_STRIDE, 0)
+    m.check()
+
+
+def test_residual_norms(hip):
+    import gpufluidsimulation_amd as bq
+    ni, nj, nk = 64, 40, 24
+    div, p = F.scalar(ni, nj, nk, 0.2), F.scalar(ni, nj, nk, 1.2)
+    ss, mx = C.c_double(), C.c_float()
+    oracle().orc_residual_norms(fp(div), fp(p), ni, nj, nk, C.byref(ss), C.byref(mx))
+    dd, dp = dev(div, p)
+    gs, gm = C.c_double(), C.c_float()
+    hip.gpu_residual_norms(dd.ptr, dp.ptr, ni, nj, nk, C.byref(gs), C.byref(gm))
+    assert gm.value == mx.value
+    assert abs(gs.value - ss.value) <= 1e-12 * ss.value     # double accumulation, different order
+    bq.check()
+
+
+def test_projection_quarter_strength(hip):
+    """SURVEY Q2 known answer: with halfrdx=0.5 on the staggered grid the converged projection
+    removes only 1/4 of the divergence (ratio 0.75); with halfrdx=1.0 it removes all of it."""
+    import gpufluidsimulation_amd as bq
+    ni = nj = nk = 32
+    h = 1.0 / ni
+    n = ni * nj * nk
+    u, v, w = F.velocity(ni, nj, nk, h)
+    # compactly supported divergence: zero the velocity near the walls so boundary cells stay div-free
+    U, V, W = u.reshape(nk, nj, ni + 1), v.reshape(nk, nj + 1, ni), w.reshape(nk + 1, nj, ni)
+    for a in (U, V, W):
+        a[:4] = 0; a[-4:] = 0; a[:, :4] = 0; a[:, -4:] = 0; a[:, :, :4] = 0; a[:, :, -4:] = 0
+    m = bq.GpuMapper(ni, nj, nk, h)
+
+    def ratio(hr, iters=3000):
+        du, dv, dw = dev(u, v, w)
+        dd, dp, dt = dev(*(np.zeros(n, np.float32) for _ in range(3)))
+        before = np.zeros(n, np.float32)
+        oracle().orc_divergence(fp(u), fp(v), fp(w), fp(before), ni, nj, nk, 1.0)
+        m.projectionJacobi(du, dv, dw, dd, dp, dt, None, iters, hr, ALPHA, BETA)
+        after = np.zeros(n, np.float32)
+        oracle().orc_divergence(fp(du.numpy()), fp(dv.numpy()), fp(dw.numpy()), fp(after), ni, nj, nk, 1.0)
+        inner = (slice(2, ni - 2),) * 3
+        A, B = after.reshape(nk, nj, ni)[inner], before.reshape(nk, nj, ni)[inner]
+        return float(np.linalg.norm(A) / np.linalg.norm(B))
+
+    assert abs(ratio(0.5) - 0.75) < 1e-4
+    assert ratio(1.0) < 1e-5
+    m.check()
