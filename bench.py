@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- bimocq3D per-step throughput on MI355X.
+
+Metric (BASELINE.json): Mvoxels/s per step of the 256^3 rising-smoke scene (L=1, h=1/N,
+dt=2h, nu=0, blend=1, alpha=0, beta=1, one spherical source at step 0, Jacobi 200 iterations,
+halfrdx=0.5 = the reference's value), plus the HBM roofline fraction of the dominant kernel (the
+Jacobi sweep, 12 algorithmic bytes per voxel per sweep) and the CPU oracle timed beside it.
+
+A "step" is one BimocqGPUSolver::advance(): map update, advection with error compensation, forces,
+projection (divergence, Jacobi sweeps, gradient), accumulation, re-initialisation -- all resident in
+HBM; nothing crosses PCIe inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--jacobi-iters 200]
+
+N > 1: launched by torch.distributed.run, one rank per GPU (see DESIGN.md "Multi-GPU").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+JACOBI_BYTES_PER_VOXEL = 12.0   # read p + read div + write p'  
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=256, help="grid is n^3 (per rank when --gpus > 1)")
+    ap.add_argument("--jacobi-iters", type=int, default=200)
+    ap.add_argument("--halfrdx", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port: the reference has no runnable CPU path for bimocq3D) on this box's
+    host cores, on a bounded sample of the same scene: smaller grid, same algorithm and settings."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.lib(march="native", out="_build_native")        # rebuilt for this host's ISA
+    n = args.cpu_n
+    s = oracle_lib.OracleSolver(n, n, n, 1.0, 0.0, 1.0)
+    s.set_smoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
+    s.set_projection(args.jacobi_iters, args.halfrdx)
+    dt = 2.0 / n
+    s.advance(0, dt)                                            # untimed: first-touch + emission
+    t0 = time.perf_counter()
+    for f in range(1, 1 + args.cpu_steps):
+        s.advance(f, dt)
+    el = time.perf_counter() - t0
+    s.close()
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(n ** 3 * args.cpu_steps / el / 1e6, 4), "unit": "Mvoxels/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{args.cpu_steps} steps of {n}^3 rising smoke ({args.jacobi_iters} Jacobi iters), "
+                      f"OpenMP C oracle (-O2 -march=native), {el:.1f} s"}
+
+
+def pmc_traffic(n):
+    """HBM bytes per Jacobi launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "jacobi_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(str(n), {}).get("bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gpufluidsimulation_amd as bq
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    lib = bq.hip_lib()
+    n = args.n
+    s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
+    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
+    s.setProjection(args.jacobi_iters, args.halfrdx)
+    dt = 2.0 / n
+
+    def barrier():
+        lib.fl_sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        lib.fl_sync()
+
+    frame = 0
+    for _ in range(args.warmup):
+        s.advance(frame, dt)
+        frame += 1
+    lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.advance(frame, dt)
+        frame += 1
+    barrier()
+    el = time.perf_counter() - t0
+    lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 0)
+    bq.check()
+    ms, launches = C.c_double(0.0), C.c_longlong(0)
+    lib.fl_jacobi_profile(C.byref(ms), C.byref(launches))
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    voxels = n ** 3 * world                     # weak scaling: every rank advances its own n^3 grid
+    ms_per_step = el / args.steps * 1e3
+    value = voxels * args.steps / el / 1e6
+    line = {
+        "metric": "Mvoxels/s per step (bimocq3D rising smoke)", "value": round(value, 2), "unit": "Mvoxels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"bimocq3D {n}^3 rising smoke, {args.jacobi_iters} Jacobi iters, fp32, "
+                               f"halfrdx {args.halfrdx}, reinit every step",
+                   "grid_per_gpu": [n, n, n], "dt": dt, "parallelism": "1 GPU" if world == 1 else f"{world} replicas"},
+    }
+    if launches.value > 0:
+        us = ms.value * 1e3 / launches.value
+        achieved = JACOBI_BYTES_PER_VOXEL * n ** 3 / (us * 1e-6) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": "jacobi_tile_kernel", "achieved": round(achieved, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "traffic": pmc_traffic(n), "us_per_launch": round(us, 3),
+                            "launches_timed": int(launches.value),
+                            "algorithmic_bytes_per_launch": int(JACOBI_BYTES_PER_VOXEL * n ** 3)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(args)
+        except Exception as e:                  # never lose the GPU numbers to a host-side hiccup
+            line["cpu_baseline"] = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    s.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,8 @@ struct Runtime {
     int         opt_residual_stride = 0;
     int         opt_skip_unit_blend = 1;
     int         opt_jacobi_variant = 0;
+    int         opt_profile_jacobi = 0;
+    int         opt_jacobi_kchunk = 0;      // 0 = auto
     // persistent workspace (replaces the cudaMalloc/cudaFree pair inside the reference's
     // gpu_projection_jacobi, GPU_kernel.cu:1847-1850,1893-1894)
     void  *scratch = nullptr;           // device: reduction partials

@@ -8,10 +8,15 @@ namespace bq {
 static const dim3 kBlock3(64, 4, 1);
 static inline dim3 grid3(int a, int b, int c) { return dim3((a + 63) / 64, (b + 3) / 4, c); }
 
-// norm3df restated as the correctly rounded sqrt of the double sum of squares (oracle: norm3)
+// norm3df / hypotf restated as the correctly rounded sqrt of the double sum of squares
+// (oracle: norm3, hypot2)
 __device__ __forceinline__ float norm3(float x, float y, float z)
 {
     return (float)sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);
+}
+__device__ __forceinline__ float hypot2(float y, float z)
+{
+    return (float)sqrt((double)y * (double)y + (double)z * (double)z);
 }
 
 // emit_smoke_velocity_kernel (GPU_kernel.cu:736-758); the u-face offset is used for all three
@@ -25,7 +30,7 @@ __global__ __launch_bounds__(256) void emit_velocity_kernel(float *field, float 
     float dy = (float)j * h - cy;
     float dz = (float)k * h - cz;
     if (norm3(dx, dy, dz) < radius) {
-        float theta = acosf(dy / hypotf(dy, dz));
+        float theta = acosf(dy / hypot2(dy, dz));
         float c8 = cosf((float)(8.0 * (double)theta));
         field[(size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k)] = (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));
     }

@@ -193,6 +193,8 @@ void fl_set_option(int option, int value)
     case FL_OPT_RESIDUAL_STRIDE: g_rt.opt_residual_stride = value < 0 ? 0 : value; break;
     case FL_OPT_SKIP_UNIT_BLEND: g_rt.opt_skip_unit_blend = value ? 1 : 0; break;
     case FL_OPT_JACOBI_VARIANT:  g_rt.opt_jacobi_variant = value; break;
+    case FL_OPT_PROFILE_JACOBI:  g_rt.opt_profile_jacobi = value ? 1 : 0; break;
+    case FL_OPT_JACOBI_KCHUNK:   g_rt.opt_jacobi_kchunk = value < 0 ? 0 : value; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -203,6 +205,8 @@ int fl_get_option(int option)
     case FL_OPT_RESIDUAL_STRIDE: return g_rt.opt_residual_stride;
     case FL_OPT_SKIP_UNIT_BLEND: return g_rt.opt_skip_unit_blend;
     case FL_OPT_JACOBI_VARIANT:  return g_rt.opt_jacobi_variant;
+    case FL_OPT_PROFILE_JACOBI:  return g_rt.opt_profile_jacobi;
+    case FL_OPT_JACOBI_KCHUNK:   return g_rt.opt_jacobi_kchunk;
     default: return -1;
     }
 }

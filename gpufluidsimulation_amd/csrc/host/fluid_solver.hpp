@@ -1,0 +1,91 @@
+// fluid_solver.hpp -- GPU-resident BiMocq smoke solver: the time-step state machine.
+//
+// Keeps the reference's BimocqGPUSolver surface (src/bimocq3D/BimocqGPUSolver.h:27-56):
+//   BimocqGPUSolver(nx, ny, nz, L, vis_coeff, blend_coeff, scheme, gpuMapper*)
+//   setSmoke(drop, raise, emitters) / advance(framenum, dt) / outputResult(frame, path)
+// so the reference's driver loop (src/bimocq3D/main.cpp:151-159) runs against it unchanged.
+// `FluidSolver` (the name BASELINE.json uses) is an alias with step()/dump() spellings.
+#pragma once
+#include <string>
+#include <vector>
+#include "bimocq_solver.h"
+#include "mapping.hpp"
+
+namespace bqhost {
+
+enum Scheme { BIMOCQ = 0, SEMILAG, MACCORMACK, MAC_REFLECTION };     // BimocqSolver.h:29
+
+// The reference's Emitter carries an OpenVDB SDF that the GPU solver never samples
+// (BimocqGPUSolver.cpp:376-392 uses hard-coded spheres); what it does use is kept.
+struct Emitter {
+    int emitFrame = 0;
+    float emit_density = 0.f, emit_temperature = 0.f;
+    float e_pos[3] = { 0.f, 0.f, 0.f };
+    float radius = 0.f;
+    float emiter = 0.f;                 // sign/scale of the x-velocity the source imposes
+};
+
+class BimocqGPUSolver {
+public:
+    BimocqGPUSolver(unsigned nx, unsigned ny, unsigned nz, float L, float vis_coeff, float blend_coeff,
+                    Scheme inScheme, gpuMapper *mymapper);
+    bool ok() const { return ok_; }
+
+    void advance(int framenum, float dt);
+    void advanceBimocq(int framenum, float dt);
+    float getCFL();
+    void emitSmoke(int framenum, float dt);
+    void addBuoyancy(float dt);
+    void diffuseField(float *field, float *t0, float *t1, int ni, int nj, int nk, int iter, float nu, float dt);
+    void projection();
+    void velocityReinitialize();
+    void scalarReinitialize();
+    void setSmoke(float drop, float raise, const std::vector<Emitter> &emitters);
+    long outputResult(unsigned frame, const std::string &filepath);
+
+    // FluidSolver spellings
+    void step(int framenum, float dt) { advance(framenum, dt); }
+    long dump(unsigned frame, const std::string &filepath) { return outputResult(frame, filepath); }
+
+    // projection variant (compile-time `#if` in the reference, BimocqGPUSolver.cpp:408-466)
+    int   jacobi_iters = 100;           // :409
+    float halfrdx = 0.5f;               // :410 (quarter-strength projection; 1.0 is the physical value)
+    bool  verbose = false;              // print "[Bimocq GPU Time: ...]" like the reference (:126)
+
+    float _alpha = 0.f, _beta = 0.f;    // smoke parameters (:529-534)
+    Scheme myscheme;
+
+    GridDims g;
+    float CellSize, MaxVelocity = 0.f, Viscosity;
+    float last_cfldt = 0.f, last_ms = 0.f;
+
+    DeviceField VelocityU, VelocityV, VelocityW;
+    DeviceField VelocityUInit, VelocityVInit, VelocityWInit;
+    DeviceField VelocityUPrev, VelocityVPrev, VelocityWPrev;
+    DeviceField VelocityUTemp, VelocityVTemp, VelocityWTemp;
+    DeviceField duProj, dvProj, dwProj, duExtern, dvExtern, dwExtern;
+    DeviceField TempSrcU, TempSrcV, TempSrcW;
+    DeviceField Density, DensityInit, DensityPrev;
+    DeviceField Temperature, TemperatureInit, TemperaturePrev;
+    DeviceField div, p, p_temp;         // the reference lends DensityTemp/TemperatureTemp/TempSrcV here (:410)
+    DeviceField debugParam;             // 4096 floats, residual history (:412-417)
+
+    std::vector<float> host_density, host_u, host_v, host_w;    // outputResult staging (:538-541)
+
+    gpuMapper *GpuSolver;
+    MapperBaseGPU VelocityAdvector, ScalarAdvector;
+    int vel_lastReinit = -11, scalar_lastReinit = -31;          // BimocqGPUSolver.h:109-110
+    std::vector<Emitter> sim_emitter;
+
+private:
+    bool ok_ = false;
+};
+
+using FluidSolver = BimocqGPUSolver;
+
+// writeVDB's contract (utils/volumeMeshTools.h:33-60) in a dependency-free container; returns the
+// number of voxels written or -1.  Defined in density_dump.cpp.
+long write_density_dump(unsigned frame, const std::string &filepath, float voxel_size,
+                        const float *density, int nx, int ny, int nz, int k_offset, int nz_global);
+
+} // namespace bqhost

@@ -1,0 +1,124 @@
+// gpu_mapper.hpp -- host-side owner of device buffers and thin operator wrappers.
+//
+// Mirrors the role of the reference's `gpuMapper` (src/bimocq3D/GPU_Advection.h:110-627): same
+// method names, argument order and pre-zeroing rules, so the solver code above it reads like the
+// reference's call sites.  Differences, all deliberate:
+//   * it speaks only the C-ABI of include/bimocq_gpu.h (fl_* instead of cuda*), so the same host
+//     code links against the HIP library in the product and against a CPU stand-in in tests;
+//   * buffers are released in the destructor (the reference never frees anything);
+//   * the DMC sub-step ping-pongs between buffers instead of copying out -> in three times.
+#pragma once
+#include <cstddef>
+#include <vector>
+#include "bimocq_gpu.h"
+
+namespace bqhost {
+
+// allocGPUBuffer (GPU_Advection.h:322-326): zero-filled device allocation, RAII.
+class DeviceField {
+public:
+    DeviceField() = default;
+    explicit DeviceField(size_t count) { alloc(count); }
+    DeviceField(const DeviceField &) = delete;
+    DeviceField &operator=(const DeviceField &) = delete;
+    DeviceField(DeviceField &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceField &operator=(DeviceField &&o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DeviceField() { release(); }
+
+    bool alloc(size_t count)
+    {
+        release();
+        p_ = static_cast<float *>(fl_malloc(count * sizeof(float)));
+        n_ = p_ ? count : 0;
+        return p_ != nullptr;
+    }
+    void release() { if (p_) fl_free(p_); p_ = nullptr; n_ = 0; }
+    void zero() const { fl_memset(p_, 0, bytes()); }
+    void copy_from(const DeviceField &src) const { fl_memcpy_d2d(p_, src.p_, bytes() < src.bytes() ? bytes() : src.bytes()); }
+    void download(float *host) const { fl_memcpy_d2h(host, p_, bytes()); }
+    void upload(const float *host) const { fl_memcpy_h2d(p_, host, bytes()); }
+    float *get() const { return p_; }
+    operator float *() const { return p_; }
+    size_t count() const { return n_; }
+    size_t bytes() const { return n_ * sizeof(float); }
+    void swap(DeviceField &o) { float *p = p_; size_t n = n_; p_ = o.p_; n_ = o.n_; o.p_ = p; o.n_ = n; }
+
+private:
+    float *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+struct GridDims {
+    int ni = 0, nj = 0, nk = 0;
+    float h = 0.f;
+    size_t n() const { return (size_t)ni * nj * nk; }
+    size_t nu() const { return (size_t)(ni + 1) * nj * nk; }
+    size_t nv() const { return (size_t)ni * (nj + 1) * nk; }
+    size_t nw() const { return (size_t)ni * nj * (nk + 1); }
+};
+
+class gpuMapper {
+public:
+    gpuMapper(int device, int nx, int ny, int nz, float h);
+    bool ok() const { return ok_; }
+
+    GridDims g;
+    // scratch owned by the mapper (GPU_Advection.h:122-136)
+    DeviceField u_src, v_src, w_src;
+    DeviceField x_out, y_out, z_out;        // DMC ping buffers (border nodes stay 0, as in the reference)
+    DeviceField x_out2, y_out2, z_out2;     // second ping set so sub-steps never copy
+
+    // event pair of startEventRecord/endEventRecord (GPU_Advection.h:228-247)
+    void startEventRecord();
+    float endEventRecord();
+
+    void solveForward(float *u, float *v, float *w, float *xf, float *yf, float *zf, float cfldt, float dt) const
+    { gpu_solve_forward(u, v, w, xf, yf, zf, g.h, g.ni, g.nj, g.nk, cfldt, dt); }
+
+    // one DMC sub-step in -> out (GPU_Advection.h:460-470 without the copy-back; the caller swaps)
+    void solveBackwardDMC(float *u, float *v, float *w, float *xi, float *yi, float *zi,
+                          float *xo, float *yo, float *zo, float substep) const
+    { gpu_solve_backwardDMC(u, v, w, xi, yi, zi, xo, yo, zo, g.h, g.ni, g.nj, g.nk, substep); }
+
+    void advectVelocity(float *u, float *v, float *w, float *ui, float *vi, float *wi,
+                        float *bx, float *by, float *bz, bool is_point) const;
+    void advectVelocityDouble(float *u, float *v, float *w, float *ut, float *vt, float *wt,
+                              float *bx, float *by, float *bz, float *px, float *py, float *pz,
+                              bool is_point, float blend) const
+    { gpu_advect_vel_double(u, v, w, ut, vt, wt, bx, by, bz, px, py, pz, g.h, g.ni, g.nj, g.nk, is_point, blend); }
+    void compensateVelocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+                            float *fx, float *fy, float *fz, float *bx, float *by, float *bz, bool is_point) const;
+    void advectField(float *f, float *fi, float *bx, float *by, float *bz, bool is_point) const;
+    void advectFieldDouble(float *f, float *fp, float *bx, float *by, float *bz,
+                           float *px, float *py, float *pz, bool is_point, float blend) const
+    { gpu_advect_field_double(f, fp, bx, by, bz, px, py, pz, g.h, g.ni, g.nj, g.nk, is_point, blend); }
+    void compensateField(float *f, float *df, float *fx, float *fy, float *fz,
+                         float *bx, float *by, float *bz, bool is_point) const;
+    void accumulateVelocity(float *uc, float *vc, float *wc, float *dui, float *dvi, float *dwi,
+                            float *fx, float *fy, float *fz, bool is_point, float coeff) const
+    { gpu_accumulate_velocity(uc, vc, wc, dui, dvi, dwi, fx, fy, fz, g.h, g.ni, g.nj, g.nk, is_point, coeff); }
+    void accumulateField(float *fc, float *dfi, float *fx, float *fy, float *fz, bool is_point, float coeff) const
+    { gpu_accumulate_field(fc, dfi, fx, fy, fz, g.h, g.ni, g.nj, g.nk, is_point, coeff); }
+    void emitSmoke(float *u, float *v, float *w, float *rho, float *T, float cx, float cy, float cz,
+                   float radius, float density, float temperature, float emiter) const
+    { gpu_emit_smoke(u, v, w, rho, T, g.h, g.ni, g.nj, g.nk, cx, cy, cz, radius, density, temperature, emiter); }
+    void add_buoyancy(float *v, float *rho, float *T, float alpha, float beta, float dt) const
+    { gpu_add_buoyancy(v, rho, T, g.ni, g.nj, g.nk, alpha, beta, dt); }
+    void diffuseField(float *f, float *t0, float *t1, int ni, int nj, int nk, int iter, float coef) const
+    { gpu_diffuse_field(f, t0, t1, ni, nj, nk, iter, coef); }
+    void addFields(float *out, float *f1, float *f2, float coeff, size_t number) const
+    { gpu_add_field(out, f1, f2, coeff, (int)number); }
+    void add(float *f1, float *f2, float coeff, size_t number) const { gpu_add(f1, f2, coeff, (int)number); }
+    void projectionJacobi(float *u, float *v, float *w, float *div, float *p, float *p_temp, float *debug,
+                          int iter, float halfrdx, float alpha, float beta) const;
+
+private:
+    bool ok_ = false;
+    void *ev_start_ = nullptr, *ev_stop_ = nullptr;
+};
+
+} // namespace bqhost

@@ -1,0 +1,141 @@
+"""Python handle on the C++ host solver (csrc/host/, C view in include/bimocq_solver.h).
+
+Same surface as the reference's BimocqGPUSolver (src/bimocq3D/BimocqGPUSolver.h:27-56):
+construct, setSmoke, advance(framenum, dt), outputResult(frame, path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+FIELD_IDS = {"rho": 0, "T": 1, "u": 2, "v": 3, "w": 4, "uinit": 5, "vinit": 6, "winit": 7,
+             "rhoinit": 8, "Tinit": 9, "fx": 10, "fy": 11, "fz": 12, "bx": 13, "by": 14, "bz": 15, "p": 16}
+
+
+class Emitter(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("cz", C.c_float), ("radius", C.c_float),
+                ("density", C.c_float), ("temperature", C.c_float), ("emiter", C.c_float),
+                ("emit_frames", C.c_int)]
+
+
+HOST_SIGS = {
+    "bq_solver_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "bq_solver_destroy": (None, [C.c_void_p]),
+    "bq_solver_set_smoke": (None, [C.c_void_p, C.c_float, C.c_float, C.POINTER(Emitter), C.c_int]),
+    "bq_solver_set_projection": (None, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "bq_solver_advance": (None, [C.c_void_p, C.c_int, C.c_float]),
+    "bq_solver_output_result": (C.c_long, [C.c_void_p, C.c_uint, C.c_char_p]),
+    "bq_solver_download": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
+    "bq_solver_last_cfldt": (C.c_float, [C.c_void_p]),
+    "bq_solver_last_ms": (C.c_float, [C.c_void_p]),
+    "bq_solver_reinit_count": (C.c_int, [C.c_void_p]),
+}
+
+_host = None
+
+
+def bind_host(lib):
+    for name, (res, args) in HOST_SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def host_lib():
+    """libbimocq_host.so (C++ solver); pulls in libbimocq_hip.so through its rpath."""
+    global _host
+    if _host is None:
+        _lib.hip_lib()
+        if not os.path.exists(_lib.HOST_SO):
+            raise _lib.BimocqLibraryMissing(f"{_lib.HOST_SO} not found: run `make`")
+        _host = bind_host(C.CDLL(_lib.HOST_SO, mode=C.RTLD_GLOBAL))
+    return _host
+
+
+class BimocqGPUSolver:
+    """advance()/outputResult() on the MI355X; `lib`/`errlib` are injectable so the CPU-only tests
+    can drive the very same host code linked against a CPU stand-in of the C-ABI."""
+
+    def __init__(self, nx, ny, nz, L=1.0, viscosity=0.0, blend=1.0, device=0, lib=None, errlib=None):
+        self.lib = lib or host_lib()
+        self.errlib = errlib or (_lib.hip_lib() if lib is None else lib)
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.h = float(np.float32(L) / np.float32(nx))
+        self.s = self.lib.bq_solver_create(device, nx, ny, nz, L, viscosity, blend, 0)
+        if not self.s:
+            self._check()
+            raise _lib.BimocqError("bq_solver_create failed")
+
+    def _check(self):
+        code = self.errlib.fl_last_error()
+        if code != 0:
+            text = self.errlib.fl_last_error_string()
+            text = text.decode(errors="replace") if isinstance(text, bytes) else str(text)
+            self.errlib.fl_clear_error()
+            raise _lib.BimocqError(f"bimocq error {code}: {text}")
+
+    def setSmoke(self, drop, rise, emitters):
+        """emitters: iterable of (cx, cy, cz, radius, density, temperature, emiter, emit_frames)"""
+        emitters = list(emitters)
+        arr = (Emitter * max(1, len(emitters)))()
+        for i, e in enumerate(emitters):
+            arr[i] = Emitter(*e)
+        self.lib.bq_solver_set_smoke(self.s, drop, rise, arr, len(emitters))
+
+    def setProjection(self, iters, halfrdx):
+        self.lib.bq_solver_set_projection(self.s, 0, iters, halfrdx)
+
+    def advance(self, framenum, dt):
+        self.lib.bq_solver_advance(self.s, framenum, dt)
+
+    def outputResult(self, frame, path=None):
+        n = self.lib.bq_solver_output_result(self.s, frame, path.encode() if path else None)
+        self._check()
+        return n
+
+    def field(self, name):
+        which = FIELD_IDS[name]
+        count = self.lib.bq_solver_download(self.s, which, None, 0)
+        out = np.empty(count, dtype=np.float32)
+        self.lib.bq_solver_download(self.s, which, out.ctypes.data, count)
+        self._check()
+        return out
+
+    @property
+    def cfldt(self):
+        return self.lib.bq_solver_last_cfldt(self.s)
+
+    @property
+    def last_ms(self):
+        return self.lib.bq_solver_last_ms(self.s)
+
+    @property
+    def reinit_count(self):
+        return self.lib.bq_solver_reinit_count(self.s)
+
+    def close(self):
+        if getattr(self, "s", None):
+            self.lib.bq_solver_destroy(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_density_dump(path):
+    """Reader of the BQDENS01 container written by outputResult (density_dump.cpp)."""
+    hdr = np.dtype([("magic", "S8"), ("frame", "<u4"), ("nx", "<i4"), ("ny", "<i4"), ("nz", "<i4"),
+                    ("k_offset", "<i4"), ("nz_local", "<i4"), ("voxel_size", "<f4"), ("threshold", "<f4"),
+                    ("grid_name", "S16"), ("grid_class", "<u4"), ("count", "<u8")])
+    rec = np.dtype([("i", "<i4"), ("j", "<i4"), ("k", "<i4"), ("value", "<f4")])
+    with open(path, "rb") as f:
+        h = np.frombuffer(f.read(hdr.itemsize), dtype=hdr)[0]
+        assert h["magic"] == b"BQDENS01", h["magic"]
+        r = np.frombuffer(f.read(), dtype=rec)
+    assert len(r) == h["count"]
+    return h, r

@@ -223,10 +223,15 @@ enum {
     FL_OPT_RESIDUAL_STRIDE = 1, /* evaluate Jacobi residual norms every k-th iterate (default 0)  */
     FL_OPT_SKIP_UNIT_BLEND = 2, /* gpu_advect_*_double with blend==1: write field+0 instead of
                                    evaluating prev (exact for finite prev; default 1)              */
-    FL_OPT_JACOBI_VARIANT  = 3  /* 0 = auto, 1 = generic scalar kernel, 2 = LDS-tiled kernel      */
+    FL_OPT_JACOBI_VARIANT  = 3, /* 0 = auto, 1 = generic scalar kernel, 2 = LDS-tiled kernel      */
+    FL_OPT_PROFILE_JACOBI  = 4, /* record a hipEvent pair around each projection's sweep loop      */
+    FL_OPT_JACOBI_KCHUNK   = 5  /* planes marched per block in the tiled kernel (0 = auto)         */
 };
 void fl_set_option(int option, int value);
 int  fl_get_option(int option);
+/* FL_OPT_PROFILE_JACOBI: total milliseconds and sweep-kernel launches of the sweep loops recorded
+ * since the previous call (blocking; resets the record) */
+void fl_jacobi_profile(double *total_ms, long long *launches);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Additive entry points (no reference counterpart)

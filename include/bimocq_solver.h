@@ -1,0 +1,64 @@
+/*
+ * bimocq_solver.h -- C view of the C++ host solver (gpufluidsimulation_amd/csrc/host/).
+ *
+ * The host solver keeps the reference's BimocqGPUSolver surface
+ * (reference: src/bimocq3D/BimocqGPUSolver.h:27-56): construct with (nx, ny, nz, L, viscosity,
+ * blend, scheme), setSmoke, advance(framenum, dt), outputResult(frame, path).  It is plain C++
+ * that calls nothing but the C-ABI of include/bimocq_gpu.h; this header lets non-C++ hosts
+ * (the Python tests and bench.py via ctypes) drive the same object.
+ */
+#ifndef BIMOCQ_SOLVER_H
+#define BIMOCQ_SOLVER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bq_solver bq_solver;
+
+/* one spherical smoke source; the reference hard-codes two of these in
+ * BimocqGPUSolver::emitSmoke (BimocqGPUSolver.cpp:387-390) */
+typedef struct bq_emitter {
+    float cx, cy, cz, radius, density, temperature, emiter;
+    int   emit_frames;                  /* active while framenum < emit_frames */
+} bq_emitter;
+
+enum { BQ_SCHEME_BIMOCQ = 0 };          /* enum Scheme, BimocqSolver.h:29 (others: out of scope) */
+enum { BQ_PROJECTION_JACOBI = 0 };      /* the `#if 0` branch of BimocqGPUSolver::projection     */
+
+/* which-ids for bq_solver_download */
+enum {
+    BQ_F_RHO = 0, BQ_F_T, BQ_F_U, BQ_F_V, BQ_F_W, BQ_F_UINIT, BQ_F_VINIT, BQ_F_WINIT,
+    BQ_F_RHOINIT, BQ_F_TINIT, BQ_F_FWDX, BQ_F_FWDY, BQ_F_FWDZ, BQ_F_BACKX, BQ_F_BACKY, BQ_F_BACKZ,
+    BQ_F_P, BQ_F_COUNT
+};
+
+/* BimocqGPUSolver::BimocqGPUSolver (BimocqGPUSolver.cpp:3-106).  device: HIP device index.
+ * Returns NULL on failure (see fl_last_error_string()). */
+bq_solver *bq_solver_create(int device, int nx, int ny, int nz, float L,
+                            float viscosity, float blend, int scheme);
+void  bq_solver_destroy(bq_solver *s);
+/* setSmoke (BimocqGPUSolver.cpp:529-534): alpha = drop (rho coefficient), beta = rise (T) */
+void  bq_solver_set_smoke(bq_solver *s, float drop, float rise, const bq_emitter *emitters, int n);
+/* projection variant + parameters (compile-time `#if` in the reference, :408-466) */
+void  bq_solver_set_projection(bq_solver *s, int kind, int iters, float halfrdx);
+/* z-slab decomposition: this rank owns cell planes [k0, k1) of a global nz (multi-GPU);
+ * must be called before the first advance.  Single-GPU default: the whole grid. */
+/* advance (BimocqGPUSolver.cpp:108-127) */
+void  bq_solver_advance(bq_solver *s, int framenum, float dt);
+/* outputResult (BimocqGPUSolver.cpp:536-543): D2H of rho,u,v,w and a sparse density dump
+ * <path>/density_render_%04d.bqd for frame+1 (writeVDB's contract, utils/volumeMeshTools.h:33-60,
+ * in a dependency-free container).  path == NULL: only refresh the host copies.  Returns the
+ * number of voxels written (|rho| > 1e-4) or -1 on error. */
+long  bq_solver_output_result(bq_solver *s, unsigned frame, const char *path);
+/* copy one device field to host (blocking).  Returns its element count (0 on bad id); copies
+ * min(count, capacity) elements when host != NULL. */
+long  bq_solver_download(bq_solver *s, int which, float *host, long capacity);
+float bq_solver_last_cfldt(const bq_solver *s);
+float bq_solver_last_ms(const bq_solver *s);          /* event time of the last advance()        */
+int   bq_solver_reinit_count(const bq_solver *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

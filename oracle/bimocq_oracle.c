@@ -544,12 +544,17 @@ void orc_mad(float *out, const float *f1, const float *f2, float c1, float c2, i
     for (int i = 0; i < number; i++) out[i] = c1 * f1[i] + c2 * f2[i];
 }
 
-/* GPU_kernel.cu:736-758 emit_smoke_velocity_kernel.  norm3df is taken as the
- * correctly-rounded sqrt of the double sum of squares (identical in the HIP path);
+/* GPU_kernel.cu:736-758 emit_smoke_velocity_kernel.  norm3df and hypotf are taken as the
+ * correctly-rounded sqrt of the double sum of squares (identical in the HIP path; within 1 ulp
+ * of any libm, and |y| <= hypot2(y,z) always holds so acosf never sees |ratio| > 1);
  * note the u-face offset (i-1/2)h is used for every component. */
 static inline float norm3(float x, float y, float z)
 {
     return (float)sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);
+}
+static inline float hypot2(float y, float z)
+{
+    return (float)sqrt((double)y * (double)y + (double)z * (double)z);
 }
 
 static void emit_velocity(float *field, float h, int ni, int nj, int nk,
@@ -563,7 +568,7 @@ static void emit_velocity(float *field, float h, int ni, int nj, int nk,
                 float dyp = (float)j * h - cy;
                 float dzp = (float)k * h - cz;
                 if (norm3(dxp, dyp, dzp) < radius) {
-                    float theta = acosf(dyp / hypotf(dyp, dzp));
+                    float theta = acosf(dyp / hypot2(dyp, dzp));
                     float c8 = cosf((float)(8.0 * (double)theta));
                     field[IDX3(i, j, k, ni, nj)] =
                         (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));

@@ -1,0 +1,145 @@
+/*
+ * oracle_abi.c -- TEST-ONLY stand-in of the C-ABI (include/bimocq_gpu.h) on top of the CPU oracle.
+ *
+ * Lives under tests/ and is linked only into tests/_build/libbimocq_host_cpu.so, which the
+ * `-m "not gpu"` tests use to exercise the C++ HOST code (csrc/host/: step state machine, buffer
+ * swaps, shared map sets, dump writer) without a GPU.  "Device" memory is host memory here.
+ * The product never links this file: libbimocq_host.so binds to libbimocq_hip.so only.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/bimocq_gpu.h"
+#include "../../oracle/bimocq_oracle.h"
+
+static int g_err = FL_OK;
+static char g_text[256];
+static int g_opt[8];
+
+static void latch(int code, const char *what)
+{
+    if (g_err != FL_OK) return;
+    g_err = code;
+    snprintf(g_text, sizeof g_text, "%s", what);
+}
+
+int fl_init(int device) { (void)device; return FL_OK; }
+void fl_shutdown(void) {}
+void *fl_malloc(size_t bytes) { return calloc(bytes ? bytes : 4, 1); }
+void fl_free(void *p) { free(p); }
+void fl_memset(void *dst, int value, size_t bytes) { memset(dst, value, bytes); }
+void fl_memcpy_h2d(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+void fl_memcpy_d2h(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+void fl_memcpy_d2d(void *dst, const void *src, size_t bytes) { if (dst != src) memmove(dst, src, bytes); }
+void fl_sync(void) {}
+void *fl_event_create(void) { return calloc(1, sizeof(struct timespec)); }
+void fl_event_record(void *ev) { if (ev) clock_gettime(CLOCK_MONOTONIC, (struct timespec *)ev); }
+float fl_event_elapsed_ms(void *a, void *b)
+{
+    struct timespec *s = (struct timespec *)a, *e = (struct timespec *)b;
+    if (!s || !e) return -1.f;
+    return (float)((e->tv_sec - s->tv_sec) * 1e3 + (e->tv_nsec - s->tv_nsec) * 1e-6);
+}
+void fl_event_destroy(void *ev) { free(ev); }
+int fl_last_error(void) { return g_err; }
+const char *fl_last_error_string(void) { return g_err == FL_OK ? "" : g_text; }
+void fl_clear_error(void) { g_err = FL_OK; g_text[0] = 0; }
+void *fl_compute_stream(void) { return NULL; }
+void fl_set_option(int option, int value) { if (option >= 0 && option < 8) g_opt[option] = value; }
+int fl_get_option(int option) { return (option >= 0 && option < 8) ? g_opt[option] : -1; }
+void fl_jacobi_profile(double *total_ms, long long *launches) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; }
+
+void gpu_solve_forward(float *u, float *v, float *w, float *x, float *y, float *z,
+                       float h, int ni, int nj, int nk, float cfldt, float dt)
+{ orc_solve_forward(u, v, w, x, y, z, h, ni, nj, nk, cfldt, dt); }
+void gpu_solve_backwardDMC(float *u, float *v, float *w, float *xi, float *yi, float *zi,
+                           float *xo, float *yo, float *zo, float h, int ni, int nj, int nk, float substep)
+{ orc_solve_backwardDMC(u, v, w, xi, yi, zi, xo, yo, zo, h, ni, nj, nk, substep); }
+void gpu_advect_velocity(float *u, float *v, float *w, float *ui, float *vi, float *wi,
+                         float *bx, float *by, float *bz, float h, int ni, int nj, int nk, bool pt)
+{ orc_advect_velocity(u, v, w, ui, vi, wi, bx, by, bz, h, ni, nj, nk, pt); }
+void gpu_advect_vel_double(float *u, float *v, float *w, float *ut, float *vt, float *wt,
+                           float *bx, float *by, float *bz, float *px, float *py, float *pz,
+                           float h, int ni, int nj, int nk, bool pt, float blend)
+{ orc_advect_vel_double(u, v, w, ut, vt, wt, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
+void gpu_advect_field(float *f, float *fi, float *bx, float *by, float *bz, float h, int ni, int nj, int nk, bool pt)
+{ orc_advect_field(f, fi, bx, by, bz, h, ni, nj, nk, pt); }
+void gpu_advect_field_double(float *f, float *fp, float *bx, float *by, float *bz, float *px, float *py, float *pz,
+                             float h, int ni, int nj, int nk, bool pt, float blend)
+{ orc_advect_field_double(f, fp, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
+void gpu_accumulate_velocity(float *uc, float *vc, float *wc, float *du, float *dv, float *dw,
+                             float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt, float coeff)
+{ orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
+void gpu_accumulate_field(float *fc, float *df, float *fx, float *fy, float *fz,
+                          float h, int ni, int nj, int nk, bool pt, float coeff)
+{ orc_accumulate_field(fc, df, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
+void gpu_estimate_distortion(float *du, float *xb, float *yb, float *zb, float *xf, float *yf, float *zf,
+                             float h, int ni, int nj, int nk)
+{ orc_estimate_distortion(du, xb, yb, zb, xf, yf, zf, h, ni, nj, nk); }
+void gpu_add(float *f1, float *f2, float coeff, int number) { orc_add(f1, f2, coeff, number); }
+void gpu_compensate_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+                             float *us, float *vs, float *ws, float *fx, float *fy, float *fz,
+                             float *bx, float *by, float *bz, float h, int ni, int nj, int nk, bool pt)
+{ orc_compensate_velocity(u, v, w, du, dv, dw, us, vs, ws, fx, fy, fz, bx, by, bz, h, ni, nj, nk, pt); }
+void gpu_compensate_field(float *u, float *du, float *us, float *fx, float *fy, float *fz,
+                          float *bx, float *by, float *bz, float h, int ni, int nj, int nk, bool pt)
+{ orc_compensate_field(u, du, us, fx, fy, fz, bx, by, bz, h, ni, nj, nk, pt); }
+void gpu_semilag(float *f, float *fs, float *u, float *v, float *w, int dx, int dy, int dz,
+                 float h, int ni, int nj, int nk, float cfldt, float dt)
+{ orc_semilag(f, fs, u, v, w, dx, dy, dz, h, ni, nj, nk, cfldt, dt); }
+void gpu_emit_smoke(float *u, float *v, float *w, float *rho, float *T, float h, int ni, int nj, int nk,
+                    float cx, float cy, float cz, float radius, float density, float temperature, float emiter)
+{ orc_emit_smoke(u, v, w, rho, T, h, ni, nj, nk, cx, cy, cz, radius, density, temperature, emiter); }
+void gpu_add_buoyancy(float *f, float *rho, float *T, int ni, int nj, int nk, float alpha, float beta, float dt)
+{ orc_add_buoyancy(f, rho, T, ni, nj, nk, alpha, beta, dt); }
+void gpu_diffuse_field(float *f, float *t0, float *t1, int ni, int nj, int nk, int iter, float coef)
+{ orc_diffuse_field(f, t0, t1, ni, nj, nk, iter, coef); }
+void gpu_add_field(float *out, float *f1, float *f2, float coeff, int number) { orc_add_field(out, f1, f2, coeff, number); }
+void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *pt, float *dbg,
+                           int ni, int nj, int nk, int iter, float halfrdx, float alpha, float beta)
+{ orc_projection_jacobi(u, v, w, div, p, pt, g_opt[FL_OPT_RESIDUAL_STRIDE] > 0 ? dbg : NULL, ni, nj, nk, iter, halfrdx, alpha, beta); }
+void gpu_clamp_extrema(float *a, float *b, float *c, float *d, float *e, int f, int g, int h, int i, int j, int k,
+                       float l, float m, float n, float o, float p)
+{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m; (void)n; (void)o; (void)p;
+  latch(FL_ERR_UNSUPPORTED, "gpu_clamp_extrema"); }
+void gpu_mad(float *out, float *f1, float *f2, float c1, float c2, int number) { orc_mad(out, f1, f2, c1, c2, number); }
+void gpu_conjugate_gradient(float *a, float *b, float *c, float *d, float *e, float *f, float *g, float *h,
+                            int i, int j, int k, int l, float m)
+{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m;
+  latch(FL_ERR_UNSUPPORTED, "gpu_conjugate_gradient"); }
+void gpu_multi_grid_conjugate_gradient(float *a, float *b, float *c, double *d, double *e, double *f, double *g,
+                                       double *h, double *i, double *j, struct SCoarseLevelInfo *k, int l, int m, double n)
+{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m; (void)n;
+  latch(FL_ERR_UNSUPPORTED, "gpu_multi_grid_conjugate_gradient"); }
+
+void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk)
+{
+    for (int k = 0; k < nk; k++)
+        for (int j = 0; j < nj; j++)
+            for (int i = 0; i < ni; i++) {
+                size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+                x[id] = (float)i * h; y[id] = (float)j * h; z[id] = (float)k * h;
+            }
+}
+float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int nj, int nk)
+{ return orc_max_abs3(u, v, w, ni, nj, nk); }
+void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float hr)
+{ orc_divergence(u, v, w, div, ni, nj, nk, hr); }
+int gpu_jacobi_sweeps(float *p, const float *div, float *pt, int ni, int nj, int nk, int sweeps, float alpha, float beta)
+{
+    float *in = p, *out = pt;
+    for (int s = 0; s < sweeps; s++) { orc_jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta); float *t = in; in = out; out = t; }
+    return in == p ? 0 : 1;
+}
+void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float hr)
+{
+    orc_gradient(u, p, ni + 1, nj, nk, 1, 0, 0, hr);
+    orc_gradient(v, p, ni, nj + 1, nk, 0, 1, 0, hr);
+    orc_gradient(w, p, ni, nj, nk + 1, 0, 0, 1, hr);
+}
+void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk, double *ss, float *mx)
+{ double s; float m; orc_residual_norms(div, p, ni, nj, nk, &s, &m); if (ss) *ss = s; if (mx) *mx = m; }
+void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
+{ orc_clamp_extrema_box(before, after, ni, nj, nk); }

@@ -1,0 +1,123 @@
+"""GPU parity of the whole step: the C++ host solver on the HIP kernels (through the C-ABI) vs the
+CPU oracle's state machine on identical initial conditions.  Bar: every field bit-identical after
+every step (value equality) -- tighter than the 1e-5 RMS the north star asks for -- at sizes the
+oracle finishes in seconds; at BASELINE's full size (256^3) size-independent properties instead:
+kernel-variant independence, finite fields, dump/field consistency, density bounds."""
+import os
+
+import numpy as np
+import pytest
+
+import fields as F
+from oracle_lib import OracleSolver
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["rho", "T", "u", "v", "w", "uinit", "vinit", "winit", "rhoinit", "Tinit",
+          "fx", "fy", "fz", "bx", "by", "bz", "p"]
+
+
+def run_pair(dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps):
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    ni, nj, nk = dims
+    o = OracleSolver(ni, nj, nk, L, visc, blend)
+    o.set_smoke(drop, rise, emitters)
+    o.set_projection(iters, hr)
+    s = BimocqGPUSolver(ni, nj, nk, L, visc, blend)
+    s.setSmoke(drop, rise, emitters)
+    s.setProjection(iters, hr)
+    dt = dt_cells * float(np.float32(L) / np.float32(ni))
+    rms = {}
+    for f in range(steps):
+        o.advance(f, dt)
+        s.advance(f, dt)
+        assert s.cfldt == o.cfldt, f
+        for name in FIELDS:
+            a, b = o.field(name), s.field(name)
+            assert F.same(a, b), (f, name, F.maxdiff(a, b))
+    for name in ("rho", "u", "v", "w"):
+        a, b = o.field(name).astype(np.float64), s.field(name).astype(np.float64)
+        rms[name] = float(np.sqrt(np.mean((a - b) ** 2)))
+    assert max(rms.values()) <= 1e-5            # the north star's stated tolerance (here: exactly 0)
+    o.close(); s.close()
+    return rms
+
+
+def test_rising_smoke_32_pow2_spacing():
+    """SURVEY 8(d) synthetic scene at 32^3 (h = 2^-5: power-of-two fast path), 12 steps."""
+    run_pair((32, 32, 32), 1.0, 0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)], 0.0, 1.0, 50, 0.5, 2.0, 12)
+
+
+def test_rising_smoke_64_200_jacobi_tiled_kernel():
+    """64^3 with the BASELINE projection settings (200 Jacobi iterations, LDS-tiled kernel)."""
+    run_pair((64, 64, 64), 1.0, 0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)], 0.0, 1.0, 200, 0.5, 2.0, 5)
+
+
+def test_noncubic_two_emitters_blend_substeps():
+    """24x20x16, h not a power of two (IEEE-division path), two sources with x-velocity, blend < 1,
+    alpha != 0, halfrdx = 1 (physically correct projection), 2 DMC sub-steps in the last frames."""
+    run_pair((24, 20, 16), 0.6, 0.0, 0.7,
+             [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 0.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, 0.0, 3)],
+             0.1, 1.0, 20, 1.0, 3.0, 6)
+
+
+def test_viscous_step():
+    run_pair((20, 24, 16), 1.0, 2e-3, 1.0, [(0.5, 0.3, 0.4, 0.15, 1.0, 2.0, 0.0, 2)], 0.0, 1.0, 12, 0.5, 2.0, 4)
+
+
+def test_emitter_with_velocity_within_libm_tolerance():
+    """A source that imposes x-velocity goes through acosf/cosf of two different libms: the fields may
+    differ in the last bits there, so this case is held to the north star's 1e-5 RMS instead."""
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    dims, L = (24, 20, 16), 0.6
+    em = [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 1.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, -1.0, 3)]
+    o = OracleSolver(*dims, L, 0.0, 0.7); o.set_smoke(0.1, 1.0, em); o.set_projection(20, 1.0)
+    s = BimocqGPUSolver(*dims, L, 0.0, 0.7); s.setSmoke(0.1, 1.0, em); s.setProjection(20, 1.0)
+    dt = 3.0 * L / dims[0]
+    for f in range(6):
+        o.advance(f, dt); s.advance(f, dt)
+    for name in ("rho", "u", "v", "w"):
+        a, b = o.field(name).astype(np.float64), s.field(name).astype(np.float64)
+        assert np.isfinite(b).all()
+        assert np.sqrt(np.mean((a - b) ** 2)) <= 1e-5, name
+
+
+def test_full_size_properties_256(tmp_path):
+    """BASELINE config 3 (256^3, 200 Jacobi iterations): the oracle would need minutes per step, so
+    check properties that do not depend on size."""
+    import gpufluidsimulation_amd as bq
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver, read_density_dump
+    N = 256
+    lib = bq.hip_lib()
+
+    def run(variant, skip_blend, steps=3):
+        lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, variant)
+        lib.fl_set_option(bq._lib.FL_OPT_SKIP_UNIT_BLEND, skip_blend)
+        s = BimocqGPUSolver(N, N, N, 1.0, 0.0, 1.0)
+        s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
+        s.setProjection(200, 0.5)
+        for f in range(steps):
+            s.advance(f, 2.0 / N)
+        return s
+
+    a = run(2, 1)                       # LDS-tiled Jacobi, unit-blend fast path
+    out = {k: a.field(k) for k in ("rho", "T", "u", "v", "w", "p")}
+    n = a.outputResult(2, str(tmp_path))
+    a.close()
+    b = run(1, 0)                       # generic Jacobi kernel, full double-advect kernel
+    for k, v in out.items():
+        assert F.same(v, b.field(k)), k                 # kernel variants are interchangeable bit for bit
+    b.close()
+    lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    lib.fl_set_option(bq._lib.FL_OPT_SKIP_UNIT_BLEND, 1)
+    for k, v in out.items():
+        assert np.isfinite(v).all(), k
+    rho = out["rho"]
+    assert rho.min() >= -1e-3 and rho.max() <= 1.0 + 1e-3       # clampExtrema keeps the advected field bounded
+    assert 0.5 < rho.sum() / (4.0 / 3.0 * np.pi * 0.1 ** 3 * N ** 3) < 1.5   # the emitted sphere is still there
+    R = rho.reshape(N, N, N).astype(np.float64)
+    cy = (R.sum(axis=(0, 2)) * np.arange(N)).sum() / R.sum() / N
+    assert 0.195 < cy < 0.25 and out["v"].max() > 0.05          # it rises (+y) under buoyancy
+    hdr, rec = read_density_dump(os.path.join(str(tmp_path), "density_render_0003.bqd"))
+    assert n == hdr["count"] == int((np.abs(rho) > 1e-4).sum())
+    bq.check()

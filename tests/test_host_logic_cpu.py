@@ -1,0 +1,98 @@
+"""CPU tests of the C++ HOST code (csrc/host/): the step state machine, its buffer swaps, the
+shared map set, the dropped no-op work and the dump writer -- linked against the test-only CPU
+stand-in of the C-ABI (tests/cpu_abi/oracle_abi.c), compared with the oracle's own, independently
+written state machine (orc_solver_advance).  Bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import fields as F
+from build_cpu_host import build as build_cpu_host
+from oracle_lib import OracleSolver
+
+FIELDS = ["rho", "T", "u", "v", "w", "uinit", "vinit", "winit", "rhoinit", "Tinit",
+          "fx", "fy", "fz", "bx", "by", "bz", "p"]
+
+
+@pytest.fixture(scope="module")
+def cpu_host():
+    from gpufluidsimulation_amd import solver
+    lib = solver.bind_host(C.CDLL(build_cpu_host(), mode=C.RTLD_LOCAL))
+    for name, res, args in (("fl_last_error", C.c_int, []), ("fl_last_error_string", C.c_char_p, []),
+                            ("fl_clear_error", None, [])):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps):
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    ni, nj, nk = dims
+    o = OracleSolver(ni, nj, nk, L, visc, blend)
+    o.set_smoke(drop, rise, emitters)
+    o.set_projection(iters, hr)
+    s = BimocqGPUSolver(ni, nj, nk, L, visc, blend, lib=cpu_host, errlib=cpu_host)
+    s.setSmoke(drop, rise, emitters)
+    s.setProjection(iters, hr)
+    dt = dt_cells * float(np.float32(L) / np.float32(ni))
+    for f in range(steps):
+        o.advance(f, dt)
+        s.advance(f, dt)
+        assert s.cfldt == o.cfldt
+        for name in FIELDS:
+            a, b = o.field(name), s.field(name)
+            assert F.same(a, b), (f, name, F.maxdiff(a, b))
+    assert s.reinit_count == steps
+    return o, s
+
+
+def test_rising_smoke_matches_oracle(cpu_host):
+    run_pair(cpu_host, (32, 32, 32), 1.0, 0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)],
+             0.0, 1.0, 50, 0.5, 2.0, 6)
+
+
+def test_noncubic_two_emitters_blend_substeps(cpu_host):
+    # non-cubic, non-power-of-two h, two sources with opposite x-velocities active for 3 frames,
+    # blend < 1 (the double-advect path really runs from frame 1), alpha != 0, dt big enough for
+    # several DMC sub-steps per frame once the flow has spun up
+    o, s = run_pair(cpu_host, (24, 20, 16), 0.6, 0.0, 0.7,
+                    [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 1.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, -1.0, 3)],
+                    0.1, 1.0, 20, 1.0, 3.0, 6)
+    assert np.isfinite(o.field("u")).all() and np.abs(o.field("u")).max() > 0.01
+    assert o.cfldt < 3.0 * 0.6 / 24                    # cfldt < dt: the last frame took 2 DMC sub-steps
+
+
+def test_viscous_step_keeps_reference_aliasing(cpu_host):
+    # nu != 0 exercises the diffusion sweeps and the reference's buffer aliasing
+    run_pair(cpu_host, (20, 24, 16), 1.0, 2e-3, 1.0, [(0.5, 0.3, 0.4, 0.15, 1.0, 2.0, 0.0, 2)],
+             0.0, 1.0, 12, 0.5, 2.0, 4)
+
+
+def test_output_result_dump(cpu_host, tmp_path):
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver, read_density_dump
+    N = 16
+    s = BimocqGPUSolver(N, N, N, 1.0, 0.0, 1.0, lib=cpu_host, errlib=cpu_host)
+    s.setSmoke(0.0, 1.0, [(0.5, 0.4, 0.5, 0.2, 1.0, 1.0, 0.0, 1)])
+    s.setProjection(10, 0.5)
+    s.advance(0, 2.0 / N)
+    out = tmp_path / "a" / "b"
+    n = s.outputResult(0, str(out))
+    rho = s.field("rho")
+    assert n == int((np.abs(rho) > 1e-4).sum()) and n > 0
+    hdr, rec = read_density_dump(os.path.join(str(out), "density_render_0001.bqd"))    # frame + 1
+    assert (hdr["nx"], hdr["ny"], hdr["nz"]) == (N, N, N) and hdr["grid_name"] == b"density"
+    assert hdr["grid_class"] == 1 and abs(hdr["voxel_size"] - 1.0 / N) < 1e-9 and hdr["count"] == n
+    dense = np.zeros(N ** 3, np.float32)
+    dense[rec["i"] + N * (rec["j"] + N * rec["k"])] = rec["value"]
+    want = np.where(np.abs(rho) > 1e-4, np.abs(rho), 0).astype(np.float32)
+    assert np.array_equal(dense, want)
+    flat = rec["i"].astype(np.int64) + N * (rec["j"] + N * rec["k"].astype(np.int64))
+    assert np.all(np.diff(flat) > 0)                  # k, j, i visiting order of writeVDB
+    assert s.outputResult(1, None) == 0               # path-less call only refreshes host copies
+
+
+def test_create_rejects_bad_arguments(cpu_host):
+    assert not cpu_host.bq_solver_create(0, 4, 16, 16, 1.0, 0.0, 1.0, 0)       # too small
+    assert not cpu_host.bq_solver_create(0, 16, 16, 16, 1.0, 0.0, 1.0, 3)      # MAC_REFLECTION: out of scope
