@@ -19,6 +19,7 @@ struct Runtime {
     int         opt_jacobi_variant = 0;
     int         opt_profile_jacobi = 0;
     int         opt_jacobi_kchunk = 0;      // 0 = auto
+    int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // persistent workspace (replaces the cudaMalloc/cudaFree pair inside the reference's
     // gpu_projection_jacobi, GPU_kernel.cu:1847-1850,1893-1894)
     void  *scratch = nullptr;           // device: reduction partials

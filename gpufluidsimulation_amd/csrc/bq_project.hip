@@ -189,6 +189,84 @@ __global__ __launch_bounds__(256) void jacobi_tile_kernel(const float *__restric
     }
 }
 
+// ---- register-marching Jacobi sweep (no LDS, no barrier) -----------------------------------------
+// At 256^3 the three arrays (201 MB) live in the 256 MiB Infinity Cache, where a plain triad streams
+// the same 12 B/voxel in ~25 us (tools/membw.hip): the sweep is then bound by how many independent
+// 16-byte loads a CU keeps in flight, and a barrier per plane (the LDS kernel above) throttles that.
+// Here a thread owns one float4 column of one row and marches along k with the k-1/k/k+1 centre
+// values in registers; the j-1/j+1 rows are re-read as float4 (L1/L2 hits: the neighbouring waves of
+// the block load them as their own centres), x-1/x+4 come from the neighbouring lanes by shuffle.
+// The loads of plane k+1 are issued before plane k is computed, so each wave always has 4 vector
+// loads in flight and never waits on another wave.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                                  float *__restrict__ out, int nx, int ny, int nz,
+                                                                  int cw, int nbx, int nby, int kchunk, float alpha, float beta)
+{
+    // XCD-aware block order: blocks b and b+8 share an XCD (its L2); give each XCD a contiguous run
+    // of (k-chunk, row-block) pairs so halo rows/planes are re-read from the same L2.
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+    const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
+
+    const int rows = (WAVES * 64) / cw;             // rows of the tile (cw float4 columns each)
+    const int c = threadIdx.x % cw, r = threadIdx.x / cw;
+    const int x = (bx * cw + c) * 4, j = by * rows + r;
+    const int kbeg = max(1, bz * kchunk), kend = min(nz - 1, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;
+    const bool active = x < nx && j >= 1 && j <= ny - 2;
+    const size_t sj = nx, sk = (size_t)nx * ny;
+    const size_t g = (size_t)x + sj * (active ? j : 1);         // inactive lanes read a valid row, never store
+    const bool xok = x < nx;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int lane = threadIdx.x & 63;
+    // a lane at a wave edge whose x-neighbour lives in another wave (rows longer than one wave)
+    const bool fix_l = lane == 0 && c > 0, fix_r = lane == 63 && c < cw - 1;
+    const bool tile_l = c == 0 && x > 0, tile_r = c == cw - 1 && x + 4 < nx;   // neighbour in another block
+
+#define BQ_LD4(ptr, off) (xok ? *reinterpret_cast<const float4 *>((ptr) + (off)) : zero4)
+    float4 pm = BQ_LD4(p, g + sk * (kbeg - 1));
+    float4 pc = BQ_LD4(p, g + sk * kbeg);
+    float4 pn = BQ_LD4(p, g + sk * (kbeg + 1));
+    float4 fr = BQ_LD4(p, g - sj + sk * kbeg);
+    float4 bk = BQ_LD4(p, g + sj + sk * kbeg);
+    float4 dv = BQ_LD4(div, g + sk * kbeg);
+
+    for (int k = kbeg; k < kend; k++) {
+        // prefetch everything plane k+1 needs (its k+2 centre, its j+-1 rows, its div)
+        float4 pn2 = zero4, fr2 = zero4, bk2 = zero4, dv2 = zero4;
+        if (k + 1 < kend) {
+            pn2 = BQ_LD4(p, g + sk * (k + 2));
+            fr2 = BQ_LD4(p, g - sj + sk * (k + 1));
+            bk2 = BQ_LD4(p, g + sj + sk * (k + 1));
+            dv2 = BQ_LD4(div, g + sk * (k + 1));
+        }
+        float left = __shfl_up(pc.w, 1, 64), right = __shfl_down(pc.x, 1, 64);
+        if (fix_l || tile_l) left = p[g - 1 + sk * k];
+        if (fix_r || tile_r) right = p[g + 4 + sk * k];
+        float4 o;
+        // ((((((l + r) + f) + b) + d) + u) + alpha*div) * beta   -- GPU_kernel.cu:1834
+        o.x = (left + pc.y + fr.x + bk.x + pm.x + pn.x + alpha * dv.x) * beta;
+        o.y = (pc.x + pc.z + fr.y + bk.y + pm.y + pn.y + alpha * dv.y) * beta;
+        o.z = (pc.y + pc.w + fr.z + bk.z + pm.z + pn.z + alpha * dv.z) * beta;
+        o.w = (pc.z + right + fr.w + bk.w + pm.w + pn.w + alpha * dv.w) * beta;
+        if (active) {
+            float *dst = out + g + sk * k;
+            if (x >= 4 && x + 4 < nx) {
+                *reinterpret_cast<float4 *>(dst) = o;
+            } else {                            // the float4 touches the x boundary: interior cells only
+                if (x >= 1) dst[0] = o.x;
+                dst[1] = o.y;
+                dst[2] = o.z;
+                if (x + 3 < nx - 1) dst[3] = o.w;
+            }
+        }
+        pm = pc; pc = pn; pn = pn2; fr = fr2; bk = bk2; dv = dv2;
+    }
+#undef BQ_LD4
+}
+
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
 // update_residual_kernel / calc_poisson_value arithmetic (GPU_kernel.cu:1048-1060,1239-1249);
 // the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
@@ -278,17 +356,41 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
     if (ni < 3 || nj < 3 || nk < 3) return;         // no interior
     int variant = rt().opt_jacobi_variant;
     const bool tile_ok = (ni % 4 == 0) && ni >= 32 && aligned16(in) && aligned16(div) && aligned16(out);
-    if (variant == 0) variant = tile_ok ? 2 : 1;
-    if (variant == 2 && !tile_ok) variant = 1;
+    if (variant == 0) variant = tile_ok ? 3 : 1;
+    if (variant != 1 && !tile_ok) variant = 1;
     hipStream_t st = rt().compute;
     if (variant == 1) {
         jacobi_generic_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(in, div, out, ni, nj, nk, alpha, beta);
         BQ_LAUNCH_CHECK("jacobi_generic_kernel");
         return;
     }
-    // tile geometry: 256-wide rows when the row is long enough, else 128-wide
+    if (variant == 3) {
+        int waves = rt().opt_jacobi_rows;
+        if (waves != 4 && waves != 8 && waves != 16) waves = 4;
+        const int threads = waves * 64;
+        int cw = 16;                                     // float4 columns per tile row: pow2 >= ni/4
+        while (cw * 4 < ni && cw < threads) cw *= 2;
+        const int rows = threads / cw;
+        const int nbx = (ni / 4 + cw - 1) / cw, nby = (nj + rows - 1) / rows;
+        // k-chunk: measured optimum at 256^3 is 16 planes (tools/jacobi_tune.py: 4/8/16/32 planes ->
+        // 34.2/34.5/31.8/34.0 us); shorter chunks re-read more planes, longer ones leave CUs idle.
+        // Keep >= ~1024 blocks when the grid is small in x/y.
+        int kchunk = 16;
+        while (kchunk > 4 && (long)nbx * nby * ((nk + kchunk - 1) / kchunk) < 1024) kchunk /= 2;
+        if (rt().opt_jacobi_kchunk > 0) kchunk = rt().opt_jacobi_kchunk;
+        const int nbz = (nk + kchunk - 1) / kchunk;
+        const int nblk = nbx * nby * nbz;
+#define BQ_JM(W) jacobi_march_kernel<W><<<nblk, W * 64, 0, st>>>(in, div, out, ni, nj, nk, cw, nbx, nby, kchunk, alpha, beta)
+        if (waves == 4) BQ_JM(4); else if (waves == 8) BQ_JM(8); else BQ_JM(16);
+#undef BQ_JM
+        BQ_LAUNCH_CHECK("jacobi_march_kernel");
+        return;
+    }
+    // tile geometry: 256-wide rows when the row is long enough, else 128-wide; R float4 per thread
     const bool wide = ni > 128;
-    const int TX = wide ? 256 : 128, TY = wide ? 16 : 32;
+    int R = rt().opt_jacobi_rows;
+    if (R != 1 && R != 2 && R != 4) R = 4;
+    const int TX = wide ? 256 : 128, TY = (wide ? 4 : 8) * R;
     const int bx = (ni + TX - 1) / TX, by = (nj + TY - 1) / TY;
     // k-chunks: enough blocks to fill 256 CUs x 2 resident blocks, at least 8 planes per chunk
     int want = (1024 + bx * by - 1) / (bx * by);
@@ -297,8 +399,10 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
     if (rt().opt_jacobi_kchunk > 0) kchunk = rt().opt_jacobi_kchunk;
     const int bz = (nk + kchunk - 1) / kchunk;
     dim3 grid(bx, by, bz);
-    if (wide) jacobi_tile_kernel<64, 4><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta);
-    else      jacobi_tile_kernel<32, 4><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta);
+#define BQ_JT(TXV, RR) jacobi_tile_kernel<TXV, RR><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta)
+    if (wide) { if (R == 4) BQ_JT(64, 4); else if (R == 2) BQ_JT(64, 2); else BQ_JT(64, 1); }
+    else      { if (R == 4) BQ_JT(32, 4); else if (R == 2) BQ_JT(32, 2); else BQ_JT(32, 1); }
+#undef BQ_JT
     BQ_LAUNCH_CHECK("jacobi_tile_kernel");
 }
 

@@ -195,6 +195,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_JACOBI_VARIANT:  g_rt.opt_jacobi_variant = value; break;
     case FL_OPT_PROFILE_JACOBI:  g_rt.opt_profile_jacobi = value ? 1 : 0; break;
     case FL_OPT_JACOBI_KCHUNK:   g_rt.opt_jacobi_kchunk = value < 0 ? 0 : value; break;
+    case FL_OPT_JACOBI_ROWS:     g_rt.opt_jacobi_rows = value; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -207,6 +208,7 @@ int fl_get_option(int option)
     case FL_OPT_JACOBI_VARIANT:  return g_rt.opt_jacobi_variant;
     case FL_OPT_PROFILE_JACOBI:  return g_rt.opt_profile_jacobi;
     case FL_OPT_JACOBI_KCHUNK:   return g_rt.opt_jacobi_kchunk;
+    case FL_OPT_JACOBI_ROWS:     return g_rt.opt_jacobi_rows;
     default: return -1;
     }
 }

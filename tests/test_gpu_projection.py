@@ -37,7 +37,7 @@ JACOBI_GRIDS = [(24, 20, 16), (30, 9, 7), (32, 32, 32), (64, 48, 40), (128, 37, 
 
 
 @pytest.mark.parametrize("ni,nj,nk", JACOBI_GRIDS)
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_jacobi_sweeps(hip, ni, nj, nk, variant):
     import gpufluidsimulation_amd as bq
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, variant)
