@@ -152,7 +152,7 @@ def main():
     if launches.value > 0:
         us = ms.value * 1e3 / launches.value
         achieved = JACOBI_BYTES_PER_VOXEL * n ** 3 / (us * 1e-6) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "jacobi_tile_kernel", "achieved": round(achieved, 1),
+        line["roofline"] = {"bound": "hbm", "kernel": "jacobi_march_kernel", "achieved": round(achieved, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                             "traffic": pmc_traffic(n), "us_per_launch": round(us, 3),
                             "launches_timed": int(launches.value),
