@@ -10,7 +10,7 @@ PKG      := gpufluidsimulation_amd
 CSRC     := $(PKG)/csrc
 OBJDIR   := build/obj
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
-RCCL_LIB ?= -L/opt/rocm/lib -lrccl
+RCCL_LIB ?= -ldl    # RCCL itself is dlopen'ed by bq_halo.hip on first multi-GPU use
 
 KERNEL_SRCS := $(sort $(wildcard $(CSRC)/*.hip))
 KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(KERNEL_SRCS))

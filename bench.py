@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="N > 1: ghost planes over RCCL/xGMI (default) or staged through the host over gloo (debug)")
     return ap.parse_args()
 
 
@@ -99,14 +102,30 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.transport == "rccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import gpufluidsimulation_amd as bq
+    from gpufluidsimulation_amd import transport
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     lib = bq.hip_lib()
     n = args.n
-    s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
-    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
+    if lib.fl_init(local_rank) != 0:
+        bq.check()
+    # N > 1: weak scaling -- the grid grows along z, n x n x (n*N), one z-slab of n planes per GPU, one
+    # source per slab (same work everywhere); N = 1 is exactly BASELINE's n^3 workload
+    keep = None
+    if world > 1:
+        if args.transport == "rccl":
+            transport.init_rccl(lib, dist)
+        else:
+            keep = transport.HostStagedTransport(lib, dist)
+        s = BimocqGPUSolver(n, n, n * world, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
+    else:
+        s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
+    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(world)])
     s.setProjection(args.jacobi_iters, args.halfrdx)
     dt = 2.0 / n
 
@@ -134,7 +153,7 @@ def main():
     ms, launches = C.c_double(0.0), C.c_longlong(0)
     lib.fl_jacobi_profile(C.byref(ms), C.byref(launches))
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -147,7 +166,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"bimocq3D {n}^3 rising smoke, {args.jacobi_iters} Jacobi iters, fp32, "
                                f"halfrdx {args.halfrdx}, reinit every step",
-                   "grid_per_gpu": [n, n, n], "dt": dt, "parallelism": "1 GPU" if world == 1 else f"{world} replicas"},
+                   "grid_per_gpu": [n, n, n], "global_grid": [n, n, n * world], "dt": dt,
+                   "parallelism": "1 GPU" if world == 1 else
+                   f"{world} z-slabs of {n} planes, {args.ghost} ghost planes, neighbour exchange over {args.transport}"},
     }
     if launches.value > 0:
         us = ms.value * 1e3 / launches.value
@@ -165,6 +186,7 @@ def main():
     s.close()
     if dist is not None:
         dist.barrier()
+        lib.fl_comm_destroy()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -68,6 +68,20 @@ HIP_SIGS = {
     "gpu_gradient": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
     "gpu_residual_norms": (None, [VP, VP, c_i, c_i, c_i, C.POINTER(c_d), C.POINTER(c_f)]),
     "gpu_clamp_extrema_box": (None, [VP, VP, c_i, c_i, c_i]),
+    "gpu_clamp_extrema_box_w": (None, [VP, VP, c_i, c_i, c_i]),
+    "gpu_compensate_error_velocity": (None, [VP] * 12 + _G + [c_b]),
+    "gpu_compensate_error_field": (None, [VP] * 6 + _G + [c_b]),
+    "fl_report_error": (None, [c_i, C.c_char_p]),
+    # 4. multi-GPU
+    "fl_set_slab": (None, [c_i, c_i, c_i, c_i, c_i]),
+    "fl_comm_unique_id": (c_i, [VP]),
+    "fl_comm_init": (c_i, [VP, c_i, c_i]),
+    "fl_comm_destroy": (None, []),
+    "fl_comm_rank": (c_i, []),
+    "fl_comm_size": (c_i, []),
+    "fl_halo_exchange": (None, [c_i, C.POINTER(VP), C.POINTER(C.c_size_t), C.POINTER(c_i), c_i, c_i, c_i, c_i]),
+    "fl_halo_wait": (None, []),
+    "fl_comm_set_custom": (None, [c_i, c_i, VP, VP]),
 }
 
 FL_OK, FL_ERR_NO_DEVICE, FL_ERR_HIP, FL_ERR_BAD_ARGUMENT, FL_ERR_UNSUPPORTED, FL_ERR_COMM = range(6)

@@ -13,12 +13,17 @@ namespace bq {
     const int i = blockIdx.x * 64 + threadIdx.x;                \
     const int j = blockIdx.y * 4 + threadIdx.y;                 \
     const int k = blockIdx.z;                                   \
-    if (i >= (nbi) || j >= (nbj) || k >= (nbk)) return;
+    if (i >= (nbi) || j >= (nbj) || k >= (nbk)) return;         \
+    const int kg = k + g.koff;                                  \
+    (void)kg;
 
 static inline dim3 grid_for(int nbi, int nbj, int nbk) { return dim3((nbi + 63) / 64, (nbj + 3) / 4, nbk); }
 static const dim3 kBlock(64, 4, 1);
 
-struct Grid { int ni, nj, nk; };     // CELL dims
+// CELL dims of the LOCAL buffers plus the z-slab context: local plane k is global plane k + koff of a
+// grid with nkg cell planes (single GPU: koff = 0, nkg = nk).  Index windows, positions and clamps
+// are evaluated in GLOBAL coordinates so that a slab rank computes exactly what one GPU would.
+struct Grid { int ni, nj, nk, koff, nkg; };
 
 // ---- 9-point stencil of sub-voxel sample positions (GPU_kernel.cu:317-348) ---------------
 struct Nine {
@@ -50,9 +55,9 @@ __global__ __launch_bounds__(256) void forward_kernel(const float *u, const floa
                                                       Spacing sp, Grid g, float cfldt, float dt)
 {
     BQ_IJK(g.ni, g.nj, g.nk)
-    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && k > 1 && k < g.nk - 2)) return;
-    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk), make_field(v, g.ni, g.nj + 1, g.nk), make_field(w, g.ni, g.nj, g.nk + 1)};
-    f3 hi = mk3((float)g.ni * sp.h - sp.h, (float)g.nj * sp.h - sp.h, (float)g.nk * sp.h - sp.h);
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) return;
+    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk, g.koff), make_field(v, g.ni, g.nj + 1, g.nk, g.koff), make_field(w, g.ni, g.nj, g.nk + 1, g.koff)};
+    f3 hi = mk3((float)g.ni * sp.h - sp.h, (float)g.nj * sp.h - sp.h, (float)g.nkg * sp.h - sp.h);
     size_t id = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
     f3 q = trace<P2>(vel, sp, hi, cfldt, dt, mk3(xf[id], yf[id], zf[id]));
     xf[id] = q.x; yf[id] = q.y; zf[id] = q.z;
@@ -72,11 +77,11 @@ __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v
                                                   Spacing sp, Grid g, float substep)
 {
     BQ_IJK(g.ni, g.nj, g.nk)
-    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && k > 1 && k < g.nk - 2)) return;
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) return;
     const float h = sp.h;
-    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk), make_field(v, g.ni, g.nj + 1, g.nk), make_field(w, g.ni, g.nj, g.nk + 1)};
-    Map3 in{make_field(xi, g.ni, g.nj, g.nk), make_field(yi, g.ni, g.nj, g.nk), make_field(zi, g.ni, g.nj, g.nk)};
-    f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk, g.koff), make_field(v, g.ni, g.nj + 1, g.nk, g.koff), make_field(w, g.ni, g.nj, g.nk + 1, g.koff)};
+    Map3 in{make_field(xi, g.ni, g.nj, g.nk, g.koff), make_field(yi, g.ni, g.nj, g.nk, g.koff), make_field(zi, g.ni, g.nj, g.nk, g.koff)};
+    f3 pt = mk3(h * (float)i, h * (float)j, h * (float)kg);
     f3 vl = get_velocity<P2>(vel, sp, pt);
     f3 tp = mk3((vl.x > 0) ? pt.x - h : pt.x + h, (vl.y > 0) ? pt.y - h : pt.y + h, (vl.z > 0) ? pt.z - h : pt.z + h);
     f3 tv = get_velocity<P2>(vel, sp, tp);
@@ -97,13 +102,13 @@ __global__ __launch_bounds__(256) void advect_kernel(float *field, const float *
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
-    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < k && k < nbk - 3)) return;
+    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < kg && kg < g.nkg + dz - 3)) return;
     const float h = sp.h;
-    Map3 back{make_field(bx, g.ni, g.nj, g.nk), make_field(by, g.ni, g.nj, g.nk), make_field(bz, g.ni, g.nj, g.nk)};
-    Field src = make_field(field_init, nbi, nbj, nbk);
+    Map3 back{make_field(bx, g.ni, g.nj, g.nk, g.koff), make_field(by, g.ni, g.nj, g.nk, g.koff), make_field(bz, g.ni, g.nj, g.nk, g.koff)};
+    Field src = make_field(field_init, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
-    f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nk - h);
-    f3 c = nine_centre(n, i, j, k);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
+    f3 c = nine_centre(n, i, j, kg);
     float sum = 0.f;
     if (PT) {
         f3 p0 = clamp3(map_at<P2>(back, sp, c), lo, hi);
@@ -129,14 +134,14 @@ __global__ __launch_bounds__(256) void double_advect_kernel(float *field, const 
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
-    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < k && k < nbk - 3)) return;
+    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < kg && kg < g.nkg + dz - 3)) return;
     const float h = sp.h;
-    Map3 back{make_field(bx, g.ni, g.nj, g.nk), make_field(by, g.ni, g.nj, g.nk), make_field(bz, g.ni, g.nj, g.nk)};
-    Map3 bprev{make_field(px, g.ni, g.nj, g.nk), make_field(py, g.ni, g.nj, g.nk), make_field(pz, g.ni, g.nj, g.nk)};
-    Field src = make_field(prev, nbi, nbj, nbk);
+    Map3 back{make_field(bx, g.ni, g.nj, g.nk, g.koff), make_field(by, g.ni, g.nj, g.nk, g.koff), make_field(bz, g.ni, g.nj, g.nk, g.koff)};
+    Map3 bprev{make_field(px, g.ni, g.nj, g.nk, g.koff), make_field(py, g.ni, g.nj, g.nk, g.koff), make_field(pz, g.ni, g.nj, g.nk, g.koff)};
+    Field src = make_field(prev, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
-    f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nk - h);
-    f3 c = nine_centre(n, i, j, k);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
+    f3 c = nine_centre(n, i, j, kg);
     float sum = 0.f;
     if (PT) {
         f3 mid = clamp3(map_at<P2>(back, sp, c), lo, hi);
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
-    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < k && k < nbk - 3)) return;
+    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < kg && kg < g.nkg + dz - 3)) return;
     size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     field[id] = field[id] + 0.0f;
 }
@@ -176,13 +181,13 @@ __global__ __launch_bounds__(256) void cumulate_kernel(const float *srcp, float 
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
-    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < k && k < nbk - 2)) return;
+    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
     const float h = sp.h;
-    Map3 m{make_field(mx, g.ni, g.nj, g.nk), make_field(my, g.ni, g.nj, g.nk), make_field(mz, g.ni, g.nj, g.nk)};
-    Field src = make_field(srcp, nbi, nbj, nbk);
+    Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
+    Field src = make_field(srcp, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
-    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nk);
-    f3 c = nine_centre(n, i, j, k);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
+    f3 c = nine_centre(n, i, j, kg);
     float sum = 0.f;
     if (PT) {
         f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
@@ -209,13 +214,13 @@ __global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, cons
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
-    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < k && k < nbk - 2)) return;
+    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
     const float h = sp.h;
-    Map3 m{make_field(mx, g.ni, g.nj, g.nk), make_field(my, g.ni, g.nj, g.nk), make_field(mz, g.ni, g.nj, g.nk)};
-    Field src = make_field(srcp, nbi, nbj, nbk);
+    Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
+    Field src = make_field(srcp, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
-    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nk);
-    f3 c = nine_centre(n, i, j, k);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
+    f3 c = nine_centre(n, i, j, kg);
     float sum = 0.f;
     if (PT) {
         f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
@@ -235,10 +240,13 @@ __global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, cons
 }
 
 // ---- A6: clampExtrema_kernel (GPU_kernel.cu:146-167) --------------------------------------
-__global__ __launch_bounds__(256) void clamp_box_kernel(const float *before, float *after, int ni, int nj, int nk)
+__global__ __launch_bounds__(256) void clamp_box_kernel(const float *before, float *after, int ni, int nj, int nk,
+                                                        int koff, int nkg)
 {
-    BQ_IJK(ni, nj, nk)
-    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1)) return;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= ni || j >= nj || k >= nk) return;
+    const int kg = k + koff;                     // nkg: GLOBAL plane count of this buffer
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && kg > 0 && kg < nkg - 1 && k > 0 && k < nk - 1)) return;
     const size_t sj = ni, sk = (size_t)ni * nj;
     const size_t id = (size_t)i + sj * j + sk * k;
     float mx = before[id], mn = mx;
@@ -263,11 +271,11 @@ __global__ __launch_bounds__(256) void estimate_kernel(float *dist,
                                                        Spacing sp, Grid g)
 {
     BQ_IJK(g.ni, g.nj, g.nk)
-    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && k > 1 && k < g.nk - 2)) return;
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) return;
     const float h = sp.h;
-    Map3 first{make_field(xb, g.ni, g.nj, g.nk), make_field(yb, g.ni, g.nj, g.nk), make_field(zb, g.ni, g.nj, g.nk)};
-    Map3 second{make_field(xf, g.ni, g.nj, g.nk), make_field(yf, g.ni, g.nj, g.nk), make_field(zf, g.ni, g.nj, g.nk)};
-    f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+    Map3 first{make_field(xb, g.ni, g.nj, g.nk, g.koff), make_field(yb, g.ni, g.nj, g.nk, g.koff), make_field(zb, g.ni, g.nj, g.nk, g.koff)};
+    Map3 second{make_field(xf, g.ni, g.nj, g.nk, g.koff), make_field(yf, g.ni, g.nj, g.nk, g.koff), make_field(zf, g.ni, g.nj, g.nk, g.koff)};
+    f3 pt = mk3(h * (float)i, h * (float)j, h * (float)kg);
     f3 back = map_at<P2>(first, sp, pt);
     f3 fwd = map_at<P2>(second, sp, back);
     float d_bf = (pt.x - fwd.x) * (pt.x - fwd.x) + (pt.y - fwd.y) * (pt.y - fwd.y) + (pt.z - fwd.z) * (pt.z - fwd.z);
@@ -285,18 +293,26 @@ __global__ __launch_bounds__(256) void semilag_kernel(float *field, const float 
 {
     const int bi = g.ni + dx, bj = g.nj + dy, bk = g.nk + dz;
     BQ_IJK(bi, bj, bk)
-    if (!(i > 1 && i < bi - 2 - dx && j > 1 && j < bj - 2 - dy && k > 1 && k < bk - 2 - dz)) return;
+    if (!(i > 1 && i < bi - 2 - dx && j > 1 && j < bj - 2 - dy && kg > 1 && kg < g.nkg - 2)) return;
     const float h = sp.h;
-    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk), make_field(v, g.ni, g.nj + 1, g.nk), make_field(w, g.ni, g.nj, g.nk + 1)};
-    Field src = make_field(field_src, bi, bj, bk);
+    Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk, g.koff), make_field(v, g.ni, g.nj + 1, g.nk, g.koff), make_field(w, g.ni, g.nj, g.nk + 1, g.koff)};
+    Field src = make_field(field_src, bi, bj, bk, g.koff);
     f3 org = mk3(-(float)dx * 0.5f * h, -(float)dy * 0.5f * h, -(float)dz * 0.5f * h);
-    f3 hi = mk3((float)g.ni * h - h, (float)g.nj * h - h, (float)g.nk * h - h);
-    f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+    f3 hi = mk3((float)g.ni * h - h, (float)g.nj * h - h, (float)g.nkg * h - h);
+    f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)kg + org.z);
     f3 pn = trace<P2>(vel, sp, hi, cfldt, dt, pt);
     field[(size_t)i + (size_t)bi * j + (size_t)bi * bj * k] = sample<P2>(src, sp, org, pn);
 }
 
 // ---- host-side dispatch helpers -----------------------------------------------------------
+// local dims + the library's slab context (fl_set_slab); single GPU: koff = 0, nkg = nk
+static inline Grid mk_grid(int ni, int nj, int nk)
+{
+    const Runtime &r = rt();
+    if (r.slab_on) return Grid{ni, nj, nk, r.slab_koff, r.slab_nkg};
+    return Grid{ni, nj, nk, 0, nk};
+}
+
 static bool dims_ok(int ni, int nj, int nk, const char *op)
 {
     if (ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, op, "non-positive grid dims"); return false; }
@@ -351,9 +367,11 @@ static void double_comp(float *f, const float *prev, const float *bx, const floa
     }
     BQ_DISPATCH2(double_advect_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, prev, bx, by, bz, px, py, pz, sp, g, dx, dy, dz, blend);
 }
-static void clamp_box(const float *before, float *after, int ni, int nj, int nk)
+// nk: local buffer planes; dz: 1 for the w buffer (its global plane count is nkg + 1)
+static void clamp_box(const float *before, float *after, int ni, int nj, int nk, int dz)
 {
-    clamp_box_kernel<<<grid_for(ni, nj, nk), kBlock, 0, rt().compute>>>(before, after, ni, nj, nk);
+    Grid g = mk_grid(1, 1, nk - dz);
+    clamp_box_kernel<<<grid_for(ni, nj, nk), kBlock, 0, rt().compute>>>(before, after, ni, nj, nk, g.koff, g.nkg + dz);
     BQ_LAUNCH_CHECK("clamp_box_kernel");
 }
 
@@ -377,7 +395,7 @@ void gpu_solve_forward(float *u, float *v, float *w, float *x_fwd, float *y_fwd,
 {
     BQ_ENTER("gpu_solve_forward", u, v, w, x_fwd, y_fwd, z_fwd)
     BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_solve_forward");     // cfldt <= 0 would never terminate
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt);
 }
 
@@ -387,7 +405,7 @@ void gpu_solve_backwardDMC(float *u, float *v, float *w, float *x_in, float *y_i
 {
     BQ_ENTER("gpu_solve_backwardDMC", u, v, w, x_in, y_in, z_in, x_out, y_out, z_out)
     BQ_REQUIRE(x_in != x_out && y_in != y_out && z_in != z_out, "gpu_solve_backwardDMC");
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep);
 }
 
@@ -396,7 +414,7 @@ void gpu_advect_velocity(float *u, float *v, float *w, float *u_init, float *v_i
                          float h, int ni, int nj, int nk, bool is_point)
 {
     BQ_ENTER("gpu_advect_velocity", u, v, w, u_init, v_init, w_init, backward_x, backward_y, backward_z)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     advect_comp(u, u_init, backward_x, backward_y, backward_z, sp, g, 1, 0, 0, is_point);
     advect_comp(v, v_init, backward_x, backward_y, backward_z, sp, g, 0, 1, 0, is_point);
     advect_comp(w, w_init, backward_x, backward_y, backward_z, sp, g, 0, 0, 1, is_point);
@@ -409,7 +427,7 @@ void gpu_advect_vel_double(float *u, float *v, float *w, float *utemp, float *vt
 {
     BQ_ENTER("gpu_advect_vel_double", u, v, w, utemp, vtemp, wtemp, backward_x, backward_y, backward_z,
              backward_xprev, backward_yprev, backward_zprev)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     double_comp(u, utemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 1, 0, 0, is_point, blend_coeff);
     double_comp(v, vtemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 1, 0, is_point, blend_coeff);
     double_comp(w, wtemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 1, is_point, blend_coeff);
@@ -419,7 +437,7 @@ void gpu_advect_field(float *field, float *field_init, float *backward_x, float 
                       float h, int ni, int nj, int nk, bool is_point)
 {
     BQ_ENTER("gpu_advect_field", field, field_init, backward_x, backward_y, backward_z)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     advect_comp(field, field_init, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point);
 }
 
@@ -429,7 +447,7 @@ void gpu_advect_field_double(float *field, float *field_prev, float *backward_x,
 {
     BQ_ENTER("gpu_advect_field_double", field, field_prev, backward_x, backward_y, backward_z,
              backward_xprev, backward_yprev, backward_zprev)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     double_comp(field, field_prev, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 0, is_point, blend_coeff);
 }
 
@@ -439,7 +457,7 @@ void gpu_accumulate_velocity(float *u_change, float *v_change, float *w_change,
                              float h, int ni, int nj, int nk, bool is_point, float coeff)
 {
     BQ_ENTER("gpu_accumulate_velocity", u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     cumulate_comp(u_change, du_init, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point, coeff);
     cumulate_comp(v_change, dv_init, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point, coeff);
     cumulate_comp(w_change, dw_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, coeff);
@@ -449,7 +467,7 @@ void gpu_accumulate_field(float *field_change, float *dfield_init, float *forwar
                           float h, int ni, int nj, int nk, bool is_point, float coeff)
 {
     BQ_ENTER("gpu_accumulate_field", field_change, dfield_init, forward_x, forward_y, forward_z)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     cumulate_comp(field_change, dfield_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point, coeff);
 }
 
@@ -457,7 +475,7 @@ void gpu_estimate_distortion(float *du, float *x_init, float *y_init, float *z_i
                              float *x_fwd, float *y_fwd, float *z_fwd, float h, int ni, int nj, int nk)
 {
     BQ_ENTER("gpu_estimate_distortion", du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     BQ_DISPATCH1(estimate_kernel, sp.pow2, grid_for(ni, nj, nk), du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd, sp, g);
 }
 
@@ -469,7 +487,7 @@ void gpu_compensate_velocity(float *u, float *v, float *w, float *du, float *dv,
 {
     BQ_ENTER("gpu_compensate_velocity", u, v, w, du, dv, dw, u_src, v_src, w_src,
              forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     const size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
     // error at time 0 into *_src (GPU_kernel.cu:652-654)
     compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point);
@@ -484,9 +502,9 @@ void gpu_compensate_velocity(float *u, float *v, float *w, float *du, float *dv,
     cumulate_comp(v_src, v, backward_x, backward_y, backward_z, sp, g, 0, 1, 0, is_point, -0.5f);
     cumulate_comp(w_src, w, backward_x, backward_y, backward_z, sp, g, 0, 0, 1, is_point, -0.5f);
     // limiter (:663-665)
-    clamp_box(du, u, ni + 1, nj, nk);
-    clamp_box(dv, v, ni, nj + 1, nk);
-    clamp_box(dw, w, ni, nj, nk + 1);
+    clamp_box(du, u, ni + 1, nj, nk, 0);
+    clamp_box(dv, v, ni, nj + 1, nk, 0);
+    clamp_box(dw, w, ni, nj, nk + 1, 1);
 }
 
 void gpu_compensate_field(float *u, float *du, float *u_src,
@@ -495,11 +513,11 @@ void gpu_compensate_field(float *u, float *du, float *u_src,
                           float h, int ni, int nj, int nk, bool is_point)
 {
     BQ_ENTER("gpu_compensate_field", u, du, u_src, forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point);
     fl_memcpy_d2d(du, u, (size_t)ni * nj * nk * sizeof(float));
     cumulate_comp(u_src, u, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point, -0.5f);
-    clamp_box(du, u, ni, nj, nk);
+    clamp_box(du, u, ni, nj, nk, 0);
 }
 
 void gpu_semilag(float *field, float *field_src, float *u, float *v, float *w,
@@ -508,14 +526,41 @@ void gpu_semilag(float *field, float *field_src, float *u, float *v, float *w,
     BQ_ENTER("gpu_semilag", field, field_src, u, v, w)
     BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_semilag");
     BQ_REQUIRE((dim_x | dim_y | dim_z) == 0 || (dim_x + dim_y + dim_z) == 1, "gpu_semilag");
-    Spacing sp = make_spacing(h); Grid g{ni, nj, nk};
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     BQ_DISPATCH1(semilag_kernel, sp.pow2, grid_for(ni + dim_x, nj + dim_y, nk + dim_z), field, field_src, u, v, w, sp, g, dim_x, dim_y, dim_z, cfldt, dt);
 }
 
 void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
 {
     BQ_ENTER("gpu_clamp_extrema_box", before, after)
-    clamp_box(before, after, ni, nj, nk);
+    clamp_box(before, after, ni, nj, nk, 0);
+}
+
+void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
+{
+    BQ_ENTER("gpu_clamp_extrema_box_w", before, after)
+    clamp_box(before, after, ni, nj, nk, 1);
+}
+
+void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+                                   float *u_src, float *v_src, float *w_src,
+                                   float *forward_x, float *forward_y, float *forward_z,
+                                   float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_compensate_error_velocity", u, v, w, du, dv, dw, u_src, v_src, w_src, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point);
+    compensate_comp(v, dv, v_src, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point);
+    compensate_comp(w, dw, w_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point);
+}
+
+void gpu_compensate_error_field(float *u, float *du, float *u_src,
+                                float *forward_x, float *forward_y, float *forward_z,
+                                float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_compensate_error_field", u, du, u_src, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point);
 }
 
 } // extern "C"

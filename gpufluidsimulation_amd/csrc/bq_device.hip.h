@@ -18,18 +18,20 @@ namespace bq {
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 
-// A dense x-fastest fp32 field as the kernels see it.
+// A dense x-fastest fp32 field as the kernels see it.  On a z-slab rank the buffer holds the
+// global planes [koff, koff + nz): sample positions are global, the plane index is made local here.
 struct Field {
     __amdgpu_buffer_rsrc_t rsrc;
     int nx, ny;            // row pitch and slab pitch factor (elements)
+    int koff;              // global k of local plane 0 (0 on a single GPU)
 };
 
-__device__ __forceinline__ Field make_field(const float *p, int nx, int ny, int nz)
+__device__ __forceinline__ Field make_field(const float *p, int nx, int ny, int nz, int koff = 0)
 {
     Field f;
     unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 4u;
     f.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
-    f.nx = nx; f.ny = ny;
+    f.nx = nx; f.ny = ny; f.koff = koff;
     return f;
 }
 
@@ -93,7 +95,7 @@ __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off
     int i = (int)flx, j = (int)fly, k = (int)flz;
     Cell c;
     c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k;
-    int idx = i + f.nx * j + f.nx * f.ny * k;
+    int idx = i + f.nx * j + f.nx * f.ny * (k - f.koff);
     c.base = (unsigned)idx * 4u;
     return c;
 }

@@ -1,0 +1,205 @@
+// bq_halo.hip -- z-slab context and ghost-plane exchange over RCCL.
+//
+// One process per GPU.  Rank r owns the global cell planes [own0, own1) of a grid with nkg planes and
+// stores the planes [own0 - G, own1 + G) of every field (G ghost planes per side; ghost planes that
+// fall outside the global grid stay zero, which is what a read outside the allocation returns on a
+// single GPU).  A plane is one contiguous nx*ny block, so an exchange is four contiguous transfers:
+// ncclSend/ncclRecv to/from rank-1 and rank+1 inside one ncclGroup, on the library's halo stream.
+// xGMI is point-to-point: a slab neighbour exchange uses exactly one link per neighbour and there is
+// no bulk collective anywhere on this path (the only all-reduces carry 1-2 scalars).
+//
+// RCCL is dlopen'ed on first use, so single-GPU runs never load it.
+#include "bq_host.h"
+
+#include <dlfcn.h>
+#include <cstdint>
+#include <cstring>
+
+namespace bq {
+
+// the slice of the RCCL API this file uses (rccl/rccl.h), resolved with dlsym
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat = 7, ncclDouble = 8 };       // ncclDataType_t
+enum { ncclSum = 0, ncclMax = 2 };            // ncclRedOp_t
+
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+static Rccl g_rccl;
+static ncclComm_t g_comm = nullptr;
+static int g_rank = 0, g_nranks = 1;
+// optional host-side transport (fl_comm_set_custom): used instead of RCCL when set
+static fl_exchange_cb g_custom_exchange = nullptr;
+static fl_allreduce_cb g_custom_allreduce = nullptr;
+static hipEvent_t g_ev_ready = nullptr, g_ev_done = nullptr;
+
+static bool load_rccl()
+{
+    if (g_rccl.handle) return true;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { latch(FL_ERR_COMM, "dlopen(librccl)", dlerror()); return false; }
+    g_rccl.handle = h;
+#define BQ_SYM(field, name) *(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) { latch(FL_ERR_COMM, "dlsym", name); return false; }
+    BQ_SYM(GetUniqueId, "ncclGetUniqueId")
+    BQ_SYM(CommInitRank, "ncclCommInitRank")
+    BQ_SYM(CommDestroy, "ncclCommDestroy")
+    BQ_SYM(Send, "ncclSend")
+    BQ_SYM(Recv, "ncclRecv")
+    BQ_SYM(AllReduce, "ncclAllReduce")
+    BQ_SYM(GroupStart, "ncclGroupStart")
+    BQ_SYM(GroupEnd, "ncclGroupEnd")
+    BQ_SYM(GetErrorString, "ncclGetErrorString")
+#undef BQ_SYM
+    return true;
+}
+
+static bool nccl_ok(int rc, const char *what)
+{
+    if (rc == ncclSuccess) return true;
+    latch(FL_ERR_COMM, what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error");
+    return false;
+}
+#define BQ_NCCL(call) nccl_ok(g_rccl.call, #call)
+
+// In-stream all-reduce of `count` values already on the device (used by gpu_max_abs3 and the
+// residual norms when a communicator exists).  No-op on a single rank.
+bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStream_t st)
+{
+    if (g_nranks <= 1) return true;
+    if (g_custom_allreduce) {
+        const size_t bytes = count * (is_double ? 8 : 4);
+        void *host = pinned(bytes < 64 ? 64 : bytes);
+        if (!host) return false;
+        if (!BQ_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return false;
+        g_custom_allreduce(host, (int)count, is_double ? 1 : 0, is_max ? 1 : 0);
+        return BQ_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st)) && BQ_HIP(hipStreamSynchronize(st));
+    }
+    if (!g_comm) return true;
+    return BQ_NCCL(AllReduce(dev, dev, count, is_double ? ncclDouble : ncclFloat, is_max ? ncclMax : ncclSum, g_comm, st));
+}
+int comm_ranks() { return g_nranks; }
+
+} // namespace bq
+
+using namespace bq;
+
+extern "C" {
+
+void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
+{
+    Runtime &r = rt();
+    if (nk_global <= 0) { r.slab_on = false; return; }
+    r.slab_on = true;
+    r.slab_koff = koff; r.slab_nkg = nk_global; r.slab_own0 = own0; r.slab_own1 = own1; r.slab_nkl = nk_local;
+}
+
+int fl_comm_rank(void) { return g_rank; }
+int fl_comm_size(void) { return g_nranks; }
+
+int fl_comm_unique_id(void *id128)
+{
+    if (!id128) return FL_ERR_BAD_ARGUMENT;
+    if (!ensure_ready("fl_comm_unique_id") || !load_rccl()) return fl_last_error();
+    ncclUniqueId id;
+    if (!BQ_NCCL(GetUniqueId(&id))) return FL_ERR_COMM;
+    memcpy(id128, &id, sizeof id);
+    return FL_OK;
+}
+
+int fl_comm_init(const void *id128, int rank, int nranks)
+{
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) { latch(FL_ERR_BAD_ARGUMENT, "fl_comm_init", "bad rank/size"); return FL_ERR_BAD_ARGUMENT; }
+    if (!ensure_ready("fl_comm_init")) return fl_last_error();
+    g_rank = rank; g_nranks = nranks;
+    if (nranks == 1) return FL_OK;
+    if (!load_rccl()) return FL_ERR_COMM;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    if (!BQ_NCCL(CommInitRank(&g_comm, nranks, id, rank))) return FL_ERR_COMM;
+    if (!g_ev_ready) { BQ_HIP(hipEventCreateWithFlags(&g_ev_ready, hipEventDisableTiming)); BQ_HIP(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming)); }
+    return fl_last_error();
+}
+
+void fl_comm_destroy(void)
+{
+    if (g_comm) { fl_sync(); g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
+    g_custom_exchange = nullptr; g_custom_allreduce = nullptr;
+    g_rank = 0; g_nranks = 1;
+}
+
+void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb exchange, fl_allreduce_cb allreduce)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!exchange || !allreduce))) {
+        latch(FL_ERR_BAD_ARGUMENT, "fl_comm_set_custom", "bad rank/size/callbacks"); return;
+    }
+    g_rank = rank; g_nranks = nranks;
+    g_custom_exchange = exchange; g_custom_allreduce = allreduce;
+}
+
+// Refresh `depth` ghost planes on both sides of n fields in one RCCL group.
+//   fields[f]      local buffer of (nk_local + extra[f]) planes of plane_elems[f] floats
+//   extra[f]       1 for the w component (nk+1 planes; its high ghost takes depth+1 planes), else 0
+//   nk_local       local CELL planes = owned + 2*G
+// Ordering: the halo stream first waits for everything queued on the compute stream; with
+// wait != 0 the compute stream then waits for the exchange (otherwise call fl_halo_wait() before
+// the ghost planes are read or the sent planes are overwritten).
+void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, const int *extra,
+                      int nk_local, int G, int depth, int wait)
+{
+    if (g_nranks <= 1) return;
+    Runtime &r = rt();
+    const int own = nk_local - 2 * G;
+    if (n <= 0 || !fields || !plane_elems || !extra || depth < 1 || depth > G || own < depth + 1) {
+        latch(FL_ERR_BAD_ARGUMENT, "fl_halo_exchange", "bad depth/ghost/owned plane counts"); return;
+    }
+    if (g_custom_exchange) {                    // host-side transport: everything queued so far must be done
+        BQ_HIP(hipStreamSynchronize(r.compute));
+        g_custom_exchange(n, fields, plane_elems, extra, nk_local, G, depth);
+        (void)wait;
+        return;
+    }
+    if (!g_comm) { latch(FL_ERR_COMM, "fl_halo_exchange", "no communicator (fl_comm_init)"); return; }
+    BQ_HIP(hipEventRecord(g_ev_ready, r.compute));
+    BQ_HIP(hipStreamWaitEvent(r.halo, g_ev_ready, 0));
+    const int lo = g_rank - 1, hi = g_rank + 1;
+    if (!BQ_NCCL(GroupStart())) return;
+    for (int f = 0; f < n; f++) {
+        float *b = fields[f];
+        const size_t pe = plane_elems[f];
+        const int ex = extra[f];
+        if (lo >= 0) {
+            // my bottom owned planes [G, G+depth+ex) become rank-1's high ghost; its top owned planes fill my low ghost
+            BQ_NCCL(Send(b + pe * (size_t)G, pe * (size_t)(depth + ex), ncclFloat, lo, g_comm, r.halo));
+            BQ_NCCL(Recv(b + pe * (size_t)(G - depth), pe * (size_t)depth, ncclFloat, lo, g_comm, r.halo));
+        }
+        if (hi < g_nranks) {
+            BQ_NCCL(Send(b + pe * (size_t)(G + own - depth), pe * (size_t)depth, ncclFloat, hi, g_comm, r.halo));
+            BQ_NCCL(Recv(b + pe * (size_t)(G + own), pe * (size_t)(depth + ex), ncclFloat, hi, g_comm, r.halo));
+        }
+    }
+    if (!BQ_NCCL(GroupEnd())) return;
+    BQ_HIP(hipEventRecord(g_ev_done, r.halo));
+    if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, g_ev_done, 0));
+}
+
+void fl_halo_wait(void)
+{
+    if (g_nranks <= 1 || !g_ev_done) return;
+    BQ_HIP(hipStreamWaitEvent(rt().compute, g_ev_done, 0));
+}
+
+} // extern "C"

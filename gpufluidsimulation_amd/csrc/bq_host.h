@@ -20,6 +20,10 @@ struct Runtime {
     int         opt_profile_jacobi = 0;
     int         opt_jacobi_kchunk = 0;      // 0 = auto
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
+    // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;
+    // this rank owns global planes [slab_own0, slab_own1) (reductions count only those)
+    bool        slab_on = false;
+    int         slab_koff = 0, slab_nkg = 0, slab_own0 = 0, slab_own1 = 0, slab_nkl = 0;  // nkl: local cell planes
     // persistent workspace (replaces the cudaMalloc/cudaFree pair inside the reference's
     // gpu_projection_jacobi, GPU_kernel.cu:1847-1850,1893-1894)
     void  *scratch = nullptr;           // device: reduction partials
@@ -33,6 +37,9 @@ void latch(int code, const char *what, const char *detail);
 bool ensure_ready(const char *op);      // lazily fl_init(current device); false -> latched
 void *scratch(size_t bytes);            // device scratch of at least `bytes` (grows, never shrinks)
 void *pinned(size_t bytes);
+// bq_halo.hip: in-stream all-reduce of device values across slab ranks (no-op on one rank)
+bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStream_t st);
+int  comm_ranks();
 
 inline bool hip_ok(hipError_t e, const char *what)
 {

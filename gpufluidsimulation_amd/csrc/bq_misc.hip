@@ -22,29 +22,33 @@ __device__ __forceinline__ float hypot2(float y, float z)
 // emit_smoke_velocity_kernel (GPU_kernel.cu:736-758); the u-face offset is used for all three
 // components, as in the reference
 __global__ __launch_bounds__(256) void emit_velocity_kernel(float *field, float h, int ni, int nj, int nk,
-                                                            float cx, float cy, float cz, float radius, float emiter)
+                                                            float cx, float cy, float cz, float radius, float emiter,
+                                                            int koff, int nkg)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (!(i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && k > 1 && k < nk - 2)) return;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, kl = blockIdx.z;
+    const int k = kl + koff;                    // global plane; nkg = GLOBAL planes of this buffer
+    if (!(i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && k > 1 && k < nkg - 2)) return;
     float dx = (float)(((double)(float)i - 0.5) * (double)h - (double)cx);
     float dy = (float)j * h - cy;
     float dz = (float)k * h - cz;
     if (norm3(dx, dy, dz) < radius) {
         float theta = acosf(dy / hypot2(dy, dz));
         float c8 = cosf((float)(8.0 * (double)theta));
-        field[(size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k)] = (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));
+        field[(size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * kl)] = (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));
     }
 }
 
 // emit_smoke_field_kernel (GPU_kernel.cu:760-780)
 __global__ __launch_bounds__(256) void emit_field_kernel(float *rho, float *T, float h, int ni, int nj, int nk,
-                                                         float cx, float cy, float cz, float radius, float density, float temperature)
+                                                         float cx, float cy, float cz, float radius, float density, float temperature,
+                                                         int koff, int nkg)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (!(i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && k > 1 && k < nk - 2)) return;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, kl = blockIdx.z;
+    const int k = kl + koff;
+    if (!(i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && k > 1 && k < nkg - 2)) return;
     float dx = (float)i * h - cx, dy = (float)j * h - cy, dz = (float)k * h - cz;
     if (norm3(dx, dy, dz) < radius) {
-        size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+        size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * kl);
         rho[id] = density;
         T[id] = temperature;
     }
@@ -52,10 +56,11 @@ __global__ __launch_bounds__(256) void emit_field_kernel(float *rho, float *T, f
 
 // add_buoyancy_kernel (GPU_kernel.cu:804-823) with the intended rho/T indexing
 __global__ __launch_bounds__(256) void buoyancy_kernel(float *__restrict__ v, const float *__restrict__ rho, const float *__restrict__ T,
-                                                       int ni, int nj, int nk, float alpha, float beta, float dt)
+                                                       int ni, int nj, int nk, float alpha, float beta, float dt,
+                                                       int koff, int nkg)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= ni || j < 1 || j >= nj) return;
+    if (i >= ni || j < 1 || j >= nj || k + koff < 0 || k + koff >= nkg) return;
     const size_t c0 = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k), c1 = c0 - ni;
     float d0 = rho[c0], T0 = T[c0], d1 = rho[c1], T1 = T[c1];
     float f = (float)(0.5 * (double)dt * (double)(beta * (T0 + T1) - alpha * (d0 + d1)));
@@ -77,12 +82,16 @@ __global__ __launch_bounds__(256) void mad_kernel(float *out, const float *f1, c
 }
 
 // MapperBaseGPU::init host loop (Mapping.cpp:310-324) on the device
-__global__ __launch_bounds__(256) void init_maps_kernel(float *x, float *y, float *z, float h, int ni, int nj, int nk)
+__global__ __launch_bounds__(256) void init_maps_kernel(float *x, float *y, float *z, float h, int ni, int nj, int nk,
+                                                        int koff, int nkg)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (i >= ni || j >= nj) return;
     size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
-    x[id] = (float)i * h; y[id] = (float)j * h; z[id] = (float)k * h;
+    const int kg = k + koff;
+    // ghost planes outside the global grid stay 0: that is what a read outside the allocation returns
+    const bool in = kg >= 0 && kg < nkg;
+    x[id] = in ? (float)i * h : 0.f; y[id] = in ? (float)j * h : 0.f; z[id] = in ? (float)kg * h : 0.f;
 }
 
 // getCFL (BimocqGPUSolver.cpp:348-373) as a wave64 max-reduction over the three components
@@ -117,6 +126,14 @@ __global__ __launch_bounds__(256) void max_final_kernel(const float *__restrict_
     }
 }
 
+// slab context of the library: (koff, nkg); single GPU: (0, nk)
+static inline void slab_ctx(int nk, int &koff, int &nkg)
+{
+    const Runtime &r = rt();
+    koff = r.slab_on ? r.slab_koff : 0;
+    nkg = r.slab_on ? r.slab_nkg : nk;
+}
+
 static inline int stream_blocks(size_t n)
 {
     size_t b = (n + 255) / 256;
@@ -135,10 +152,12 @@ void gpu_emit_smoke(float *u, float *v, float *w, float *rho, float *T, float h,
     if (!ensure_ready("gpu_emit_smoke")) return;
     BQ_REQUIRE(u && v && w && rho && T && ni > 0 && nj > 0 && nk > 0 && nk < 65535, "gpu_emit_smoke");
     hipStream_t st = rt().compute;
-    emit_velocity_kernel<<<grid3(ni + 1, nj, nk), kBlock3, 0, st>>>(u, h, ni + 1, nj, nk, centerX, centerY, centerZ, radius, emiter);
-    emit_velocity_kernel<<<grid3(ni, nj + 1, nk), kBlock3, 0, st>>>(v, h, ni, nj + 1, nk, centerX, centerY, centerZ, radius, 0.f);
-    emit_velocity_kernel<<<grid3(ni, nj, nk + 1), kBlock3, 0, st>>>(w, h, ni, nj, nk + 1, centerX, centerY, centerZ, radius, 0.f);
-    emit_field_kernel<<<grid3(ni, nj, nk), kBlock3, 0, st>>>(rho, T, h, ni, nj, nk, centerX, centerY, centerZ, radius, density, temperature);
+    int koff, nkg;
+    slab_ctx(nk, koff, nkg);
+    emit_velocity_kernel<<<grid3(ni + 1, nj, nk), kBlock3, 0, st>>>(u, h, ni + 1, nj, nk, centerX, centerY, centerZ, radius, emiter, koff, nkg);
+    emit_velocity_kernel<<<grid3(ni, nj + 1, nk), kBlock3, 0, st>>>(v, h, ni, nj + 1, nk, centerX, centerY, centerZ, radius, 0.f, koff, nkg);
+    emit_velocity_kernel<<<grid3(ni, nj, nk + 1), kBlock3, 0, st>>>(w, h, ni, nj, nk + 1, centerX, centerY, centerZ, radius, 0.f, koff, nkg + 1);
+    emit_field_kernel<<<grid3(ni, nj, nk), kBlock3, 0, st>>>(rho, T, h, ni, nj, nk, centerX, centerY, centerZ, radius, density, temperature, koff, nkg);
     BQ_LAUNCH_CHECK("gpu_emit_smoke");
 }
 
@@ -146,7 +165,9 @@ void gpu_add_buoyancy(float *field, float *density, float *temperature, int ni, 
 {
     if (!ensure_ready("gpu_add_buoyancy")) return;
     BQ_REQUIRE(field && density && temperature && ni > 0 && nj > 0 && nk > 0 && nk < 65535, "gpu_add_buoyancy");
-    buoyancy_kernel<<<grid3(ni, nj, nk), kBlock3, 0, rt().compute>>>(field, density, temperature, ni, nj, nk, alpha, beta, dt);
+    int koff, nkg;
+    slab_ctx(nk, koff, nkg);
+    buoyancy_kernel<<<grid3(ni, nj, nk), kBlock3, 0, rt().compute>>>(field, density, temperature, ni, nj, nk, alpha, beta, dt, koff, nkg);
     BQ_LAUNCH_CHECK("buoyancy_kernel");
 }
 
@@ -186,7 +207,9 @@ void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk
 {
     if (!ensure_ready("gpu_init_maps")) return;
     BQ_REQUIRE(x && y && z && ni > 0 && nj > 0 && nk > 0 && nk < 65535, "gpu_init_maps");
-    init_maps_kernel<<<grid3(ni, nj, nk), kBlock3, 0, rt().compute>>>(x, y, z, h, ni, nj, nk);
+    int koff, nkg;
+    slab_ctx(nk, koff, nkg);
+    init_maps_kernel<<<grid3(ni, nj, nk), kBlock3, 0, rt().compute>>>(x, y, z, h, ni, nj, nk, koff, nkg);
     BQ_LAUNCH_CHECK("init_maps_kernel");
 }
 
@@ -199,10 +222,17 @@ float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int n
     float *host = (float *)pinned(64);
     if (!part || !host) return 0.f;
     hipStream_t st = rt().compute;
-    const size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
-    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(u, nu, v, nv, w, nw, part);
+    // a slab rank reduces the planes it owns (ghost copies may be stale); the last rank also owns w's top plane
+    const Runtime &r = rt();
+    const int p0 = r.slab_on ? r.slab_own0 - r.slab_koff : 0;
+    const int p1 = r.slab_on ? r.slab_own1 - r.slab_koff : nk;
+    const int wtop = (!r.slab_on || r.slab_own1 == r.slab_nkg) ? 1 : 0;
+    const size_t pu = (size_t)(ni + 1) * nj, pv = (size_t)ni * (nj + 1), pw = (size_t)ni * nj;
+    const size_t nu = pu * (p1 - p0), nv = pv * (p1 - p0), nw = pw * (p1 - p0 + wtop);
+    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(u + pu * p0, nu, v + pv * p0, nv, w + pw * p0, nw, part);
     max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 1e-4f, part + blocks);
     BQ_LAUNCH_CHECK("max_abs3");
+    comm_allreduce(part + blocks, 1, false, true, st);        // global CFL over the slab ranks
     BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     return host[0];

@@ -12,13 +12,17 @@
 
 namespace bq {
 
+// z-slab context of a launch: local plane k is global plane k + koff; nkg = global cell planes.
+struct Slab { int koff, nkg; };
+
 // ---- divergence_kernel (GPU_kernel.cu:967-985) --------------------------------------------
 __global__ __launch_bounds__(256) void divergence_kernel(const float *__restrict__ u, const float *__restrict__ v,
                                                          const float *__restrict__ w, float *__restrict__ div,
-                                                         int ni, int nj, int nk, float halfrdx)
+                                                         int ni, int nj, int nk, float halfrdx, Slab sl)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= ni || j >= nj) return;
+    const int kg = k + sl.koff;
+    if (i >= ni || j >= nj || kg < 0 || kg >= sl.nkg) return;
     const size_t iu = (size_t)i + (size_t)(ni + 1) * ((size_t)j + (size_t)nj * k);
     const size_t iv = (size_t)i + (size_t)ni * ((size_t)j + (size_t)(nj + 1) * k);
     const size_t ic = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
@@ -31,10 +35,11 @@ __global__ __launch_bounds__(256) void divergence_kernel(const float *__restrict
 // ---- gradient_kernel x3 fused (GPU_kernel.cu:1024-1041, launches :1881-1891) -------------
 // All three components update the same cell window 2..n-1, so one pass reads p once.
 __global__ __launch_bounds__(256) void gradient_kernel(float *__restrict__ u, float *__restrict__ v, float *__restrict__ w,
-                                                       const float *__restrict__ p, int ni, int nj, int nk, float halfrdx)
+                                                       const float *__restrict__ p, int ni, int nj, int nk, float halfrdx, Slab sl)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i < 2 || i >= ni || j < 2 || j >= nj || k < 2) return;
+    const int kg = k + sl.koff;
+    if (i < 2 || i >= ni || j < 2 || j >= nj || kg < 2 || kg >= sl.nkg || k < 1) return;
     const size_t ic = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
     const float p0 = p[ic];
     const size_t iu = (size_t)i + (size_t)(ni + 1) * ((size_t)j + (size_t)nj * k);
@@ -47,10 +52,11 @@ __global__ __launch_bounds__(256) void gradient_kernel(float *__restrict__ u, fl
 // ---- generic Jacobi sweep: any dims, one thread per cell (GPU_kernel.cu:1819-1837) --------
 __global__ __launch_bounds__(256) void jacobi_generic_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                              float *__restrict__ out, int ni, int nj, int nk,
-                                                             float alpha, float beta)
+                                                             float alpha, float beta, Slab sl)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1)) return;
+    const int kg = k + sl.koff;
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1 && kg > 0 && kg < sl.nkg - 1)) return;
     const size_t sj = ni, sk = (size_t)ni * nj;
     const size_t id = (size_t)i + sj * j + sk * k;
     out[id] = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk] + alpha * div[id]) * beta;
@@ -75,7 +81,7 @@ struct JTile {
 template <int TXV, int R>
 __global__ __launch_bounds__(256) void jacobi_tile_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                           float *__restrict__ out, int nx, int ny, int nz,
-                                                          int kchunk, float alpha, float beta)
+                                                          int kchunk, float alpha, float beta, Slab sl)
 {
     using T = JTile<TXV, R>;
     __shared__ __attribute__((aligned(16))) float lds[2][T::PLANE];
@@ -83,8 +89,9 @@ __global__ __launch_bounds__(256) void jacobi_tile_kernel(const float *__restric
     const int tid = threadIdx.x;
     const int lx = tid % TXV, rp = tid / TXV;
     const int x0 = blockIdx.x * T::TX, j0 = blockIdx.y * T::TY;
-    const int kbeg = max(1, (int)blockIdx.z * kchunk);
-    const int kend = min(nz - 1, (int)blockIdx.z * kchunk + kchunk);
+    // local planes 1..nz-2 that are interior planes of the GLOBAL grid
+    const int kbeg = max(max(1, 1 - sl.koff), (int)blockIdx.z * kchunk);
+    const int kend = min(min(nz - 1, sl.nkg - 1 - sl.koff), (int)blockIdx.z * kchunk + kchunk);
     if (kbeg >= kend) return;
 
     const int x = x0 + 4 * lx;                  // first column of this thread's float4 (nx % 4 == 0)
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256) void jacobi_tile_kernel(const float *__restric
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                   float *__restrict__ out, int nx, int ny, int nz,
-                                                                  int cw, int nbx, int nby, int kchunk, float alpha, float beta)
+                                                                  int cw, int nbx, int nby, int kchunk, float alpha, float beta, Slab sl)
 {
     // XCD-aware block order: blocks b and b+8 share an XCD (its L2); give each XCD a contiguous run
     // of (k-chunk, row-block) pairs so halo rows/planes are re-read from the same L2.
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
     const int rows = (WAVES * 64) / cw;             // rows of the tile (cw float4 columns each)
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
     const int x = (bx * cw + c) * 4, j = by * rows + r;
-    const int kbeg = max(1, bz * kchunk), kend = min(nz - 1, bz * kchunk + kchunk);
+    const int kbeg = max(max(1, 1 - sl.koff), bz * kchunk), kend = min(min(nz - 1, sl.nkg - 1 - sl.koff), bz * kchunk + kchunk);
     if (kbeg >= kend) return;
     const bool active = x < nx && j >= 1 && j <= ny - 2;
     const size_t sj = nx, sk = (size_t)nx * ny;
@@ -272,7 +279,8 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 // the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
 __global__ __launch_bounds__(256) void residual_partial_kernel(const float *__restrict__ div, const float *__restrict__ p,
                                                                int ni, int nj, int nk,
-                                                               double *__restrict__ part_sum, float *__restrict__ part_max)
+                                                               double *__restrict__ part_sum, float *__restrict__ part_max,
+                                                               Slab sl, int own0, int own1)
 {
     const size_t sj = ni, sk = (size_t)ni * nj;
     const size_t total = sk * nk;
@@ -280,7 +288,8 @@ __global__ __launch_bounds__(256) void residual_partial_kernel(const float *__re
     float mx = 0.f;
     for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
         const int i = (int)(id % sj), j = (int)((id / sj) % nj), k = (int)(id / sk);
-        if (i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1) {
+        const int kg = k + sl.koff;
+        if (i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && kg > 0 && kg < sl.nkg - 1 && kg >= own0 && kg < own1 && k > 0 && k < nk - 1) {
             float ax = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk]) - p[id] * 6;
             float r = div[id] - ax;
             s += (double)r * (double)r;
@@ -326,10 +335,12 @@ __global__ __launch_bounds__(256) void residual_final_kernel(const double *__res
 
 // ---- diffuse_field_kernel (GPU_kernel.cu:834-853) ------------------------------------------
 __global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ field, const float *__restrict__ in,
-                                                      float *__restrict__ out, int ni, int nj, int nk, float coef)
+                                                      float *__restrict__ out, int ni, int nj, int nk, float coef,
+                                                      int koff, int nkg)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1)) return;
+    const int kg = k + koff;                    // nkg: GLOBAL plane count of this buffer
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1 && kg > 0 && kg < nkg - 1)) return;
     const size_t sj = ni, sk = (size_t)ni * nj;
     const size_t id = (size_t)i + sj * j + sk * k;
     float s = in[id - 1] + in[id + 1] + in[id - sj] + in[id + sj] + in[id - sk] + in[id + sk];
@@ -348,6 +359,13 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
     return true;
 }
 
+static inline Slab slab_of(int nk)
+{
+    const Runtime &r = rt();
+    if (r.slab_on) return Slab{r.slab_koff, r.slab_nkg};
+    return Slab{0, nk};
+}
+
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 // One Jacobi sweep in -> out on the compute stream.
@@ -360,7 +378,7 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
     if (variant != 1 && !tile_ok) variant = 1;
     hipStream_t st = rt().compute;
     if (variant == 1) {
-        jacobi_generic_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(in, div, out, ni, nj, nk, alpha, beta);
+        jacobi_generic_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(in, div, out, ni, nj, nk, alpha, beta, slab_of(nk));
         BQ_LAUNCH_CHECK("jacobi_generic_kernel");
         return;
     }
@@ -380,7 +398,7 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
         if (rt().opt_jacobi_kchunk > 0) kchunk = rt().opt_jacobi_kchunk;
         const int nbz = (nk + kchunk - 1) / kchunk;
         const int nblk = nbx * nby * nbz;
-#define BQ_JM(W) jacobi_march_kernel<W><<<nblk, W * 64, 0, st>>>(in, div, out, ni, nj, nk, cw, nbx, nby, kchunk, alpha, beta)
+#define BQ_JM(W) jacobi_march_kernel<W><<<nblk, W * 64, 0, st>>>(in, div, out, ni, nj, nk, cw, nbx, nby, kchunk, alpha, beta, slab_of(nk))
         if (waves == 4) BQ_JM(4); else if (waves == 8) BQ_JM(8); else BQ_JM(16);
 #undef BQ_JM
         BQ_LAUNCH_CHECK("jacobi_march_kernel");
@@ -399,7 +417,7 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
     if (rt().opt_jacobi_kchunk > 0) kchunk = rt().opt_jacobi_kchunk;
     const int bz = (nk + kchunk - 1) / kchunk;
     dim3 grid(bx, by, bz);
-#define BQ_JT(TXV, RR) jacobi_tile_kernel<TXV, RR><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta)
+#define BQ_JT(TXV, RR) jacobi_tile_kernel<TXV, RR><<<grid, 256, 0, st>>>(in, div, out, ni, nj, nk, kchunk, alpha, beta, slab_of(nk))
     if (wide) { if (R == 4) BQ_JT(64, 4); else if (R == 2) BQ_JT(64, 2); else BQ_JT(64, 1); }
     else      { if (R == 4) BQ_JT(32, 4); else if (R == 2) BQ_JT(32, 2); else BQ_JT(32, 1); }
 #undef BQ_JT
@@ -416,10 +434,20 @@ static void residual_norms_async(const float *div, const float *p, int ni, int n
     double *ps = (double *)ws;
     float *pm = (float *)(ws + kResidualBlocks * sizeof(double));
     hipStream_t st = rt().compute;
-    residual_partial_kernel<<<kResidualBlocks, 256, 0, st>>>(div, p, ni, nj, nk, ps, pm);
+    {
+        const Runtime &r = rt();
+        const int own0 = r.slab_on ? r.slab_own0 : 0, own1 = r.slab_on ? r.slab_own1 : nk;
+        residual_partial_kernel<<<kResidualBlocks, 256, 0, st>>>(div, p, ni, nj, nk, ps, pm, slab_of(nk), own0, own1);
+    }
     BQ_LAUNCH_CHECK("residual_partial_kernel");
     residual_final_kernel<<<1, 256, 0, st>>>(ps, pm, kResidualBlocks, d_sum, d_max, dbg_sum, dbg_max);
     BQ_LAUNCH_CHECK("residual_final_kernel");
+    if (comm_ranks() > 1) {                     // owned-plane partials -> global norms
+        if (d_sum) comm_allreduce(d_sum, 1, true, false, st);
+        if (d_max) comm_allreduce(d_max, 1, false, true, st);
+        if (dbg_sum) comm_allreduce(dbg_sum, 1, false, false, st);
+        if (dbg_max) comm_allreduce(dbg_max, 1, false, true, st);
+    }
 }
 
 // hipEvent pairs around the sweep loops of gpu_projection_jacobi (FL_OPT_PROFILE_JACOBI):
@@ -445,7 +473,7 @@ extern "C" {
 void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float halfrdx)
 {
     BQ_ENTER("gpu_divergence", u, v, w, div)
-    divergence_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, div, ni, nj, nk, halfrdx);
+    divergence_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, div, ni, nj, nk, halfrdx, slab_of(nk));
     BQ_LAUNCH_CHECK("divergence_kernel");
 }
 
@@ -465,7 +493,7 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *p_temp, int ni, int nj,
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float halfrdx)
 {
     BQ_ENTER("gpu_gradient", u, v, w, p)
-    gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, p, ni, nj, nk, halfrdx);
+    gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, p, ni, nj, nk, halfrdx, slab_of(nk));
     BQ_LAUNCH_CHECK("gradient_kernel");
 }
 
@@ -492,7 +520,7 @@ void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
     BQ_ENTER("gpu_projection_jacobi", u, v, w, div, p, p_temp)
     BQ_REQUIRE(p != p_temp && iter >= 0, "gpu_projection_jacobi");
     hipStream_t st = rt().compute;
-    divergence_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(u, v, w, div, ni, nj, nk, halfrdx);
+    divergence_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(u, v, w, div, ni, nj, nk, halfrdx, slab_of(nk));
     BQ_LAUNCH_CHECK("divergence_kernel");
     const int stride = rt().opt_residual_stride;
     const bool dbg = debugParam != nullptr && stride > 0;
@@ -510,7 +538,7 @@ void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
     if (dbg && iter > 0 && (iter - 1) % stride == 0 && iter - 1 < 2000)
         residual_norms_async(div, in, ni, nj, nk, nullptr, nullptr, debugParam + iter - 1, debugParam + 2000 + iter - 1);
     if (in != p) fl_memcpy_d2d(p, in, (size_t)ni * nj * nk * sizeof(float));
-    gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(u, v, w, p, ni, nj, nk, halfrdx);
+    gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, st>>>(u, v, w, p, ni, nj, nk, halfrdx, slab_of(nk));
     BQ_LAUNCH_CHECK("gradient_kernel");
 }
 
@@ -537,9 +565,12 @@ void gpu_diffuse_field(float *field, float *fieldTemp0, float *filedTemp1, int n
     BQ_REQUIRE(field != fieldTemp0 && field != filedTemp1 && fieldTemp0 != filedTemp1 && iter >= 0, "gpu_diffuse_field");
     const size_t bytes = (size_t)ni * nj * nk * sizeof(float);
     float *in = fieldTemp0, *out = filedTemp1;
+    // nk is a BUFFER dim here (nk+1 for w); the slab context carries cell planes: keep the difference
+    Slab dsl = slab_of(nk);
+    if (rt().slab_on) dsl.nkg += nk - rt().slab_nkl;
     fl_memcpy_d2d(in, field, bytes);
     for (int it = 0; it < iter; it++) {
-        diffuse_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(field, in, out, ni, nj, nk, coef);
+        diffuse_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(field, in, out, ni, nj, nk, coef, dsl.koff, dsl.nkg);
         BQ_LAUNCH_CHECK("diffuse_kernel");
         float *t = out; out = in; in = t;
     }

@@ -185,6 +185,7 @@ void fl_event_destroy(void *ev)
 int fl_last_error(void) { return g_rt.err; }
 const char *fl_last_error_string(void) { return g_rt.err == FL_OK ? "" : g_rt.err_text; }
 void fl_clear_error(void) { g_rt.err = FL_OK; g_rt.err_text[0] = 0; }
+void fl_report_error(int code, const char *text) { bq::latch(code, "host", text ? text : ""); }
 void *fl_compute_stream(void) { return bq::ensure_ready("fl_compute_stream") ? (void *)g_rt.compute : nullptr; }
 
 void fl_set_option(int option, int value)

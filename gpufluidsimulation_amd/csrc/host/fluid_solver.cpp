@@ -6,31 +6,84 @@
 // place of copies whose source is dead).  Everything else -- including the reference's quirks that
 // DO change values -- is kept, and tests/ checks the trajectory against
 // the CPU oracle bit for bit.
+//
+// z-slab ranks run the same code: gpuMapper::require()/produced() keep track of how many ghost
+// planes of every field are correct and exchange them with the z-neighbours exactly when an operator
+// reaches further than that (no-ops on a single GPU).
 #include "fluid_solver.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 namespace bqhost {
+
+// BQ_TRACE=1 (debug): after each stage print the sum of squares of the planes this rank owns, so a
+// slab run can be compared stage by stage with a single-GPU run (sum the ranks' lines).
+static void trace_stage(BimocqGPUSolver &s, const char *stage, int frame)
+{
+    static const bool on = getenv("BQ_TRACE") && atoi(getenv("BQ_TRACE")) != 0;
+    if (!on) return;
+    const SlabCtx &sl = s.GpuSolver->slab;
+    const int G = sl.on ? sl.G : 0, own = sl.on ? sl.own1 - sl.own0 : s.g.nk;
+    const bool top = !sl.on || sl.own1 == sl.nkg;
+    struct Item { const char *name; DeviceField *f; } items[] = {
+        { "U", &s.VelocityU }, { "V", &s.VelocityV }, { "W", &s.VelocityW }, { "Ui", &s.VelocityUInit }, { "Wi", &s.VelocityWInit },
+        { "rho", &s.Density }, { "bz", &s.VelocityAdvector.maps->BackwardZ }, { "fz", &s.VelocityAdvector.maps->ForwardZ },
+        { "dUp", &s.duProj }, { "dWp", &s.dwProj }, { "p", &s.p }, { "div", &s.div },
+        { "bx", &s.VelocityAdvector.maps->BackwardX }, { "by", &s.VelocityAdvector.maps->BackwardY },
+        { "fx", &s.VelocityAdvector.maps->ForwardX }, { "usrc", &s.GpuSolver->u_src }, { "vsrc", &s.GpuSolver->v_src }, { "wsrc", &s.GpuSolver->w_src } };
+    std::vector<float> host;
+    char fname[128];
+    snprintf(fname, sizeof fname, "/tmp/bqtrace_%dof%d.txt", sl.rank, sl.nranks);
+    FILE *fo = fopen(fname, "a");
+    if (!fo) return;
+    fprintf(fo, "[trace r%d f%d %-14s]", sl.rank, frame, stage);
+    for (const Item &it : items) {
+        host.resize(it.f->count());
+        it.f->download(host.data());
+        const size_t pe = it.f->plane ? it.f->plane : (size_t)s.g.ni * s.g.nj;
+        const size_t lo = pe * (size_t)G, hi = pe * (size_t)(G + own + ((it.f->extra && top) ? 1 : 0));
+        double acc = 0;
+        for (size_t a = lo; a < hi && a < host.size(); a++) acc += (double)host[a] * (double)host[a];
+        fprintf(fo, " %s=%.17g", it.name, acc);
+    }
+    fprintf(fo, "\n");
+    fclose(fo);
+    const char *dump = getenv("BQ_DUMP");
+    if (dump && frame == 1 && strcmp(dump, stage) == 0) {
+        for (const Item &it : items) {
+            host.resize(it.f->count());
+            it.f->download(host.data());
+            snprintf(fname, sizeof fname, "/tmp/bqdump_%dof%d_%s.bin", sl.rank, sl.nranks, it.name);
+            FILE *fd = fopen(fname, "wb");
+            if (fd) { fwrite(host.data(), sizeof(float), host.size(), fd); fclose(fd); }
+        }
+    }
+}
 
 BimocqGPUSolver::BimocqGPUSolver(unsigned nx, unsigned ny, unsigned nz, float L, float vis_coeff, float blend_coeff,
                                  Scheme inScheme, gpuMapper *mymapper)
     : myscheme(inScheme), GpuSolver(mymapper)
 {
-    g.ni = (int)nx; g.nj = (int)ny; g.nk = (int)nz;
     CellSize = L / nx;                                   // :10
-    g.h = CellSize;
     Viscosity = vis_coeff;
+    (void)ny; (void)nz;
     if (!mymapper || !mymapper->ok()) return;
+    g = mymapper->g;                                     // local dims (a slab rank holds owned + ghost planes)
+    g.h = CellSize;
 
     DeviceField *ub[] = { &VelocityU, &VelocityUInit, &VelocityUPrev, &VelocityUTemp, &duProj, &duExtern, &TempSrcU };
     DeviceField *vb[] = { &VelocityV, &VelocityVInit, &VelocityVPrev, &VelocityVTemp, &dvProj, &dvExtern, &TempSrcV };
     DeviceField *wb[] = { &VelocityW, &VelocityWInit, &VelocityWPrev, &VelocityWTemp, &dwProj, &dwExtern, &TempSrcW };
     for (int a = 0; a < 7; a++)
-        if (!ub[a]->alloc(g.nu()) || !vb[a]->alloc(g.nv()) || !wb[a]->alloc(g.nw())) return;
+        if (!mymapper->allocField(*ub[a], FIELD_U) || !mymapper->allocField(*vb[a], FIELD_V) || !mymapper->allocField(*wb[a], FIELD_W)) return;
     DeviceField *sb[] = { &Density, &DensityInit, &DensityPrev, &Temperature, &TemperatureInit, &TemperaturePrev,
                           &div, &p, &p_temp };
     for (DeviceField *f : sb)
-        if (!f->alloc(g.n())) return;
+        if (!mymapper->allocField(*f, FIELD_S)) return;
     if (!debugParam.alloc(4096)) return;
 
     if (!VelocityAdvector.init(g.ni, g.nj, g.nk, CellSize, blend_coeff, mymapper)) return;      // :92
@@ -66,14 +119,15 @@ void BimocqGPUSolver::advance(int framenum, float dt)
 }
 
 // :348-373.  The reference scans host copies that outputResult() refreshed after the previous
-// frame; the same numbers are on the device at this point, so reduce them there.
+// frame; the same numbers are on the device at this point, so reduce them there (slab ranks reduce
+// their owned planes and all-reduce the maximum).
 float BimocqGPUSolver::getCFL()
 {
     MaxVelocity = gpu_max_abs3(VelocityU, VelocityV, VelocityW, g.ni, g.nj, g.nk);    // includes the 1e-4 floor
     return CellSize / MaxVelocity;
 }
 
-// :376-392 with the hard-coded scene constants replaced by the emitter list
+// :376-392 with the hard-coded scene constants replaced by the emitter list (pointwise in z)
 void BimocqGPUSolver::emitSmoke(int framenum, float /*dt*/)
 {
     for (const Emitter &e : sim_emitter)
@@ -82,10 +136,11 @@ void BimocqGPUSolver::emitSmoke(int framenum, float /*dt*/)
                                  e.e_pos[0], e.e_pos[1], e.e_pos[2], e.radius, e.emit_density, e.emit_temperature, e.emiter);
 }
 
-// :394-397
+// :394-397 (reads rho/T at j and j-1 of the same plane: no reach along z)
 void BimocqGPUSolver::addBuoyancy(float dt)
 {
     GpuSolver->add_buoyancy(VelocityV, Density, Temperature, _alpha, _beta, dt);
+    GpuSolver->produced(VelocityV, gpuMapper::minValid({ &VelocityV, &Density, &Temperature }));
 }
 
 // :399-404
@@ -98,8 +153,41 @@ void BimocqGPUSolver::diffuseField(float *field, float *t0, float *t1, int ni, i
 // :406-467, the Jacobi branch (:409-410): alpha = -1, beta = 1/6
 void BimocqGPUSolver::projection()
 {
-    GpuSolver->projectionJacobi(VelocityU, VelocityV, VelocityW, div, p, p_temp, debugParam,
-                                jacobi_iters, halfrdx, -1.f, (float)(1.0 / 6.0));
+    gpuMapper &gs = *GpuSolver;
+    const float alpha = -1.f, beta = (float)(1.0 / 6.0);
+    if (!gs.slab.on || gs.slab.nranks <= 1) {
+        gs.projectionJacobi(VelocityU, VelocityV, VelocityW, div, p, p_temp, debugParam, jacobi_iters, halfrdx, alpha, beta);
+        return;
+    }
+    // z-slab form of gpu_projection_jacobi (GPU_kernel.cu:1839-1895): same three kernels, with the
+    // sweeps issued in chunks of G: one exchange of G ghost planes of p buys G sweeps, because each
+    // sweep shrinks the correct ghost depth by one plane (the ghost planes are swept redundantly,
+    // which yields the very values the neighbour computes).
+    const int G = gs.slab.G;
+    gs.require({ &VelocityU, &VelocityV, &VelocityW }, G);
+    div.zero(); p.zero(); p_temp.zero();                                 // GPU_Advection.h:604-606
+    gpu_divergence(VelocityU, VelocityV, VelocityW, div, g.ni, g.nj, g.nk, halfrdx);
+    gs.produced(div, std::min({ VelocityU.valid, VelocityV.valid, VelocityW.valid - 1 }));
+    DeviceField *cur = &p, *oth = &p_temp;
+    gs.produced(*cur, G);                                                // zeros everywhere
+    int left = jacobi_iters - 1;                                         // iterate iter-1 is applied
+    while (left > 0) {
+        const int chunk = std::min(left, G);
+        gs.require({ cur }, chunk);
+        const int where = gpu_jacobi_sweeps(*cur, div, *oth, g.ni, g.nj, g.nk, chunk, alpha, beta);
+        int v = cur->valid;
+        for (int s = 0; s < chunk; s++) v = std::min(v - 1, div.valid);     // each sweep reaches one plane
+        if (where) std::swap(cur, oth);
+        gs.produced(*cur, v);
+        gs.produced(*oth, 0);
+        left -= chunk;
+    }
+    if (cur != &p) p.copy_from(*cur);
+    gs.require({ &p }, 1);
+    gpu_gradient(VelocityU, VelocityV, VelocityW, p, g.ni, g.nj, g.nk, halfrdx);
+    gs.produced(VelocityU, std::min(VelocityU.valid, p.valid));
+    gs.produced(VelocityV, std::min(VelocityV.valid, p.valid));
+    gs.produced(VelocityW, std::min(VelocityW.valid, p.valid - 1));
 }
 
 // :503-516.  UPrev <- UInit by swap (UInit is refilled right after), UInit <- U by copy.
@@ -116,23 +204,33 @@ void BimocqGPUSolver::scalarReinitialize()
     DensityInit.copy_from(Density); TemperatureInit.copy_from(Temperature);
 }
 
+static BimocqGPUSolver *g_trace_solver = nullptr;
+static int g_trace_frame = 0;
+static void trace_hook_fn(const char *stage) { if (g_trace_solver) trace_stage(*g_trace_solver, stage, g_trace_frame); }
+
 // :129-230
 void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
 {
+    gpuMapper &gs = *GpuSolver;
+    g_trace_solver = this; g_trace_frame = framenum; g_trace_hook = trace_hook_fn;
     if (framenum == 0) MaxVelocity = CellSize;           // :131 (overwritten by getCFL, kept for the record)
     float proj_coeff = 2.f;
     const float cfldt = getCFL();                        // :136
     last_cfldt = cfldt;
+    // how many cells anything can travel this step (bounds the reach of the gather kernels on slab ranks)
+    const int dcells = (int)std::ceil((double)dt * (double)MaxVelocity / (double)CellSize) + 1;
 
     // :138-139.  One update serves both advectors (shared map set).
-    VelocityAdvector.updateMapping(VelocityU, VelocityV, VelocityW, cfldt, dt);
-    if (!ScalarAdvector.sharesMaps()) ScalarAdvector.updateMapping(VelocityU, VelocityV, VelocityW, cfldt, dt);
+    VelocityAdvector.updateMapping(VelocityU, VelocityV, VelocityW, cfldt, dt, dcells);
+    if (!ScalarAdvector.sharesMaps()) ScalarAdvector.updateMapping(VelocityU, VelocityV, VelocityW, cfldt, dt, dcells);
+    trace_stage(*this, "maps", framenum);
 
     // :143-145
     VelocityAdvector.advectVelocity(VelocityU, VelocityV, VelocityW, VelocityUInit, VelocityVInit, VelocityWInit,
                                     VelocityUPrev, VelocityVPrev, VelocityWPrev);
     ScalarAdvector.advectField(Density, DensityInit, DensityPrev);
     ScalarAdvector.advectField(Temperature, TemperatureInit, TemperaturePrev);
+    trace_stage(*this, "advect", framenum);
 
     // :157-159
     VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
@@ -141,25 +239,37 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     addBuoyancy(dt);                                     // :165
 
     if (Viscosity) {                                     // :167-172, with the reference's buffer aliasing
+        if (gs.slab.on && gs.slab.nranks > 1) {
+            fl_report_error(FL_ERR_UNSUPPORTED, "viscous diffusion sweeps on z-slabs are not built yet (nu must be 0)");
+            return;
+        }
         diffuseField(VelocityU, VelocityUTemp, TempSrcU, g.ni + 1, g.nj, g.nk, 20, Viscosity, dt);
         diffuseField(VelocityV, VelocityVTemp, TempSrcV, g.ni, g.nj + 1, g.nk, 20, Viscosity, dt);
         diffuseField(VelocityW, VelocityWTemp, TempSrcW, g.ni, g.nj, g.nk + 1, 20, Viscosity, dt);
     }
 
     // :175-177 velocity change due to external forces
-    GpuSolver->addFields(duExtern, VelocityU, VelocityUTemp, -1.f, g.nu());
-    GpuSolver->addFields(dvExtern, VelocityV, VelocityVTemp, -1.f, g.nv());
-    GpuSolver->addFields(dwExtern, VelocityW, VelocityWTemp, -1.f, g.nw());
+    gs.addFields(duExtern, VelocityU, VelocityUTemp, -1.f, g.nu());
+    gs.addFields(dvExtern, VelocityV, VelocityVTemp, -1.f, g.nv());
+    gs.addFields(dwExtern, VelocityW, VelocityWTemp, -1.f, g.nw());
+    gs.produced(duExtern, std::min(VelocityU.valid, VelocityUTemp.valid));
+    gs.produced(dvExtern, std::min(VelocityV.valid, VelocityVTemp.valid));
+    gs.produced(dwExtern, std::min(VelocityW.valid, VelocityWTemp.valid));
     // :179-181
     VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
 
+    trace_stage(*this, "forces", framenum);
     projection();                                        // :183
+    trace_stage(*this, "projection", framenum);
 
     // :188-193 dProj = U - UTemp.  The reference copies U into dProj and then adds -1*UTemp in
     // place; out = U + (-1)*UTemp is the same expression in one pass.
-    GpuSolver->addFields(duProj, VelocityU, VelocityUTemp, -1.f, g.nu());
-    GpuSolver->addFields(dvProj, VelocityV, VelocityVTemp, -1.f, g.nv());
-    GpuSolver->addFields(dwProj, VelocityW, VelocityWTemp, -1.f, g.nw());
+    gs.addFields(duProj, VelocityU, VelocityUTemp, -1.f, g.nu());
+    gs.addFields(dvProj, VelocityV, VelocityVTemp, -1.f, g.nv());
+    gs.addFields(dwProj, VelocityW, VelocityWTemp, -1.f, g.nw());
+    gs.produced(duProj, std::min(VelocityU.valid, VelocityUTemp.valid));
+    gs.produced(dvProj, std::min(VelocityV.valid, VelocityVTemp.valid));
+    gs.produced(dwProj, std::min(VelocityW.valid, VelocityWTemp.valid));
     // :185-186,195-198: DensityExtern = Density - DensityTemp right after DensityTemp <- Density is
     // identically zero, and accumulating a zero field (:215-216) adds 0: not executed.
 
@@ -174,6 +284,7 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     // :213-214
     VelocityAdvector.accumulateVelocity(VelocityUInit, VelocityVInit, VelocityWInit, duExtern, dvExtern, dwExtern, 1.f);
     VelocityAdvector.accumulateVelocity(VelocityUInit, VelocityVInit, VelocityWInit, duProj, dvProj, dwProj, proj_coeff);
+    trace_stage(*this, "accumulate", framenum);
 
     // :218-223 `if (1)`: re-initialise every frame
     VelocityAdvector.reinitializeMapping();
@@ -184,9 +295,10 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     if (ScalarAdvector.sharesMaps()) ScalarAdvector.noteSharedReinit();
     else ScalarAdvector.reinitializeMapping();
     scalarReinitialize();
+    trace_stage(*this, "reinit", framenum);
 }
 
-// :536-543
+// :536-543.  A slab rank downloads its local planes and writes the planes it owns.
 long BimocqGPUSolver::outputResult(unsigned frame, const std::string &filepath)
 {
     Density.download(host_density.data());
@@ -195,7 +307,12 @@ long BimocqGPUSolver::outputResult(unsigned frame, const std::string &filepath)
     VelocityW.download(host_w.data());
     if (fl_last_error() != FL_OK) return -1;
     if (filepath.empty()) return 0;
-    return write_density_dump(frame + 1, filepath, CellSize, host_density.data(), g.ni, g.nj, g.nk, 0, g.nk);
+    const SlabCtx &sl = GpuSolver->slab;
+    if (!sl.on)
+        return write_density_dump(frame + 1, filepath, CellSize, host_density.data(), g.ni, g.nj, g.nk, 0, g.nk);
+    const size_t plane = (size_t)g.ni * g.nj;
+    return write_density_dump(frame + 1, filepath, CellSize, host_density.data() + plane * sl.G, g.ni, g.nj,
+                              sl.own1 - sl.own0, sl.own0, sl.nkg);
 }
 
 } // namespace bqhost

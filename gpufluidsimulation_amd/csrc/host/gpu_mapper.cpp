@@ -1,15 +1,52 @@
 // gpu_mapper.cpp -- see gpu_mapper.hpp.  Reference: src/bimocq3D/GPU_Advection.h:110-627.
 #include "gpu_mapper.hpp"
 
+#include <cstdlib>
+
 namespace bqhost {
 
-gpuMapper::gpuMapper(int device, int nx, int ny, int nz, float h)
+void (*g_trace_hook)(const char *stage) = nullptr;
+
+gpuMapper::gpuMapper(int device, int nx, int ny, int nz, float h, const SlabCtx &sl)
 {
-    g.ni = nx; g.nj = ny; g.nk = nz; g.h = h;
+    slab = sl;
+    g.ni = nx; g.nj = ny; g.nk = slab.on ? slab.nk_local() : nz; g.h = h;
     if (fl_init(device) != FL_OK) return;                 // cudaInit(), GPU_Advection.h:214-226
-    ok_ = u_src.alloc(g.nu()) && v_src.alloc(g.nv()) && w_src.alloc(g.nw())
-       && x_out.alloc(g.n()) && y_out.alloc(g.n()) && z_out.alloc(g.n())
-       && x_out2.alloc(g.n()) && y_out2.alloc(g.n()) && z_out2.alloc(g.n());
+    if (slab.on) fl_set_slab(slab.koff(), slab.nkg, slab.own0, slab.own1, slab.nk_local());
+    else fl_set_slab(0, 0, 0, 0, 0);
+    ok_ = allocField(u_src, FIELD_U) && allocField(v_src, FIELD_V) && allocField(w_src, FIELD_W)
+       && allocField(x_out, FIELD_S) && allocField(y_out, FIELD_S) && allocField(z_out, FIELD_S)
+       && allocField(x_out2, FIELD_S) && allocField(y_out2, FIELD_S) && allocField(z_out2, FIELD_S);
+}
+
+bool gpuMapper::allocField(DeviceField &f, FieldKind kind) const
+{
+    size_t count = kind == FIELD_U ? g.nu() : kind == FIELD_V ? g.nv() : kind == FIELD_W ? g.nw() : g.n();
+    if (!f.alloc(count)) return false;
+    f.plane = kind == FIELD_U ? (size_t)(g.ni + 1) * g.nj : kind == FIELD_V ? (size_t)g.ni * (g.nj + 1) : (size_t)g.ni * g.nj;
+    f.extra = kind == FIELD_W ? 1 : 0;
+    f.valid = slab.on ? slab.G : DeviceField::kAlwaysValid;      // zero-filled: trivially consistent
+    return true;
+}
+
+void gpuMapper::require(std::initializer_list<DeviceField *> fields, int depth)
+{
+    if (!slab.on || slab.nranks <= 1) return;
+    if (depth > slab.G) {
+        // the caller asked for more ghost planes than exist: the time step moved data further than the
+        // slab overlap (CFL too large for G); refuse rather than compute from missing planes
+        fl_report_error(FL_ERR_BAD_ARGUMENT, "z-slab ghost zone too shallow for this time step (CFL travel + stencil reach > G)");
+        return;
+    }
+    // BQ_HALO_ALWAYS=1 (debug): refresh on every request, whatever the bookkeeping says
+    static const bool always = getenv("BQ_HALO_ALWAYS") && atoi(getenv("BQ_HALO_ALWAYS")) != 0;
+    float *ptrs[16]; size_t planes[16]; int extras[16]; int n = 0;
+    for (DeviceField *f : fields)
+        if ((always || f->valid < depth) && n < 16) { ptrs[n] = f->get(); planes[n] = f->plane; extras[n] = f->extra; n++; }
+    if (!n) return;
+    fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, slab.G, 1);
+    for (DeviceField *f : fields)
+        if (always || f->valid < depth) f->valid = slab.G;
 }
 
 void gpuMapper::startEventRecord()
@@ -40,7 +77,7 @@ void gpuMapper::compensateVelocity(float *u, float *v, float *w, float *du, floa
                                    float *fx, float *fy, float *fz, float *bx, float *by, float *bz,
                                    bool is_point) const
 {
-    u_src.zero(); v_src.zero(); w_src.zero();
+    fl_memset(u_src, 0, u_src.bytes()); fl_memset(v_src, 0, v_src.bytes()); fl_memset(w_src, 0, w_src.bytes());
     gpu_compensate_velocity(u, v, w, du, dv, dw, u_src, v_src, w_src, fx, fy, fz, bx, by, bz,
                             g.h, g.ni, g.nj, g.nk, is_point);
 }

@@ -9,6 +9,7 @@
 //   * the DMC sub-step ping-pongs between buffers instead of copying out -> in three times.
 #pragma once
 #include <cstddef>
+#include <initializer_list>
 #include <vector>
 #include "bimocq_gpu.h"
 
@@ -37,23 +38,51 @@ public:
         return p_ != nullptr;
     }
     void release() { if (p_) fl_free(p_); p_ = nullptr; n_ = 0; }
-    void zero() const { fl_memset(p_, 0, bytes()); }
-    void copy_from(const DeviceField &src) const { fl_memcpy_d2d(p_, src.p_, bytes() < src.bytes() ? bytes() : src.bytes()); }
+    // an all-zero field is consistent across slab ranks; a copy inherits the source's ghost validity
+    void zero() { fl_memset(p_, 0, bytes()); valid = kAlwaysValid; }
+    void copy_from(const DeviceField &src)
+    {
+        fl_memcpy_d2d(p_, src.p_, bytes() < src.bytes() ? bytes() : src.bytes());
+        valid = src.valid;
+    }
     void download(float *host) const { fl_memcpy_d2h(host, p_, bytes()); }
     void upload(const float *host) const { fl_memcpy_h2d(p_, host, bytes()); }
     float *get() const { return p_; }
     operator float *() const { return p_; }
     size_t count() const { return n_; }
     size_t bytes() const { return n_ * sizeof(float); }
-    void swap(DeviceField &o) { float *p = p_; size_t n = n_; p_ = o.p_; n_ = o.n_; o.p_ = p; o.n_ = n; }
+    void swap(DeviceField &o)
+    {
+        float *p = p_; size_t n = n_; p_ = o.p_; n_ = o.n_; o.p_ = p; o.n_ = n;
+        int v = valid; valid = o.valid; o.valid = v;
+    }
+
+    // z-slab bookkeeping (multi-GPU): how many ghost planes per side currently hold correct values,
+    // elements per plane, and 1 for a w-type buffer (nk+1 planes).  Ignored on a single GPU.
+    int    valid = kAlwaysValid;
+    size_t plane = 0;
+    int    extra = 0;
+    static constexpr int kAlwaysValid = 1 << 20;
 
 private:
     float *p_ = nullptr;
     size_t n_ = 0;
 };
 
+// z-slab decomposition of the global grid.  Rank `rank` of `nranks` owns the global cell
+// planes [own0, own1) and stores [own0 - G, own1 + G); off = single GPU.
+struct SlabCtx {
+    bool on = false;
+    int rank = 0, nranks = 1;
+    int nkg = 0;            // global cell planes
+    int own0 = 0, own1 = 0;
+    int G = 0;              // ghost planes per side
+    int koff() const { return own0 - G; }
+    int nk_local() const { return own1 - own0 + 2 * G; }
+};
+
 struct GridDims {
-    int ni = 0, nj = 0, nk = 0;
+    int ni = 0, nj = 0, nk = 0;     // nk: LOCAL cell planes (owned + ghosts on a slab rank)
     float h = 0.f;
     size_t n() const { return (size_t)ni * nj * nk; }
     size_t nu() const { return (size_t)(ni + 1) * nj * nk; }
@@ -61,12 +90,34 @@ struct GridDims {
     size_t nw() const { return (size_t)ni * nj * (nk + 1); }
 };
 
+enum FieldKind { FIELD_U, FIELD_V, FIELD_W, FIELD_S };
+
+// debug hook (BQ_TRACE): called with a stage name from inside the mapper sequences
+extern void (*g_trace_hook)(const char *stage);
+inline void trace_point(const char *stage) { if (g_trace_hook) g_trace_hook(stage); }
+
 class gpuMapper {
 public:
-    gpuMapper(int device, int nx, int ny, int nz, float h);
+    // nz: GLOBAL cell planes; with a slab context the buffers hold slab.nk_local() planes
+    gpuMapper(int device, int nx, int ny, int nz, float h, const SlabCtx &slab = SlabCtx());
     bool ok() const { return ok_; }
 
     GridDims g;
+    SlabCtx slab;
+    // allocate a field of the given staggering, with its slab metadata
+    bool allocField(DeviceField &f, FieldKind kind) const;
+    // make sure the listed fields have at least `depth` valid ghost planes: those that do not are
+    // refreshed from the z-neighbours (all G planes, one RCCL group).  No-op on a single GPU.
+    void require(std::initializer_list<DeviceField *> fields, int depth);
+    // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes
+    void produced(DeviceField &f, int valid) const { if (slab.on) f.valid = valid < 0 ? 0 : valid; }
+    void producedAll(std::initializer_list<DeviceField *> fields, int valid) const { for (DeviceField *f : fields) produced(*f, valid); }
+    static int minValid(std::initializer_list<const DeviceField *> fields)
+    {
+        int v = DeviceField::kAlwaysValid;
+        for (const DeviceField *f : fields) if (f->valid < v) v = f->valid;
+        return v;
+    }
     // scratch owned by the mapper (GPU_Advection.h:122-136)
     DeviceField u_src, v_src, w_src;
     DeviceField x_out, y_out, z_out;        // DMC ping buffers (border nodes stay 0, as in the reference)

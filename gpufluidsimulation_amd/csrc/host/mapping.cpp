@@ -1,14 +1,25 @@
 // mapping.cpp -- see mapping.hpp.  Reference: src/bimocq3D/Mapping.cpp:276-447.
 #include "mapping.hpp"
 
+#include <algorithm>
+
 namespace bqhost {
 
-bool MapSet::alloc(const GridDims &g)
+// How far (in planes) the kernels reach along z, as a function of the map displacement bound D:
+//   a map sampled at the 9 sub-voxel points of a node touches planes k-1..k+1          -> 1
+//   a field sampled at a mapped position that sits <= D cells from the node, +-0.25h
+//   offset, trilinear footprint                                                          -> D + 2
+//   DMC sub-step: velocity at x and x -+ h, map at a point <= 1 cell away (CFL sub-step)  -> 3
+static const int kReachMap = 1;
+static inline int reachField(int D) { return D + 2; }
+static const int kReachDMC = 3;
+
+bool MapSet::alloc(const gpuMapper &m)
 {
     DeviceField *all[] = { &ForwardX, &ForwardY, &ForwardZ, &BackwardX, &BackwardY, &BackwardZ,
                            &BackwardXPrev, &BackwardYPrev, &BackwardZPrev, &InitX, &InitY, &InitZ };
     for (DeviceField *f : all)
-        if (!f->alloc(g.n())) return false;
+        if (!m.allocField(*f, FIELD_S)) return false;
     return true;
 }
 
@@ -20,7 +31,7 @@ bool MapperBaseGPU::init(int ni, int nj, int nk, float h, float coeff, gpuMapper
     TotalReinitCount = 0;
     gpuSolver = mymapper;
     maps = std::make_shared<MapSet>();
-    if (!maps->alloc(g)) return false;
+    if (!maps->alloc(*mymapper)) return false;
     MapSet &m = *maps;
     gpu_init_maps(m.InitX, m.InitY, m.InitZ, h, ni, nj, nk);    // host loop + H2D in the reference (:306-328)
     m.ForwardX.copy_from(m.InitX); m.ForwardY.copy_from(m.InitY); m.ForwardZ.copy_from(m.InitZ);
@@ -30,85 +41,193 @@ bool MapperBaseGPU::init(int ni, int nj, int nk, float h, float coeff, gpuMapper
 }
 
 // Mapping.cpp:347-352
-void MapperBaseGPU::updateMapping(float *U, float *V, float *W, float cfldt, float dt)
+void MapperBaseGPU::updateMapping(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells)
 {
-    updateBackward(U, V, W, cfldt, dt);
-    updateForward(U, V, W, cfldt, dt);
+    updateBackward(U, V, W, cfldt, dt, dcells);
+    updateForward(U, V, W, cfldt, dt, dcells);
 }
 
 // Mapping.cpp:354-368.  The reference copies x_out -> Backward after every sub-step
 // (GPU_Advection.h:466-468); here sub-steps ping-pong between the mapper's two scratch sets and
 // only the final result is copied into Backward.  Both scratch sets keep zero border nodes,
 // exactly like the reference's x_out, so the copied-in border is the same.
-void MapperBaseGPU::updateBackward(float *U, float *V, float *W, float cfldt, float dt)
+void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells)
 {
     MapSet &m = *maps;
+    gpuMapper &gs = *gpuSolver;
     float T = 0.f;
     float substep = cfldt;
-    float *in[3] = { m.BackwardX, m.BackwardY, m.BackwardZ };
-    float *ping[2][3] = { { gpuSolver->x_out, gpuSolver->y_out, gpuSolver->z_out },
-                          { gpuSolver->x_out2, gpuSolver->y_out2, gpuSolver->z_out2 } };
+    DeviceField *in[3] = { &m.BackwardX, &m.BackwardY, &m.BackwardZ };
+    DeviceField *ping[2][3] = { { &gs.x_out, &gs.y_out, &gs.z_out }, { &gs.x_out2, &gs.y_out2, &gs.z_out2 } };
     int which = 0;
     bool any = false;
     while (T < dt) {
         if (T + substep > dt) substep = dt - T;
-        float **out = ping[which];
-        gpuSolver->solveBackwardDMC(U, V, W, in[0], in[1], in[2], out[0], out[1], out[2], substep);
+        DeviceField **out = ping[which];
+        if (keepDmcBorder) { out[0]->copy_from(*in[0]); out[1]->copy_from(*in[1]); out[2]->copy_from(*in[2]); }
+        gs.require({ &U, &V, &W, in[0], in[1], in[2] }, kReachDMC);
+        gs.solveBackwardDMC(U, V, W, *in[0], *in[1], *in[2], *out[0], *out[1], *out[2], substep);
+        const int v = gpuMapper::minValid({ &U, &V, &W, in[0], in[1], in[2] }) - kReachDMC;
+        gs.producedAll({ out[0], out[1], out[2] }, v);
         in[0] = out[0]; in[1] = out[1]; in[2] = out[2];
         which ^= 1;
         any = true;
         T += substep;
     }
     if (any) {
-        fl_memcpy_d2d(m.BackwardX, in[0], m.BackwardX.bytes());
-        fl_memcpy_d2d(m.BackwardY, in[1], m.BackwardY.bytes());
-        fl_memcpy_d2d(m.BackwardZ, in[2], m.BackwardZ.bytes());
+        m.BackwardX.copy_from(*in[0]); m.BackwardY.copy_from(*in[1]); m.BackwardZ.copy_from(*in[2]);
     }
+    m.Dback += dcells;
 }
 
-// Mapping.cpp:370-373
-void MapperBaseGPU::updateForward(float *U, float *V, float *W, float cfldt, float dt)
+// Mapping.cpp:370-373.  In place; a node's trace starts at its own map value and samples the
+// velocity along a path that stays within Dfwd + dcells cells of the node.
+void MapperBaseGPU::updateForward(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells)
 {
     MapSet &m = *maps;
-    gpuSolver->solveForward(U, V, W, m.ForwardX, m.ForwardY, m.ForwardZ, cfldt, dt);
+    gpuMapper &gs = *gpuSolver;
+    const int reach = reachField(m.Dfwd + dcells);
+    gs.require({ &U, &V, &W }, reach);
+    gs.solveForward(U, V, W, m.ForwardX, m.ForwardY, m.ForwardZ, cfldt, dt);
+    const int v = std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }),
+                           gpuMapper::minValid({ &U, &V, &W }) - reach);
+    gs.producedAll({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, v);
+    m.Dfwd += dcells;
 }
 
-// Mapping.cpp:375-391
-void MapperBaseGPU::advectVelocity(float *U, float *V, float *W, float *Ui, float *Vi, float *Wi,
-                                   float *Up, float *Vp, float *Wp)
+// Mapping.cpp:375-391.  gpu_compensate_velocity is issued as its four stages (GPU_kernel.cu:652-665)
+// so that a slab rank can refresh ghost planes between them; the arithmetic is the same.
+void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &W,
+                                   DeviceField &Ui, DeviceField &Vi, DeviceField &Wi,
+                                   DeviceField &Up, DeviceField &Vp, DeviceField &Wp)
 {
     MapSet &m = *maps;
-    gpuSolver->advectVelocity(U, V, W, Ui, Vi, Wi, m.BackwardX, m.BackwardY, m.BackwardZ, false);
-    gpuSolver->compensateVelocity(U, V, W, Ui, Vi, Wi, m.ForwardX, m.ForwardY, m.ForwardZ,
-                                  m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    gpuMapper &gs = *gpuSolver;
+    const float h = g.h;
+    const int ni = g.ni, nj = g.nj, nk = g.nk;
+
+    // advect: U(x) = blend9(Ui(psi_back(x)))
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+    gs.require({ &Ui, &Vi, &Wi }, reachField(m.Dback));
+    gs.advectVelocity(U, V, W, Ui, Vi, Wi, m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    gs.producedAll({ &U, &V, &W }, std::min(gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                                            gpuMapper::minValid({ &Ui, &Vi, &Wi }) - reachField(m.Dback)));
+
+    trace_point("v.advect");
+    // stage 1: error at time 0, u_src = blend9(U(psi_fwd(x))) - Ui(x)      (GPU_Advection.h:499-501 zeroes u_src)
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    gs.require({ &U, &V, &W }, reachField(m.Dfwd));
+    gs.u_src.zero(); gs.v_src.zero(); gs.w_src.zero();
+    gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
+                                  m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    gs.producedAll({ &gs.u_src, &gs.v_src, &gs.w_src },
+                   std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
+                              gpuMapper::minValid({ &U, &V, &W }) - reachField(m.Dfwd),
+                              gpuMapper::minValid({ &Ui, &Vi, &Wi }) }));
+    trace_point("v.stage1");
+    // stage 2: Ui <- uncompensated U (clobbers the caller's init)
+    Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W);
+    // stage 3: U += blend9(-0.5 * u_src(psi_back(x)))
+    gs.require({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback));
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+    gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
+    gs.producedAll({ &U, &V, &W }, std::min({ gpuMapper::minValid({ &U, &V, &W }),
+                                              gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                                              gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) }));
+    trace_point("v.stage3");
+    // stage 4: limiter against the 3x3x3 box of the uncompensated field
+    gs.require({ &Ui, &Vi, &Wi }, 1);
+    gpu_clamp_extrema_box(Ui, U, ni + 1, nj, nk);
+    gpu_clamp_extrema_box(Vi, V, ni, nj + 1, nk);
+    gpu_clamp_extrema_box_w(Wi, W, ni, nj, nk + 1);
+    gs.producedAll({ &U, &V, &W }, std::min(gpuMapper::minValid({ &U, &V, &W }), gpuMapper::minValid({ &Ui, &Vi, &Wi }) - 1));
+
     const float blend = (TotalReinitCount != 0) ? BlendCoeff : 1.f;
-    gpuSolver->advectVelocityDouble(U, V, W, Up, Vp, Wp, m.BackwardX, m.BackwardY, m.BackwardZ,
-                                    m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    if (blend != 1.f) {
+        gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+        gs.require({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }, reachField(m.Dback));
+        gs.require({ &Up, &Vp, &Wp }, reachField(m.Dback + m.DbackPrev));
+    }
+    gs.advectVelocityDouble(U, V, W, Up, Vp, Wp, m.BackwardX, m.BackwardY, m.BackwardZ,
+                            m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    if (blend != 1.f)
+        gs.producedAll({ &U, &V, &W }, std::min({ gpuMapper::minValid({ &U, &V, &W }),
+                                                  gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                                                  gpuMapper::minValid({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }) - reachField(m.Dback),
+                                                  gpuMapper::minValid({ &Up, &Vp, &Wp }) - reachField(m.Dback + m.DbackPrev) }));
 }
 
-// Mapping.cpp:393-407
-void MapperBaseGPU::advectField(float *f, float *fInit, float *fPrev)
+// Mapping.cpp:393-407, same four-stage expansion of gpu_compensate_field (GPU_kernel.cu:676-681)
+void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField &fPrev)
 {
     MapSet &m = *maps;
-    gpuSolver->advectField(f, fInit, m.BackwardX, m.BackwardY, m.BackwardZ, false);
-    gpuSolver->compensateField(f, fInit, m.ForwardX, m.ForwardY, m.ForwardZ,
-                               m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    gpuMapper &gs = *gpuSolver;
+    const float h = g.h;
+    const int ni = g.ni, nj = g.nj, nk = g.nk;
+
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+    gs.require({ &fInit }, reachField(m.Dback));
+    gs.advectField(f, fInit, m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    gs.produced(f, std::min(gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                            fInit.valid - reachField(m.Dback)));
+
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    gs.require({ &f }, reachField(m.Dfwd));
+    fl_memset(gs.u_src, 0, g.n() * sizeof(float));            // GPU_Advection.h:526 (u_src doubles as scalar scratch)
+    gpu_compensate_error_field(f, fInit, gs.u_src, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    // u_src is the u-sized scratch: as a scalar field its planes are ni*nj wide
+    const size_t saved_plane = gs.u_src.plane;
+    gs.u_src.plane = (size_t)ni * nj;
+    gs.produced(gs.u_src, std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
+                                     f.valid - reachField(m.Dfwd), fInit.valid }));
+    fInit.copy_from(f);
+    gs.require({ &gs.u_src }, reachField(m.Dback));
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+    gs.accumulateField(gs.u_src, f, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
+    gs.produced(f, std::min({ f.valid, gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                              gs.u_src.valid - reachField(m.Dback) }));
+    gs.u_src.plane = saved_plane;
+    gs.require({ &fInit }, 1);
+    gpu_clamp_extrema_box(fInit, f, ni, nj, nk);
+    gs.produced(f, std::min(f.valid, fInit.valid - 1));
+
     const float blend = (TotalReinitCount != 0) ? BlendCoeff : 1.f;
-    gpuSolver->advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
-                                 m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    if (blend != 1.f) {
+        gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+        gs.require({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }, reachField(m.Dback));
+        gs.require({ &fPrev }, reachField(m.Dback + m.DbackPrev));
+    }
+    gs.advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
+                         m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    if (blend != 1.f)
+        gs.produced(f, std::min({ f.valid, gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                                  gpuMapper::minValid({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }) - reachField(m.Dback),
+                                  fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
 }
 
 // Mapping.cpp:420-428 (note the Init/Change order swap towards the gpuMapper)
-void MapperBaseGPU::accumulateVelocity(float *dUi, float *dVi, float *dWi, float *Uc, float *Vc, float *Wc, float coeff)
+void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
+                                       DeviceField &Uc, DeviceField &Vc, DeviceField &Wc, float coeff)
 {
     MapSet &m = *maps;
-    gpuSolver->accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
+    gpuMapper &gs = *gpuSolver;
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    gs.require({ &Uc, &Vc, &Wc }, reachField(m.Dfwd));
+    gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
+    gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
+                                                    gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
+                                                    gpuMapper::minValid({ &Uc, &Vc, &Wc }) - reachField(m.Dfwd) }));
 }
 
-void MapperBaseGPU::accumulateField(float *dfInit, float *fChange)
+void MapperBaseGPU::accumulateField(DeviceField &dfInit, DeviceField &fChange)
 {
     MapSet &m = *maps;
-    gpuSolver->accumulateField(fChange, dfInit, m.ForwardX, m.ForwardY, m.ForwardZ, false, 1.0f);
+    gpuMapper &gs = *gpuSolver;
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    gs.require({ &fChange }, reachField(m.Dfwd));
+    gs.accumulateField(fChange, dfInit, m.ForwardX, m.ForwardY, m.ForwardZ, false, 1.0f);
+    gs.produced(dfInit, std::min({ dfInit.valid, gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
+                                   fChange.valid - reachField(m.Dfwd) }));
 }
 
 // Mapping.cpp:430-447.  BackwardPrev <- Backward is a buffer swap (the old BackwardPrev content is
@@ -120,6 +239,9 @@ void MapperBaseGPU::reinitializeMapping()
     m.BackwardXPrev.swap(m.BackwardX); m.BackwardYPrev.swap(m.BackwardY); m.BackwardZPrev.swap(m.BackwardZ);
     m.BackwardX.copy_from(m.InitX); m.BackwardY.copy_from(m.InitY); m.BackwardZ.copy_from(m.InitZ);
     m.ForwardX.copy_from(m.InitX); m.ForwardY.copy_from(m.InitY); m.ForwardZ.copy_from(m.InitZ);
+    m.DbackPrev = m.Dback;
+    m.Dback = 0;
+    m.Dfwd = 0;
 }
 
 } // namespace bqhost

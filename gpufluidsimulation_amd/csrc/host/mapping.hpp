@@ -1,6 +1,11 @@
 // mapping.hpp -- device-resident BiMocq map state and its update/advect/accumulate/reinit
 // sequences.  Mirrors the reference's MapperBaseGPU (src/bimocq3D/Mapping.h:54-105,
 // src/bimocq3D/Mapping.cpp:276-447).
+//
+// z-slab ranks (multi-GPU): every method states how far its kernels reach along z
+// (`require(fields, depth)`) before launching and records how many ghost planes of its outputs are
+// still correct afterwards (`produced`), so ghost planes are exchanged exactly when an operator needs
+// more of them than are valid.  On a single GPU both calls are no-ops.
 #pragma once
 #include <memory>
 #include "gpu_mapper.hpp"
@@ -16,7 +21,10 @@ struct MapSet {
     DeviceField BackwardX, BackwardY, BackwardZ;
     DeviceField BackwardXPrev, BackwardYPrev, BackwardZPrev;
     DeviceField InitX, InitY, InitZ;
-    bool alloc(const GridDims &g);
+    // upper bounds (in cells) of |map(x) - x| along any axis: how far a mapped position can sit from
+    // the node it belongs to.  Grow by the step's CFL travel, reset by reinitializeMapping().
+    int Dfwd = 0, Dback = 0, DbackPrev = 0;
+    bool alloc(const gpuMapper &m);
 };
 
 class MapperBaseGPU {
@@ -28,20 +36,30 @@ public:
     bool sharesMaps() const { return shared_; }
     void noteSharedReinit() { TotalReinitCount++; }
 
-    void updateForward(float *U, float *V, float *W, float cfldt, float dt);
-    void updateBackward(float *U, float *V, float *W, float cfldt, float dt);
-    void updateMapping(float *U, float *V, float *W, float cfldt, float dt);
+    // dcells: upper bound of the distance (in cells) anything travels during this update
+    void updateForward(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells);
+    void updateBackward(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells);
+    void updateMapping(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells);
 
-    void advectVelocity(float *U, float *V, float *W, float *Ui, float *Vi, float *Wi,
-                        float *Up, float *Vp, float *Wp);
-    void advectField(float *f, float *fInit, float *fPrev);
-    void accumulateVelocity(float *dUi, float *dVi, float *dWi, float *Uc, float *Vc, float *Wc, float coeff);
-    void accumulateField(float *dfInit, float *fChange);
+    void advectVelocity(DeviceField &U, DeviceField &V, DeviceField &W,
+                        DeviceField &Ui, DeviceField &Vi, DeviceField &Wi,
+                        DeviceField &Up, DeviceField &Vp, DeviceField &Wp);
+    void advectField(DeviceField &f, DeviceField &fInit, DeviceField &fPrev);
+    void accumulateVelocity(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
+                            DeviceField &Uc, DeviceField &Vc, DeviceField &Wc, float coeff);
+    void accumulateField(DeviceField &dfInit, DeviceField &fChange);
     void reinitializeMapping();
 
     GridDims g;
     float BlendCoeff = 1.f;
     unsigned TotalReinitCount = 0;
+    // The reference copies the DMC scratch buffer, whose border nodes (outside 2..n-3) are zero, back
+    // into the backward map (GPU_Advection.h:464-468; the pre-copy that would have kept the border is
+    // commented out at :335-337).  Wall-adjacent nodes of the compensation gather then sample positions
+    // pulled 25 % towards the origin -- arbitrarily far along z.  Default false = replicate (single-GPU
+    // parity with the reference); true = keep the incoming border (the evident intent), which is also the
+    // only setting under which z-slab ranks reproduce a single GPU bit for bit.
+    bool keepDmcBorder = false;
     std::shared_ptr<MapSet> maps;
     gpuMapper *gpuSolver = nullptr;
 

@@ -15,9 +15,25 @@ extern "C" {
 
 bq_solver *bq_solver_create(int device, int nx, int ny, int nz, float L, float viscosity, float blend, int scheme)
 {
+    return bq_solver_create_slab(device, nx, ny, nz, L, viscosity, blend, scheme, 0, 1, 0);
+}
+
+bq_solver *bq_solver_create_slab(int device, int nx, int ny, int nz, float L, float viscosity, float blend, int scheme,
+                                 int rank, int nranks, int ghost)
+{
     if (nx < 8 || ny < 8 || nz < 8 || scheme != BQ_SCHEME_BIMOCQ) return nullptr;
+    SlabCtx sl;
+    if (nranks > 1 || ghost > 0) {
+        // even z-slabs: rank r owns planes [r*nz/nranks, (r+1)*nz/nranks); each must be deeper than the ghost zone
+        if (nranks < 1 || rank < 0 || rank >= nranks || ghost < 2 || nz % nranks != 0 || nz / nranks < ghost + 1) {
+            fl_report_error(FL_ERR_BAD_ARGUMENT, "bq_solver_create_slab: need nz % nranks == 0, ghost >= 2 and nz/nranks > ghost");
+            return nullptr;
+        }
+        sl.on = true; sl.rank = rank; sl.nranks = nranks; sl.nkg = nz; sl.G = ghost;
+        sl.own0 = rank * (nz / nranks); sl.own1 = sl.own0 + nz / nranks;
+    }
     auto s = std::make_unique<bq_solver>();
-    s->mapper = std::make_unique<gpuMapper>(device, nx, ny, nz, L / nx);       // main.cpp:151 / :37 (h = L/ni)
+    s->mapper = std::make_unique<gpuMapper>(device, nx, ny, nz, L / nx, sl);   // main.cpp:151 / :37 (h = L/ni)
     if (!s->mapper->ok()) return nullptr;
     s->solver = std::make_unique<BimocqGPUSolver>(nx, ny, nz, L, viscosity, blend, BIMOCQ, s->mapper.get());
     if (!s->solver->ok()) return nullptr;
@@ -57,6 +73,15 @@ void bq_solver_set_projection(bq_solver *s, int kind, int iters, float halfrdx)
     s->solver->halfrdx = halfrdx;
 }
 
+void bq_solver_set_option(bq_solver *s, int option, int value)
+{
+    if (!s) return;
+    if (option == BQ_OPT_KEEP_DMC_BORDER) {
+        s->solver->VelocityAdvector.keepDmcBorder = value != 0;
+        s->solver->ScalarAdvector.keepDmcBorder = value != 0;
+    }
+}
+
 void bq_solver_advance(bq_solver *s, int framenum, float dt)
 {
     if (s) s->solver->advance(framenum, dt);
@@ -76,12 +101,21 @@ long bq_solver_download(bq_solver *s, int which, float *host, long capacity)
     const DeviceField *f[BQ_F_COUNT] = {
         &b.Density, &b.Temperature, &b.VelocityU, &b.VelocityV, &b.VelocityW,
         &b.VelocityUInit, &b.VelocityVInit, &b.VelocityWInit, &b.DensityInit, &b.TemperatureInit,
-        &m.ForwardX, &m.ForwardY, &m.ForwardZ, &m.BackwardX, &m.BackwardY, &m.BackwardZ, &b.p };
+        &m.ForwardX, &m.ForwardY, &m.ForwardZ, &m.BackwardX, &m.BackwardY, &m.BackwardZ, &b.p, &b.div };
     if (which < 0 || which >= BQ_F_COUNT) return 0;
     long count = (long)f[which]->count();
     if (host && capacity > 0)
         fl_memcpy_d2h(host, f[which]->get(), (size_t)std::min(count, capacity) * sizeof(float));
     return count;
+}
+
+/* slab geometry of this solver: {on, rank, nranks, nk_global, own0, own1, ghost, nk_local} */
+void bq_solver_slab_info(const bq_solver *s, int out[8])
+{
+    if (!s || !out) return;
+    const SlabCtx &sl = s->mapper->slab;
+    out[0] = sl.on; out[1] = sl.rank; out[2] = sl.nranks; out[3] = sl.on ? sl.nkg : s->mapper->g.nk;
+    out[4] = sl.on ? sl.own0 : 0; out[5] = sl.on ? sl.own1 : s->mapper->g.nk; out[6] = sl.G; out[7] = s->mapper->g.nk;
 }
 
 float bq_solver_last_cfldt(const bq_solver *s) { return s ? s->solver->last_cfldt : 0.f; }

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 
 FIELD_IDS = {"rho": 0, "T": 1, "u": 2, "v": 3, "w": 4, "uinit": 5, "vinit": 6, "winit": 7,
-             "rhoinit": 8, "Tinit": 9, "fx": 10, "fy": 11, "fz": 12, "bx": 13, "by": 14, "bz": 15, "p": 16}
+             "rhoinit": 8, "Tinit": 9, "fx": 10, "fy": 11, "fz": 12, "bx": 13, "by": 14, "bz": 15, "p": 16, "div": 17}
 
 
 class Emitter(C.Structure):
@@ -22,9 +22,13 @@ class Emitter(C.Structure):
 
 HOST_SIGS = {
     "bq_solver_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "bq_solver_create_slab": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+                                          C.c_int, C.c_int, C.c_int]),
+    "bq_solver_slab_info": (None, [C.c_void_p, C.POINTER(C.c_int)]),
     "bq_solver_destroy": (None, [C.c_void_p]),
     "bq_solver_set_smoke": (None, [C.c_void_p, C.c_float, C.c_float, C.POINTER(Emitter), C.c_int]),
     "bq_solver_set_projection": (None, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "bq_solver_set_option": (None, [C.c_void_p, C.c_int, C.c_int]),
     "bq_solver_advance": (None, [C.c_void_p, C.c_int, C.c_float]),
     "bq_solver_output_result": (C.c_long, [C.c_void_p, C.c_uint, C.c_char_p]),
     "bq_solver_download": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
@@ -58,15 +62,21 @@ class BimocqGPUSolver:
     """advance()/outputResult() on the MI355X; `lib`/`errlib` are injectable so the CPU-only tests
     can drive the very same host code linked against a CPU stand-in of the C-ABI."""
 
-    def __init__(self, nx, ny, nz, L=1.0, viscosity=0.0, blend=1.0, device=0, lib=None, errlib=None):
+    def __init__(self, nx, ny, nz, L=1.0, viscosity=0.0, blend=1.0, device=0, lib=None, errlib=None,
+                 rank=0, nranks=1, ghost=0):
+        """nz is the GLOBAL plane count; with nranks > 1 (or ghost > 0) this object is one z-slab rank
+        (set the communicator up first: gpufluidsimulation_amd.transport)."""
         self.lib = lib or host_lib()
         self.errlib = errlib or (_lib.hip_lib() if lib is None else lib)
         self.nx, self.ny, self.nz = nx, ny, nz
         self.h = float(np.float32(L) / np.float32(nx))
-        self.s = self.lib.bq_solver_create(device, nx, ny, nz, L, viscosity, blend, 0)
+        self.s = self.lib.bq_solver_create_slab(device, nx, ny, nz, L, viscosity, blend, 0, rank, nranks, ghost)
         if not self.s:
             self._check()
             raise _lib.BimocqError("bq_solver_create failed")
+        info = (C.c_int * 8)()
+        self.lib.bq_solver_slab_info(self.s, info)
+        (self.slab_on, self.rank, self.nranks, _, self.own0, self.own1, self.ghost, self.nk_local) = list(info)
 
     def _check(self):
         code = self.errlib.fl_last_error()
@@ -87,6 +97,10 @@ class BimocqGPUSolver:
     def setProjection(self, iters, halfrdx):
         self.lib.bq_solver_set_projection(self.s, 0, iters, halfrdx)
 
+    def setOption(self, option, value):
+        """option 1 = BQ_OPT_KEEP_DMC_BORDER"""
+        self.lib.bq_solver_set_option(self.s, option, value)
+
     def advance(self, framenum, dt):
         self.lib.bq_solver_advance(self.s, framenum, dt)
 
@@ -102,6 +116,17 @@ class BimocqGPUSolver:
         self.lib.bq_solver_download(self.s, which, out.ctypes.data, count)
         self._check()
         return out
+
+    def owned(self, name):
+        """the planes this rank owns, as a flat array in global plane order (w on the last rank also
+        carries its top plane) -- concatenating owned() over the ranks gives the single-GPU field"""
+        a = self.field(name)
+        if not self.slab_on:
+            return a
+        kind = {"u": (self.nx + 1) * self.ny, "uinit": (self.nx + 1) * self.ny,
+                "v": self.nx * (self.ny + 1), "vinit": self.nx * (self.ny + 1)}.get(name, self.nx * self.ny)
+        extra = 1 if name in ("w", "winit") and self.own1 == self.nz else 0
+        return a[kind * self.ghost: kind * (self.ghost + self.own1 - self.own0 + extra)]
 
     @property
     def cfldt(self):

@@ -216,6 +216,8 @@ void  fl_event_destroy(void *ev);
 int         fl_last_error(void);
 const char *fl_last_error_string(void);
 void        fl_clear_error(void);
+/* latch an error on behalf of host code that sits on top of this ABI (first error wins) */
+void        fl_report_error(int code, const char *text);
 /* the hipStream_t the operators launch on (for timing / interop with other runtimes) */
 void *fl_compute_stream(void);
 
@@ -253,8 +255,51 @@ void gpu_gradient(float *u, float *v, float *w, const float *p,
 /* exact sum r^2 (double) and max|r| of r = div - (sum6 p - 6p) over interior cells; blocking */
 void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk,
                         double *sum_sq, float *max_abs);
+/* stage 1 of gpu_compensate_velocity / _field on its own (compensate_kernel, GPU_kernel.cu:438-499,
+ * launches :652-654 / :676): u_src = blend9(u(psi_fwd(x))) - du.  The full operator is then
+ * [this] ; du <- u ; gpu_accumulate_*(u_src -> u, backward map, -0.5) ; gpu_clamp_extrema_box(du, u),
+ * which lets a z-slab host refresh ghost planes between the stages. */
+void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+                                   float *u_src, float *v_src, float *w_src,
+                                   float *forward_x, float *forward_y, float *forward_z,
+                                   float h, int ni, int nj, int nk, bool is_point);
+void gpu_compensate_error_field(float *u, float *du, float *u_src,
+                                float *forward_x, float *forward_y, float *forward_z,
+                                float h, int ni, int nj, int nk, bool is_point);
+/* clamp_extrema_box for a staggered buffer: dz = 1 for the w component (nk+1 planes) */
+void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
 /* clampExtrema_kernel (GPU_kernel.cu:146-167) on its own: after = clamp(after, min/max27(before)) */
 void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Multi-GPU: z-slab context and ghost-plane exchange (one process per GPU, RCCL over xGMI)
+ * ---------------------------------------------------------------------------------------- */
+/* Tell the operators that the buffers they are given hold the global cell planes
+ * [koff, koff + nk_local) of a grid with nk_global planes, of which this rank owns [own0, own1).
+ * Index windows, positions and clamps are then evaluated in global coordinates; reductions
+ * (gpu_max_abs3, residual norms) count owned planes and are all-reduced.  nk_global <= 0 resets. */
+void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local);
+/* rank 0 obtains a 128-byte ncclUniqueId, the host program distributes it, every rank calls init */
+int  fl_comm_unique_id(void *id128);
+int  fl_comm_init(const void *id128, int rank, int nranks);
+void fl_comm_destroy(void);
+int  fl_comm_rank(void);
+int  fl_comm_size(void);
+/* refresh `depth` (<= G) ghost planes per side of n fields with the z-neighbours, one RCCL group on
+ * the halo stream.  extra[f] = 1 for a w-type buffer (nk+1 planes).  wait != 0: the compute stream
+ * waits for the exchange; else call fl_halo_wait() before touching the exchanged planes. */
+void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, const int *extra,
+                      int nk_local, int G, int depth, int wait);
+void fl_halo_wait(void);
+/* Host-side transport hook: replaces RCCL by two callbacks (blocking, called with the compute stream
+ * idle).  `exchange` receives fl_halo_exchange's arguments and must move the planes itself
+ * (fl_memcpy_d2h / its own wire / fl_memcpy_h2d; plane ranges as documented in bq_halo.hip);
+ * `allreduce` reduces `count` host values in place.  Used to run slab ranks over gloo / shared
+ * memory, e.g. several ranks on one GPU in the tests. */
+typedef void (*fl_exchange_cb)(int n, float *const *fields, const size_t *plane_elems, const int *extra,
+                               int nk_local, int G, int depth);
+typedef void (*fl_allreduce_cb)(void *host_values, int count, int is_double, int is_max);
+void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb exchange, fl_allreduce_cb allreduce);
 
 #ifdef __cplusplus
 }

@@ -30,20 +30,28 @@ enum { BQ_PROJECTION_JACOBI = 0 };      /* the `#if 0` branch of BimocqGPUSolver
 enum {
     BQ_F_RHO = 0, BQ_F_T, BQ_F_U, BQ_F_V, BQ_F_W, BQ_F_UINIT, BQ_F_VINIT, BQ_F_WINIT,
     BQ_F_RHOINIT, BQ_F_TINIT, BQ_F_FWDX, BQ_F_FWDY, BQ_F_FWDZ, BQ_F_BACKX, BQ_F_BACKY, BQ_F_BACKZ,
-    BQ_F_P, BQ_F_COUNT
+    BQ_F_P, BQ_F_DIV, BQ_F_COUNT
 };
 
 /* BimocqGPUSolver::BimocqGPUSolver (BimocqGPUSolver.cpp:3-106).  device: HIP device index.
  * Returns NULL on failure (see fl_last_error_string()). */
 bq_solver *bq_solver_create(int device, int nx, int ny, int nz, float L,
                             float viscosity, float blend, int scheme);
+/* z-slab rank of a multi-GPU run (one process per GPU): nz is the GLOBAL plane count, rank r of
+ * nranks owns planes [r*nz/nranks, (r+1)*nz/nranks) and keeps `ghost` ghost planes per side
+ * (>= CFL travel + 3; 8 covers CFL <= 5).  Requires fl_comm_init() first when nranks > 1. */
+bq_solver *bq_solver_create_slab(int device, int nx, int ny, int nz, float L, float viscosity, float blend,
+                                 int scheme, int rank, int nranks, int ghost);
+void  bq_solver_slab_info(const bq_solver *s, int out[8]);
 void  bq_solver_destroy(bq_solver *s);
 /* setSmoke (BimocqGPUSolver.cpp:529-534): alpha = drop (rho coefficient), beta = rise (T) */
 void  bq_solver_set_smoke(bq_solver *s, float drop, float rise, const bq_emitter *emitters, int n);
 /* projection variant + parameters (compile-time `#if` in the reference, :408-466) */
 void  bq_solver_set_projection(bq_solver *s, int kind, int iters, float halfrdx);
-/* z-slab decomposition: this rank owns cell planes [k0, k1) of a global nz (multi-GPU);
- * must be called before the first advance.  Single-GPU default: the whole grid. */
+/* solver options: BQ_OPT_KEEP_DMC_BORDER (default 0 = reference behaviour: the backward map's border
+ * nodes are zeroed by the DMC update; 1 = they keep their values, see csrc/host/mapping.hpp) */
+enum { BQ_OPT_KEEP_DMC_BORDER = 1 };
+void  bq_solver_set_option(bq_solver *s, int option, int value);
 /* advance (BimocqGPUSolver.cpp:108-127) */
 void  bq_solver_advance(bq_solver *s, int framenum, float dt);
 /* outputResult (BimocqGPUSolver.cpp:536-543): D2H of rho,u,v,w and a sparse density dump

@@ -21,6 +21,23 @@ typedef struct { float x, y, z; } f3;
 
 static inline f3 mk3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
 
+/* z-slab context (orc_set_slab), mirror of the library's fl_set_slab: the buffers hold the global
+ * planes [koff, koff + nk_local) of a grid with nkg cell planes.  Windows, positions and clamps are
+ * evaluated in global coordinates; off = single domain (koff = 0, nkg = nk). */
+static int S_on = 0, S_koff = 0, S_nkg = 0, S_own0 = 0, S_own1 = 0, S_nkl = 0;
+void orc_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
+{
+    S_nkl = nk_local;
+    S_on = nk_global > 0; S_koff = koff; S_nkg = nk_global; S_own0 = own0; S_own1 = own1;
+}
+#define KOFF (S_on ? S_koff : 0)
+#define NKG(nk) (S_on ? S_nkg : (nk))
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+/* local plane range [KLO, KHI) of a buffer with nkloc planes whose GLOBAL index lies in [glo, ghi) */
+#define KLO(glo) imax(0, (glo) - KOFF)
+#define KHI(ghi, nkloc) imin((nkloc), (ghi) - KOFF)
+
 /* GPU_kernel.cu:9-12 */
 static inline float clampf(float a, float lo, float hi) { return fminf(fmaxf(lo, a), hi); }
 
@@ -64,7 +81,7 @@ static inline float sample(const float *b, int nx, int ny, int nz, float h, f3 o
     int i = (int)floorf(qx), j = (int)floorf(qy), k = (int)floorf(qz);
     float fx = qx - (float)i, fy = qy - (float)j, fz = qz - (float)k;
     long sj = nx, sk = (long)nx * ny, count = (long)nx * ny * nz;
-    long base = (long)i + sj * j + sk * k;
+    long base = (long)i + sj * j + sk * (k - KOFF);
     return trilerp(ld(b, base, count),           ld(b, base + 1, count),
                    ld(b, base + sj, count),      ld(b, base + sj + 1, count),
                    ld(b, base + sk, count),      ld(b, base + sk + 1, count),
@@ -112,7 +129,7 @@ static inline f3 trace_rk3(const float *u, const float *v, const float *w,
                  pos.y + c1 * v1.y + c2 * v2.y + c3 * v3.y,
                  pos.z + c1 * v1.z + c2 * v2.z + c3 * v3.z);
     return clamp3(out, mk3(h, h, h),
-                  mk3((float)ni * h - h, (float)nj * h - h, (float)nk * h - h));
+                  mk3((float)ni * h - h, (float)nj * h - h, (float)NKG(nk) * h - h));
 }
 
 /* GPU_kernel.cu:92-125 trace: sub-step by cfldt until |dt| is consumed */
@@ -173,7 +190,7 @@ void orc_solve_forward(const float *u, const float *v, const float *w,
                        float h, int ni, int nj, int nk, float cfldt, float dt)
 {
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < nk - 2; k++)
+    for (int k = KLO(2); k < KHI(NKG(nk) - 2, nk); k++)
         for (int j = 2; j < nj - 2; j++)
             for (int i = 2; i < ni - 2; i++) {
                 long id = IDX3(i, j, k, ni, nj);
@@ -197,11 +214,11 @@ void orc_solve_backwardDMC(const float *u, const float *v, const float *w,
 {
     const f3 zero = mk3(0.f, 0.f, 0.f);
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < nk - 2; k++)
+    for (int k = KLO(2); k < KHI(NKG(nk) - 2, nk); k++)
         for (int j = 2; j < nj - 2; j++)
             for (int i = 2; i < ni - 2; i++) {
                 long id = IDX3(i, j, k, ni, nj);
-                f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+                f3 pt = mk3(h * (float)i, h * (float)j, h * (float)(k + KOFF));
                 f3 vel = get_velocity(u, v, w, h, ni, nj, nk, pt);
                 f3 tp = mk3((vel.x > 0) ? pt.x - h : pt.x + h,
                             (vel.y > 0) ? pt.y - h : pt.y + h,
@@ -258,7 +275,7 @@ static nine_t nine_setup(float h, int ni, int nj, int nk, int dx, int dy, int dz
 
 static inline f3 nine_pos(const nine_t *n, float h, int i, int j, int k, int ii)
 {
-    f3 c = mk3((float)i * h + n->origin.x, (float)j * h + n->origin.y, (float)k * h + n->origin.z);
+    f3 c = mk3((float)i * h + n->origin.x, (float)j * h + n->origin.y, (float)(k + KOFF) * h + n->origin.z);
     if (ii < 0) return c;
     return mk3(c.x + n->vol[ii].x, c.y + n->vol[ii].y, c.z + n->vol[ii].z);
 }
@@ -268,9 +285,9 @@ static void advect_comp(float *field, const float *field_init, map3 back,
                         float h, int ni, int nj, int nk, int dx, int dy, int dz, int is_point)
 {
     nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
-    f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)nk - h);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)NKG(nk) - h);
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 3 + dz; k < n.nbk - 3; k++)
+    for (int k = KLO(3 + dz); k < KHI(NKG(nk) + dz - 3, n.nbk); k++)
         for (int j = 3 + dy; j < n.nbj - 3; j++)
             for (int i = 3 + dx; i < n.nbi - 3; i++) {
                 float sum = 0.f;
@@ -290,9 +307,9 @@ static void double_advect_comp(float *field, const float *temp_field, map3 back,
                                int is_point, float blend)
 {
     nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
-    f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)nk - h);
+    f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)NKG(nk) - h);
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 3 + dz; k < n.nbk - 3; k++)
+    for (int k = KLO(3 + dz); k < KHI(NKG(nk) + dz - 3, n.nbk); k++)
         for (int j = 3 + dy; j < n.nbj - 3; j++)
             for (int i = 3 + dx; i < n.nbi - 3; i++) {
                 float sum = 0.f;
@@ -316,9 +333,9 @@ static void cumulate_comp(const float *src, float *dst, map3 m,
                           int is_point, float coeff)
 {
     nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
-    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)nk);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)NKG(nk));
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2 + dz; k < n.nbk - 2; k++)
+    for (int k = KLO(2 + dz); k < KHI(NKG(nk) + dz - 2, n.nbk); k++)
         for (int j = 2 + dy; j < n.nbj - 2; j++)
             for (int i = 2 + dx; i < n.nbi - 2; i++) {
                 float sum = 0.f;
@@ -338,9 +355,9 @@ static void compensate_comp(const float *src, const float *init, float *err, map
                             float h, int ni, int nj, int nk, int dx, int dy, int dz, int is_point)
 {
     nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
-    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)nk);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)NKG(nk));
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2 + dz; k < n.nbk - 2; k++)
+    for (int k = KLO(2 + dz); k < KHI(NKG(nk) + dz - 2, n.nbk); k++)
         for (int j = 2 + dy; j < n.nbj - 2; j++)
             for (int i = 2 + dx; i < n.nbi - 2; i++) {
                 float sum = 0.f;
@@ -357,10 +374,11 @@ static void compensate_comp(const float *src, const float *init, float *err, map
 }
 
 /* GPU_kernel.cu:146-167 clampExtrema_kernel (3x3x3 box limiter, interior only) */
-void orc_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
+/* nkgb: GLOBAL plane count of this buffer (nk on a single domain) */
+static void clamp_box(const float *before, float *after, int ni, int nj, int nk, int nkgb)
 {
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 1; k < nk - 1; k++)
+    for (int k = imax(1, KLO(1)); k < imin(nk - 1, KHI(nkgb - 1, nk)); k++)
         for (int j = 1; j < nj - 1; j++)
             for (int i = 1; i < ni - 1; i++) {
                 long id = IDX3(i, j, k, ni, nj);
@@ -374,6 +392,11 @@ void orc_clamp_extrema_box(const float *before, float *after, int ni, int nj, in
                         }
                 after[id] = fminf(fmaxf(mn, after[id]), mx);
             }
+}
+
+void orc_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
+{
+    clamp_box(before, after, ni, nj, nk, NKG(nk));
 }
 
 /* GPU_kernel.cu:586-598 */
@@ -440,9 +463,34 @@ void orc_compensate_velocity(float *u, float *v, float *w,
     cumulate_comp(u_src, u, b, h, ni, nj, nk, 1, 0, 0, is_point, -0.5f);
     cumulate_comp(v_src, v, b, h, ni, nj, nk, 0, 1, 0, is_point, -0.5f);
     cumulate_comp(w_src, w, b, h, ni, nj, nk, 0, 0, 1, is_point, -0.5f);
-    orc_clamp_extrema_box(du, u, ni + 1, nj, nk);
-    orc_clamp_extrema_box(dv, v, ni, nj + 1, nk);
-    orc_clamp_extrema_box(dw, w, ni, nj, nk + 1);
+    clamp_box(du, u, ni + 1, nj, nk, NKG(nk));
+    clamp_box(dv, v, ni, nj + 1, nk, NKG(nk));
+    clamp_box(dw, w, ni, nj, nk + 1, NKG(nk) + 1);
+}
+
+/* stage 1 of the two compensate operators on its own (GPU_kernel.cu:652-654 / :676), and the
+ * limiter for the w buffer: used by the host solver's four-stage form of the operator */
+void orc_compensate_error_velocity(const float *u, const float *v, const float *w,
+                                   const float *du, const float *dv, const float *dw,
+                                   float *u_src, float *v_src, float *w_src,
+                                   const float *fx, const float *fy, const float *fz,
+                                   float h, int ni, int nj, int nk, int is_point)
+{
+    map3 f = { fx, fy, fz };
+    compensate_comp(u, du, u_src, f, h, ni, nj, nk, 1, 0, 0, is_point);
+    compensate_comp(v, dv, v_src, f, h, ni, nj, nk, 0, 1, 0, is_point);
+    compensate_comp(w, dw, w_src, f, h, ni, nj, nk, 0, 0, 1, is_point);
+}
+void orc_compensate_error_field(const float *u, const float *du, float *u_src,
+                                const float *fx, const float *fy, const float *fz,
+                                float h, int ni, int nj, int nk, int is_point)
+{
+    map3 f = { fx, fy, fz };
+    compensate_comp(u, du, u_src, f, h, ni, nj, nk, 0, 0, 0, is_point);
+}
+void orc_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer)
+{
+    clamp_box(before, after, ni, nj, nk_buffer, NKG(nk_buffer - 1) + 1);
 }
 
 /* GPU_kernel.cu:668-682; the (ni+1)*nj*nk-sized copy of the reference (Q4) is not
@@ -456,7 +504,7 @@ void orc_compensate_field(float *u, float *du, float *u_src,
     compensate_comp(u, du, u_src, f, h, ni, nj, nk, 0, 0, 0, is_point);
     memcpy(du, u, sizeof(float) * (size_t)ni * nj * nk);
     cumulate_comp(u_src, u, b, h, ni, nj, nk, 0, 0, 0, is_point, -0.5f);
-    orc_clamp_extrema_box(du, u, ni, nj, nk);
+    clamp_box(du, u, ni, nj, nk, NKG(nk));
 }
 
 /* GPU_kernel.cu:684-696 */
@@ -488,10 +536,10 @@ void orc_estimate_distortion(float *dist,
 {
     map3 first = { xb, yb, zb }, second = { xf, yf, zf };
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < nk - 2; k++)
+    for (int k = KLO(2); k < KHI(NKG(nk) - 2, nk); k++)
         for (int j = 2; j < nj - 2; j++)
             for (int i = 2; i < ni - 2; i++) {
-                f3 pt = mk3(h * (float)i, h * (float)j, h * (float)k);
+                f3 pt = mk3(h * (float)i, h * (float)j, h * (float)(k + KOFF));
                 f3 back = map_at(first, ni, nj, nk, h, pt);
                 f3 fwd = map_at(second, ni, nj, nk, h, back);
                 float d_bf = (pt.x - fwd.x) * (pt.x - fwd.x) + (pt.y - fwd.y) * (pt.y - fwd.y)
@@ -513,10 +561,10 @@ void orc_semilag(float *field, const float *field_src,
     f3 org = mk3(-(float)dx * 0.5f * h, -(float)dy * 0.5f * h, -(float)dz * 0.5f * h);
     int bi = ni + dx, bj = nj + dy, bk = nk + dz;
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < bk - 2 - dz; k++)
+    for (int k = KLO(2); k < KHI(NKG(nk) - 2, bk); k++)
         for (int j = 2; j < bj - 2 - dy; j++)
             for (int i = 2; i < bi - 2 - dx; i++) {
-                f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+                f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)(k + KOFF) + org.z);
                 f3 pn = trace(u, v, w, h, ni, nj, nk, cfldt, dt, pt);
                 field[IDX3(i, j, k, bi, bj)] = sample(field_src, bi, bj, bk, h, org, pn);
             }
@@ -557,16 +605,16 @@ static inline float hypot2(float y, float z)
     return (float)sqrt((double)y * (double)y + (double)z * (double)z);
 }
 
-static void emit_velocity(float *field, float h, int ni, int nj, int nk,
+static void emit_velocity(float *field, float h, int ni, int nj, int nk, int nkgb,
                           float cx, float cy, float cz, float radius, float emiter)
 {
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < nk - 2; k++)
+    for (int k = KLO(2); k < KHI(nkgb - 2, nk); k++)
         for (int j = 2; j < nj - 2; j++)
             for (int i = 2; i < ni - 2; i++) {
                 float dxp = (float)(((double)(float)i - 0.5) * (double)h - (double)cx);
                 float dyp = (float)j * h - cy;
-                float dzp = (float)k * h - cz;
+                float dzp = (float)(k + KOFF) * h - cz;
                 if (norm3(dxp, dyp, dzp) < radius) {
                     float theta = acosf(dyp / hypot2(dyp, dzp));
                     float c8 = cosf((float)(8.0 * (double)theta));
@@ -581,10 +629,10 @@ static void emit_field(float *rho, float *T, float h, int ni, int nj, int nk,
                        float cx, float cy, float cz, float radius, float density, float temperature)
 {
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < nk - 2; k++)
+    for (int k = KLO(2); k < KHI(NKG(nk) - 2, nk); k++)
         for (int j = 2; j < nj - 2; j++)
             for (int i = 2; i < ni - 2; i++) {
-                float dxp = (float)i * h - cx, dyp = (float)j * h - cy, dzp = (float)k * h - cz;
+                float dxp = (float)i * h - cx, dyp = (float)j * h - cy, dzp = (float)(k + KOFF) * h - cz;
                 if (norm3(dxp, dyp, dzp) < radius) {
                     long id = IDX3(i, j, k, ni, nj);
                     rho[id] = density;
@@ -599,9 +647,9 @@ void orc_emit_smoke(float *u, float *v, float *w, float *rho, float *T,
                     float cx, float cy, float cz, float radius,
                     float density, float temperature, float emiter)
 {
-    emit_velocity(u, h, ni + 1, nj, nk, cx, cy, cz, radius, emiter);
-    emit_velocity(v, h, ni, nj + 1, nk, cx, cy, cz, radius, 0.f);
-    emit_velocity(w, h, ni, nj, nk + 1, cx, cy, cz, radius, 0.f);
+    emit_velocity(u, h, ni + 1, nj, nk, NKG(nk), cx, cy, cz, radius, emiter);
+    emit_velocity(v, h, ni, nj + 1, nk, NKG(nk), cx, cy, cz, radius, 0.f);
+    emit_velocity(w, h, ni, nj, nk + 1, NKG(nk) + 1, cx, cy, cz, radius, 0.f);
     emit_field(rho, T, h, ni, nj, nk, cx, cy, cz, radius, density, temperature);
 }
 
@@ -613,7 +661,7 @@ void orc_add_buoyancy(float *v, const float *rho, const float *T,
                       int ni, int nj, int nk, float alpha, float beta, float dt)
 {
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 0; k < nk; k++)
+    for (int k = KLO(0); k < KHI(NKG(nk), nk); k++)
         for (int j = 1; j < nj; j++)
             for (int i = 0; i < ni; i++) {
                 long c0 = IDX3(i, j, k, ni, nj), c1 = IDX3(i, j - 1, k, ni, nj);
@@ -630,10 +678,12 @@ void orc_diffuse_field(float *field, float *tmp0, float *tmp1,
 {
     size_t number = (size_t)ni * nj * nk;
     float *in = tmp0, *out = tmp1;
+    /* nk is a BUFFER dim (nk+1 for w): in slab mode the global plane count keeps that +1 */
+    const int nkgb = S_on ? S_nkg + (nk - S_nkl) : nk;
     memcpy(in, field, number * sizeof(float));
     for (int it = 0; it < iter; it++) {
 #pragma omp parallel for collapse(2) schedule(static)
-        for (int k = 1; k < nk - 1; k++)
+        for (int k = imax(1, KLO(1)); k < imin(nk - 1, KHI(nkgb - 1, nk)); k++)
             for (int j = 1; j < nj - 1; j++)
                 for (int i = 1; i < ni - 1; i++) {
                     long id = IDX3(i, j, k, ni, nj);
@@ -651,7 +701,7 @@ void orc_divergence(const float *u, const float *v, const float *w, float *div,
                     int ni, int nj, int nk, float halfrdx)
 {
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 0; k < nk; k++)
+    for (int k = KLO(0); k < KHI(NKG(nk), nk); k++)
         for (int j = 0; j < nj; j++)
             for (int i = 0; i < ni; i++) {
                 float ul = u[IDX3(i, j, k, ni + 1, nj)], ur = u[IDX3(i + 1, j, k, ni + 1, nj)];
@@ -667,7 +717,7 @@ void orc_jacobi_sweep(const float *p, const float *div, float *out,
 {
     long sj = ni, sk = (long)ni * nj;
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 1; k < nk - 1; k++)
+    for (int k = imax(1, KLO(1)); k < imin(nk - 1, KHI(NKG(nk) - 1, nk)); k++)
         for (int j = 1; j < nj - 1; j++)
             for (int i = 1; i < ni - 1; i++) {
                 long id = IDX3(i, j, k, ni, nj);
@@ -682,7 +732,7 @@ void orc_gradient(float *field, const float *p, int nbi, int nbj, int nbk,
 {
     int pi = nbi - dx, pj = nbj - dy, pk = nbk - dz;
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = 2; k < pk; k++)
+    for (int k = imax(dz, KLO(2)); k < KHI(NKG(pk), pk); k++)
         for (int j = 2; j < pj; j++)
             for (int i = 2; i < pi; i++) {
                 float p0 = p[IDX3(i, j, k, pi, pj)];
@@ -699,7 +749,7 @@ void orc_residual_norms(const float *div, const float *p, int ni, int nj, int nk
     long sj = ni, sk = (long)ni * nj;
     double ss = 0.0;
     float mx = 0.f;
-    for (int k = 1; k < nk - 1; k++)
+    for (int k = imax(1, KLO(S_on ? imax(1, S_own0) : 1)); k < imin(nk - 1, KHI(S_on ? imin(S_nkg - 1, S_own1) : nk - 1, nk)); k++)
         for (int j = 1; j < nj - 1; j++)
             for (int i = 1; i < ni - 1; i++) {
                 long id = IDX3(i, j, k, ni, nj);
@@ -747,10 +797,15 @@ void orc_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
 float orc_max_abs3(const float *u, const float *v, const float *w, int ni, int nj, int nk)
 {
     float m = 1e-4f;
-    size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
-    for (size_t i = 0; i < nu; i++) if (fabsf(u[i]) > m) m = fabsf(u[i]);
-    for (size_t i = 0; i < nv; i++) if (fabsf(v[i]) > m) m = fabsf(v[i]);
-    for (size_t i = 0; i < nw; i++) if (fabsf(w[i]) > m) m = fabsf(w[i]);
+    /* a slab rank scans the planes it owns (the last rank also owns w's top plane); the caller all-reduces */
+    const int p0 = S_on ? S_own0 - S_koff : 0, p1 = S_on ? S_own1 - S_koff : nk;
+    const int wtop = (!S_on || S_own1 == S_nkg) ? 1 : 0;
+    size_t pu = (size_t)(ni + 1) * nj, pv = (size_t)ni * (nj + 1), pw = (size_t)ni * nj;
+    const float *u0 = u + pu * p0, *v0 = v + pv * p0, *w0 = w + pw * p0;
+    size_t nu = pu * (p1 - p0), nv = pv * (p1 - p0), nw = pw * (p1 - p0 + wtop);
+    for (size_t i = 0; i < nu; i++) if (fabsf(u0[i]) > m) m = fabsf(u0[i]);
+    for (size_t i = 0; i < nv; i++) if (fabsf(v0[i]) > m) m = fabsf(v0[i]);
+    for (size_t i = 0; i < nw; i++) if (fabsf(w0[i]) > m) m = fabsf(w0[i]);
     return m;
 }
 
@@ -776,6 +831,7 @@ struct orc_solver {
     float *u_src, *v_src, *w_src, *xo, *yo, *zo;
     mapper_t vel, scal;
     int vel_last, scal_last;        /* BimocqGPUSolver.h:109-110 */
+    int keep_dmc_border;            /* 0 = reference (border of the DMC scratch is zero), 1 = keep */
     orc_emitter *em; int n_em;
     float last_cfldt;
 };
@@ -853,6 +909,11 @@ void orc_solver_set_smoke(orc_solver *s, float drop_alpha, float rise_beta,
     s->n_em = n_emitters;
 }
 
+void orc_solver_set_option(orc_solver *s, int option, int value)
+{
+    if (option == 1) s->keep_dmc_border = value != 0;
+}
+
 void orc_solver_set_projection(orc_solver *s, int jacobi_iters, float halfrdx)
 {
     s->jacobi_iters = jacobi_iters; s->halfrdx = halfrdx;
@@ -865,6 +926,11 @@ static void mapper_update(orc_solver *s, mapper_t *m, float cfldt, float dt)
     float T = 0.f, substep = cfldt;
     while (T < dt) {
         if (T + substep > dt) substep = dt - T;
+        if (s->keep_dmc_border) {   /* the pre-copy the reference has commented out (GPU_Advection.h:335-337) */
+            memcpy(s->xo, m->bx, s->n * sizeof(float));
+            memcpy(s->yo, m->by, s->n * sizeof(float));
+            memcpy(s->zo, m->bz, s->n * sizeof(float));
+        }
         orc_solve_backwardDMC(s->U, s->V, s->W, m->bx, m->by, m->bz, s->xo, s->yo, s->zo,
                               s->h, s->ni, s->nj, s->nk, substep);
         memcpy(m->bx, s->xo, s->n * sizeof(float));
@@ -996,10 +1062,10 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
 const float *orc_solver_field(orc_solver *s, int which, long *count)
 {
     const float *f[] = { s->rho, s->T, s->U, s->V, s->W, s->Ui, s->Vi, s->Wi, s->rhoi, s->Ti,
-                         s->vel.fx, s->vel.fy, s->vel.fz, s->vel.bx, s->vel.by, s->vel.bz, s->p };
+                         s->vel.fx, s->vel.fy, s->vel.fz, s->vel.bx, s->vel.by, s->vel.bz, s->p, s->div };
     size_t c[] = { s->n, s->n, s->nu, s->nv, s->nw, s->nu, s->nv, s->nw, s->n, s->n,
-                   s->n, s->n, s->n, s->n, s->n, s->n, s->n };
-    if (which < 0 || which > 16) { if (count) *count = 0; return NULL; }
+                   s->n, s->n, s->n, s->n, s->n, s->n, s->n, s->n };
+    if (which < 0 || which > 17) { if (count) *count = 0; return NULL; }
     if (count) *count = (long)c[which];
     return f[which];
 }

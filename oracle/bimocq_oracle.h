@@ -31,6 +31,11 @@
 extern "C" {
 #endif
 
+/* z-slab context (mirror of fl_set_slab, include/bimocq_gpu.h section 4): the buffers of every
+ * following call hold the global planes [koff, koff + nk_local) of a grid with nk_global cell
+ * planes, of which [own0, own1) are owned.  nk_global <= 0 switches back to a single domain. */
+void orc_set_slab(int koff, int nk_global, int own0, int own1, int nk_local);
+
 /* ---- math helpers exposed for tests ---- */
 float orc_expf(float x);
 float orc_lerp(float a, float b, float c);
@@ -83,6 +88,15 @@ void orc_compensate_field(float *u, float *du, float *u_src,
                           const float *fx, const float *fy, const float *fz,
                           const float *bx, const float *by, const float *bz,
                           float h, int ni, int nj, int nk, int is_point);
+void orc_compensate_error_velocity(const float *u, const float *v, const float *w,
+                                   const float *du, const float *dv, const float *dw,
+                                   float *u_src, float *v_src, float *w_src,
+                                   const float *fx, const float *fy, const float *fz,
+                                   float h, int ni, int nj, int nk, int is_point);
+void orc_compensate_error_field(const float *u, const float *du, float *u_src,
+                                const float *fx, const float *fy, const float *fz,
+                                float h, int ni, int nj, int nk, int is_point);
+void orc_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
 void orc_semilag(float *field, const float *field_src,
                  const float *u, const float *v, const float *w,
                  int dim_x, int dim_y, int dim_z,
@@ -128,6 +142,8 @@ void  orc_solver_destroy(orc_solver *s);
 void  orc_solver_set_smoke(orc_solver *s, float drop_alpha, float rise_beta,
                            const orc_emitter *emitters, int n_emitters);
 void  orc_solver_set_projection(orc_solver *s, int jacobi_iters, float halfrdx);
+/* option 1: keep the backward map's border through the DMC update (0 = reference behaviour) */
+void  orc_solver_set_option(orc_solver *s, int option, int value);
 void  orc_solver_advance(orc_solver *s, int framenum, float dt);
 /* which: 0 rho, 1 T, 2 u, 3 v, 4 w, 5 uinit, 6 vinit, 7 winit, 8 rhoinit, 9 Tinit,
  *        10..12 forward xyz (velocity mapper), 13..15 backward xyz, 16 p          */

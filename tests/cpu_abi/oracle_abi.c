@@ -114,17 +114,61 @@ void gpu_multi_grid_conjugate_gradient(float *a, float *b, float *c, double *d, 
 { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m; (void)n;
   latch(FL_ERR_UNSUPPORTED, "gpu_multi_grid_conjugate_gradient"); }
 
+/* ---- slab context + communicator (mirrors csrc/bq_halo.hip with the custom transport only) ---- */
+static int s_on, s_koff, s_nkg;
+static int c_rank, c_nranks = 1;
+static fl_exchange_cb c_exchange;
+static fl_allreduce_cb c_allreduce;
+
+void fl_report_error(int code, const char *text) { latch(code, text ? text : ""); }
+void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
+{
+    s_on = nk_global > 0; s_koff = koff; s_nkg = nk_global;
+    orc_set_slab(koff, nk_global, own0, own1, nk_local);
+}
+int fl_comm_unique_id(void *id128) { memset(id128, 0, 128); return FL_OK; }
+int fl_comm_init(const void *id128, int rank, int nranks) { (void)id128; (void)rank; if (nranks > 1) latch(FL_ERR_COMM, "no RCCL in the CPU stand-in"); return g_err; }
+void fl_comm_destroy(void) { c_rank = 0; c_nranks = 1; c_exchange = NULL; c_allreduce = NULL; }
+int fl_comm_rank(void) { return c_rank; }
+int fl_comm_size(void) { return c_nranks; }
+void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb ex, fl_allreduce_cb ar)
+{ c_rank = rank; c_nranks = nranks; c_exchange = ex; c_allreduce = ar; }
+void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, const int *extra,
+                      int nk_local, int G, int depth, int wait)
+{
+    (void)wait;
+    if (c_nranks <= 1) return;
+    if (!c_exchange) { latch(FL_ERR_COMM, "fl_halo_exchange: no transport"); return; }
+    c_exchange(n, fields, plane_elems, extra, nk_local, G, depth);
+}
+void fl_halo_wait(void) {}
+
 void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk)
 {
     for (int k = 0; k < nk; k++)
         for (int j = 0; j < nj; j++)
             for (int i = 0; i < ni; i++) {
                 size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
-                x[id] = (float)i * h; y[id] = (float)j * h; z[id] = (float)k * h;
+                int kg = k + (s_on ? s_koff : 0);
+                int in = !s_on || (kg >= 0 && kg < s_nkg);
+                x[id] = in ? (float)i * h : 0.f; y[id] = in ? (float)j * h : 0.f; z[id] = in ? (float)kg * h : 0.f;
             }
 }
 float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int nj, int nk)
-{ return orc_max_abs3(u, v, w, ni, nj, nk); }
+{
+    float m = orc_max_abs3(u, v, w, ni, nj, nk);
+    if (c_nranks > 1 && c_allreduce) c_allreduce(&m, 1, 0, 1);
+    return m;
+}
+void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+                                   float *us, float *vs, float *ws, float *fx, float *fy, float *fz,
+                                   float h, int ni, int nj, int nk, bool pt)
+{ orc_compensate_error_velocity(u, v, w, du, dv, dw, us, vs, ws, fx, fy, fz, h, ni, nj, nk, pt); }
+void gpu_compensate_error_field(float *u, float *du, float *us, float *fx, float *fy, float *fz,
+                                float h, int ni, int nj, int nk, bool pt)
+{ orc_compensate_error_field(u, du, us, fx, fy, fz, h, ni, nj, nk, pt); }
+void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
+{ orc_clamp_extrema_box_w(before, after, ni, nj, nk); }
 void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float hr)
 { orc_divergence(u, v, w, div, ni, nj, nk, hr); }
 int gpu_jacobi_sweeps(float *p, const float *div, float *pt, int ni, int nj, int nk, int sweeps, float alpha, float beta)

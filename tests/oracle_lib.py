@@ -62,6 +62,7 @@ _SIGS = {
     "orc_solver_destroy": (None, [C.c_void_p]),
     "orc_solver_set_smoke": (None, [C.c_void_p, c_f, c_f, C.POINTER(Emitter), c_i]),
     "orc_solver_set_projection": (None, [C.c_void_p, c_i, c_f]),
+    "orc_solver_set_option": (None, [C.c_void_p, c_i, c_i]),
     "orc_solver_advance": (None, [C.c_void_p, c_i, c_f]),
     "orc_solver_field": (FP, [C.c_void_p, c_i, C.POINTER(C.c_long)]),
     "orc_solver_last_cfldt": (c_f, [C.c_void_p]),
@@ -89,7 +90,7 @@ def fp(a):
 
 
 FIELD_IDS = {"rho": 0, "T": 1, "u": 2, "v": 3, "w": 4, "uinit": 5, "vinit": 6, "winit": 7,
-             "rhoinit": 8, "Tinit": 9, "fx": 10, "fy": 11, "fz": 12, "bx": 13, "by": 14, "bz": 15, "p": 16}
+             "rhoinit": 8, "Tinit": 9, "fx": 10, "fy": 11, "fz": 12, "bx": 13, "by": 14, "bz": 15, "p": 16, "div": 17}
 
 
 class OracleSolver:
@@ -109,6 +110,9 @@ class OracleSolver:
 
     def set_projection(self, iters, halfrdx):
         self.l.orc_solver_set_projection(self.s, iters, halfrdx)
+
+    def set_option(self, option, value):
+        self.l.orc_solver_set_option(self.s, option, value)
 
     def advance(self, frame, dt):
         self.l.orc_solver_advance(self.s, frame, dt)
