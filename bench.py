@@ -10,7 +10,7 @@ A "step" is one BimocqGPUSolver::advance(): map update, advection with error com
 projection (divergence, Jacobi sweeps, gradient), accumulation, re-initialisation -- all resident in
 HBM; nothing crosses PCIe inside the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--jacobi-iters 200]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--jacobi-iters 200]
 
 N > 1: launched by torch.distributed.run, one rank per GPU (see DESIGN.md "Multi-GPU").
 """
@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=256, help="grid is n^3 (per rank when --gpus > 1)")
+    ap.add_argument("--size", dest="n", type=int, default=256, help="grid is size^3 (per rank when --gpus > 1)")
     ap.add_argument("--jacobi-iters", type=int, default=200)
     ap.add_argument("--halfrdx", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,6 +97,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        if args.transport != "host":
+            sys.exit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
+        local_rank %= torch.cuda.device_count()         # debug transport: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
