@@ -94,8 +94,24 @@ __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v
     xo[id] = r.x; yo[id] = r.y; zo[id] = r.z;
 }
 
+// The 9 mapped positions of a node: out[0..7] corners (reference order), out[8] centre.  SD >= 0 selects
+// the structured power-of-two path (SD = staggered axis + 1, 0 = none); SD < 0 the generic one.
+template <bool P2, bool PT, int SD>
+__device__ __forceinline__ void mapped9(const Map3 &m, const Spacing &sp, const Nine &n, f3 c, int i, int j, int kl, f3 out[9])
+{
+    if constexpr (P2 && !PT && SD >= 0) {
+        map9<SD == 1, SD == 2, SD == 3>(m, i, j, kl, out);
+    } else {
+        if (!PT) {
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) out[ii] = map_at<P2>(m, sp, nine_corner(n, c, ii));
+        }
+        out[8] = map_at<P2>(m, sp, c);
+    }
+}
+
 // ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
-template <bool P2, bool PT>
+template <bool P2, bool PT, int SD>
 __global__ __launch_bounds__(256) void advect_kernel(float *field, const float *field_init,
                                                      const float *bx, const float *by, const float *bz,
                                                      Spacing sp, Grid g, int dx, int dy, int dz)
@@ -109,24 +125,21 @@ __global__ __launch_bounds__(256) void advect_kernel(float *field, const float *
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
     f3 c = nine_centre(n, i, j, kg);
+    f3 mp[9];
+    mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
     float sum = 0.f;
     if (PT) {
-        f3 p0 = clamp3(map_at<P2>(back, sp, c), lo, hi);
-        sum += 1.0f * sample<P2>(src, sp, n.org, p0);
+        sum += 1.0f * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
     } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ii++) {
-            f3 p0 = clamp3(map_at<P2>(back, sp, nine_corner(n, c, ii)), lo, hi);
-            sum += 0.125f * sample<P2>(src, sp, n.org, p0);
-        }
+        for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, clamp3(mp[ii], lo, hi));
     }
-    f3 pc = clamp3(map_at<P2>(back, sp, c), lo, hi);
-    float value = sample<P2>(src, sp, n.org, pc);
+    float value = sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
     field[(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum + 0.5f * value;
 }
 
 // ---- A7: doubleAdvect_kernel (GPU_kernel.cu:236-310) --------------------------------------
-template <bool P2, bool PT>
+template <bool P2, bool PT, int SD>
 __global__ __launch_bounds__(256) void double_advect_kernel(float *field, const float *prev,
                                                             const float *bx, const float *by, const float *bz,
                                                             const float *px, const float *py, const float *pz,
@@ -142,21 +155,20 @@ __global__ __launch_bounds__(256) void double_advect_kernel(float *field, const 
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
     f3 c = nine_centre(n, i, j, kg);
+    f3 mp[9];
+    mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
     float sum = 0.f;
     if (PT) {
-        f3 mid = clamp3(map_at<P2>(back, sp, c), lo, hi);
-        f3 fin = clamp3(map_at<P2>(bprev, sp, mid), lo, hi);
+        f3 fin = clamp3(map_at<P2>(bprev, sp, clamp3(mp[8], lo, hi)), lo, hi);
         sum += 1.0f * sample<P2>(src, sp, n.org, fin);
     } else {
 #pragma unroll
         for (int ii = 0; ii < 8; ii++) {
-            f3 mid = clamp3(map_at<P2>(back, sp, nine_corner(n, c, ii)), lo, hi);
-            f3 fin = clamp3(map_at<P2>(bprev, sp, mid), lo, hi);
+            f3 fin = clamp3(map_at<P2>(bprev, sp, clamp3(mp[ii], lo, hi)), lo, hi);
             sum += 0.125f * sample<P2>(src, sp, n.org, fin);
         }
     }
-    f3 mid = clamp3(map_at<P2>(back, sp, c), lo, hi);
-    f3 fin = clamp3(map_at<P2>(bprev, sp, mid), lo, hi);
+    f3 fin = clamp3(map_at<P2>(bprev, sp, clamp3(mp[8], lo, hi)), lo, hi);
     float value = sample<P2>(src, sp, n.org, fin);
     float prev_value = 0.5f * (sum + value);
     size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 }
 
 // ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
-template <bool P2, bool PT>
+template <bool P2, bool PT, int SD>
 __global__ __launch_bounds__(256) void cumulate_kernel(const float *srcp, float *dst,
                                                        const float *mx, const float *my, const float *mz,
                                                        Spacing sp, Grid g, int dx, int dy, int dz, float coeff)
@@ -188,26 +200,23 @@ __global__ __launch_bounds__(256) void cumulate_kernel(const float *srcp, float 
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
+    f3 mp[9];
+    mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
     float sum = 0.f;
     if (PT) {
-        f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
-        sum += 1.0f * coeff * sample<P2>(src, sp, n.org, mp);
+        sum += 1.0f * coeff * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
     } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ii++) {
-            f3 mp = clamp3(map_at<P2>(m, sp, nine_corner(n, c, ii)), lo, hi);
-            sum += 0.125f * coeff * sample<P2>(src, sp, n.org, mp);
-        }
+        for (int ii = 0; ii < 8; ii++) sum += 0.125f * coeff * sample<P2>(src, sp, n.org, clamp3(mp[ii], lo, hi));
     }
-    f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
-    float value = coeff * sample<P2>(src, sp, n.org, mp);
+    float value = coeff * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
     sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
     size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     dst[id] += sum;
 }
 
 // ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
-template <bool P2, bool PT>
+template <bool P2, bool PT, int SD>
 __global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, const float *init, float *err,
                                                          const float *mx, const float *my, const float *mz,
                                                          Spacing sp, Grid g, int dx, int dy, int dz)
@@ -221,19 +230,16 @@ __global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, cons
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
+    f3 mp[9];
+    mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
     float sum = 0.f;
     if (PT) {
-        f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
-        sum += 1.0f * sample<P2>(src, sp, n.org, mp);
+        sum += 1.0f * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
     } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ii++) {
-            f3 mp = clamp3(map_at<P2>(m, sp, nine_corner(n, c, ii)), lo, hi);
-            sum += 0.125f * sample<P2>(src, sp, n.org, mp);
-        }
+        for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, clamp3(mp[ii], lo, hi));
     }
-    f3 mp = clamp3(map_at<P2>(m, sp, c), lo, hi);
-    float value = sample<P2>(src, sp, n.org, mp);
+    float value = sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
     sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
     size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     err[id] = sum - init[id];
@@ -323,13 +329,23 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
     return true;
 }
 
-#define BQ_DISPATCH2(KERNEL, P2V, PTV, GRID, ...)                                                           \
+// SDV: staggered axis + 1 (0 = none) -> structured power-of-two map look-up when the spacing allows it
+// (FL_OPT_STRUCTURED_MAPS, default on); every other case takes the generic path (SD = -1).
+#define BQ_DISPATCH2(KERNEL, P2V, PTV, SDV, GRID, ...)                                                      \
     do {                                                                                                    \
         hipStream_t st_ = rt().compute;                                                                     \
-        if (P2V) { if (PTV) KERNEL<true, true><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);                      \
-                   else     KERNEL<true, false><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); }                   \
-        else     { if (PTV) KERNEL<false, true><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);                     \
-                   else     KERNEL<false, false><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); }                  \
+        if ((P2V) && !(PTV) && rt().opt_structured_maps) {                                                  \
+            switch (SDV) {                                                                                  \
+            case 0:  KERNEL<true, false, 0><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); break;                  \
+            case 1:  KERNEL<true, false, 1><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); break;                  \
+            case 2:  KERNEL<true, false, 2><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); break;                  \
+            default: KERNEL<true, false, 3><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); break;                  \
+            }                                                                                               \
+        }                                                                                                   \
+        else if (P2V) { if (PTV) KERNEL<true, true, -1><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);             \
+                        else     KERNEL<true, false, -1><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); }          \
+        else          { if (PTV) KERNEL<false, true, -1><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__);            \
+                        else     KERNEL<false, false, -1><<<GRID, kBlock, 0, st_>>>(__VA_ARGS__); }         \
         BQ_LAUNCH_CHECK(#KERNEL);                                                                           \
     } while (0)
 
@@ -344,17 +360,17 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
 static void advect_comp(float *f, const float *init, const float *bx, const float *by, const float *bz,
                         Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
-    BQ_DISPATCH2(advect_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, init, bx, by, bz, sp, g, dx, dy, dz);
+    BQ_DISPATCH2(advect_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, init, bx, by, bz, sp, g, dx, dy, dz);
 }
 static void cumulate_comp(const float *src, float *dst, const float *mx, const float *my, const float *mz,
                           Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float coeff)
 {
-    BQ_DISPATCH2(cumulate_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, dst, mx, my, mz, sp, g, dx, dy, dz, coeff);
+    BQ_DISPATCH2(cumulate_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, dst, mx, my, mz, sp, g, dx, dy, dz, coeff);
 }
 static void compensate_comp(const float *src, const float *init, float *err, const float *mx, const float *my, const float *mz,
                             Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
-    BQ_DISPATCH2(compensate_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, init, err, mx, my, mz, sp, g, dx, dy, dz);
+    BQ_DISPATCH2(compensate_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, init, err, mx, my, mz, sp, g, dx, dy, dz);
 }
 static void double_comp(float *f, const float *prev, const float *bx, const float *by, const float *bz,
                         const float *px, const float *py, const float *pz,
@@ -365,7 +381,7 @@ static void double_comp(float *f, const float *prev, const float *bx, const floa
         BQ_LAUNCH_CHECK("unit_blend_kernel");
         return;
     }
-    BQ_DISPATCH2(double_advect_kernel, sp.pow2, pt, grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, prev, bx, by, bz, px, py, pz, sp, g, dx, dy, dz, blend);
+    BQ_DISPATCH2(double_advect_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, prev, bx, by, bz, px, py, pz, sp, g, dx, dy, dz, blend);
 }
 // nk: local buffer planes; dz: 1 for the w buffer (its global plane count is nkg + 1)
 static void clamp_box(const float *before, float *after, int ni, int nj, int nk, int dz)

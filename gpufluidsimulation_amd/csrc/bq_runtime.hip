@@ -197,6 +197,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_PROFILE_JACOBI:  g_rt.opt_profile_jacobi = value ? 1 : 0; break;
     case FL_OPT_JACOBI_KCHUNK:   g_rt.opt_jacobi_kchunk = value < 0 ? 0 : value; break;
     case FL_OPT_JACOBI_ROWS:     g_rt.opt_jacobi_rows = value; break;
+    case FL_OPT_STRUCTURED_MAPS: g_rt.opt_structured_maps = value ? 1 : 0; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -210,6 +211,7 @@ int fl_get_option(int option)
     case FL_OPT_PROFILE_JACOBI:  return g_rt.opt_profile_jacobi;
     case FL_OPT_JACOBI_KCHUNK:   return g_rt.opt_jacobi_kchunk;
     case FL_OPT_JACOBI_ROWS:     return g_rt.opt_jacobi_rows;
+    case FL_OPT_STRUCTURED_MAPS: return g_rt.opt_structured_maps;
     default: return -1;
     }
 }

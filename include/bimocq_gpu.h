@@ -228,7 +228,8 @@ enum {
     FL_OPT_JACOBI_VARIANT  = 3, /* 0 = auto, 1 = generic scalar kernel, 2 = LDS-tiled kernel      */
     FL_OPT_PROFILE_JACOBI  = 4, /* record a hipEvent pair around each projection's sweep loop      */
     FL_OPT_JACOBI_KCHUNK   = 5, /* planes marched per block in the tiled kernel (0 = auto)         */
-    FL_OPT_JACOBI_ROWS     = 6  /* float4 rows per thread in the tiled kernel: 1, 2, 4 (0 = auto)  */
+    FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread in the tiled kernel: 1, 2, 4 (0 = auto)  */
+    FL_OPT_STRUCTURED_MAPS = 7  /* 9-point kernels: compile-time taps when h is a power of two (1)  */
 };
 void fl_set_option(int option, int value);
 int  fl_get_option(int option);
