@@ -59,7 +59,7 @@ HIP_SIGS = {
     "fl_compute_stream": (VP, []),
     "fl_set_option": (None, [c_i, c_i]),
     "fl_get_option": (c_i, [c_i]),
-    "fl_jacobi_profile": (None, [C.POINTER(c_d), C.POINTER(C.c_longlong)]),
+    "fl_jacobi_profile": (None, [C.POINTER(c_d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     # 3. additive
     "gpu_init_maps": (None, [VP, VP, VP] + _G),
     "gpu_max_abs3": (c_f, [VP, VP, VP, c_i, c_i, c_i]),
@@ -87,6 +87,7 @@ HIP_SIGS = {
 FL_OK, FL_ERR_NO_DEVICE, FL_ERR_HIP, FL_ERR_BAD_ARGUMENT, FL_ERR_UNSUPPORTED, FL_ERR_COMM = range(6)
 FL_OPT_RESIDUAL_STRIDE, FL_OPT_SKIP_UNIT_BLEND, FL_OPT_JACOBI_VARIANT = 1, 2, 3
 FL_OPT_PROFILE_JACOBI, FL_OPT_JACOBI_KCHUNK, FL_OPT_JACOBI_ROWS, FL_OPT_STRUCTURED_MAPS = 4, 5, 6, 7
+FL_OPT_JACOBI_FUSE, FL_OPT_JACOBI_KCHUNK2 = 8, 9
 
 
 class BimocqLibraryMissing(RuntimeError):

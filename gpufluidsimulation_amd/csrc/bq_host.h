@@ -18,7 +18,9 @@ struct Runtime {
     int         opt_skip_unit_blend = 1;
     int         opt_jacobi_variant = 0;
     int         opt_profile_jacobi = 0;
-    int         opt_structured_maps = 1;    // structured (compile-time taps) map look-up on power-of-two spacing
+    int         opt_structured_maps = 1;
+    int         opt_jacobi_fuse = 1;        // 0 never, 1 inside gpu_projection_jacobi, 2 also in gpu_jacobi_sweeps
+    int         opt_jacobi_kchunk2 = 0;     // planes per block of the fused kernel (0 = auto)    // structured (compile-time taps) map look-up on power-of-two spacing
     int         opt_jacobi_kchunk = 0;      // 0 = auto
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;

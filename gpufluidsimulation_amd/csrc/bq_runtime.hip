@@ -198,6 +198,8 @@ void fl_set_option(int option, int value)
     case FL_OPT_JACOBI_KCHUNK:   g_rt.opt_jacobi_kchunk = value < 0 ? 0 : value; break;
     case FL_OPT_JACOBI_ROWS:     g_rt.opt_jacobi_rows = value; break;
     case FL_OPT_STRUCTURED_MAPS: g_rt.opt_structured_maps = value ? 1 : 0; break;
+    case FL_OPT_JACOBI_FUSE:     g_rt.opt_jacobi_fuse = value; break;
+    case FL_OPT_JACOBI_KCHUNK2:  g_rt.opt_jacobi_kchunk2 = value < 0 ? 0 : value; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -212,6 +214,8 @@ int fl_get_option(int option)
     case FL_OPT_JACOBI_KCHUNK:   return g_rt.opt_jacobi_kchunk;
     case FL_OPT_JACOBI_ROWS:     return g_rt.opt_jacobi_rows;
     case FL_OPT_STRUCTURED_MAPS: return g_rt.opt_structured_maps;
+    case FL_OPT_JACOBI_FUSE:     return g_rt.opt_jacobi_fuse;
+    case FL_OPT_JACOBI_KCHUNK2:  return g_rt.opt_jacobi_kchunk2;
     default: return -1;
     }
 }

@@ -49,7 +49,8 @@ void fl_clear_error(void) { g_err = FL_OK; g_text[0] = 0; }
 void *fl_compute_stream(void) { return NULL; }
 void fl_set_option(int option, int value) { if (option >= 0 && option < 8) g_opt[option] = value; }
 int fl_get_option(int option) { return (option >= 0 && option < 8) ? g_opt[option] : -1; }
-void fl_jacobi_profile(double *total_ms, long long *launches) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; }
+void fl_jacobi_profile(double *total_ms, long long *launches, long long *sweeps)
+{ if (total_ms) *total_ms = 0; if (launches) *launches = 0; if (sweeps) *sweeps = 0; }
 
 void gpu_solve_forward(float *u, float *v, float *w, float *x, float *y, float *z,
                        float h, int ni, int nj, int nk, float cfldt, float dt)

@@ -40,13 +40,17 @@ def main():
     if a.variants:
         variants = [tuple(int(x) for x in v.split(":")) for v in a.variants.split(",")]
     else:
-        variants = [(1, 0, 0), (2, 1, 16), (2, 2, 8)] + [(3, w, k) for w in (4, 8, 16) for k in (4, 8, 16, 32, 64, 256)]
+        variants = [(1, 0, 0), (2, 2, 8), (3, 4, 16)] + [(4, 0, k) for k in (8, 16, 32, 64, 128)]
     res = {v: [] for v in variants}
     for rep in range(a.reps + 1):
         for v in variants:
-            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, v[0])
-            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, v[1])
-            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, v[2])
+            # variant 4 = two sweeps per launch (fused kernel) with kchunk v[2]
+            fused = v[0] == 4
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0 if fused else v[0])
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2 if fused else 0)
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0 if fused else v[1])
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0 if fused else v[2])
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, v[2] if fused else 0)
             lib.fl_event_record(e0)
             lib.gpu_jacobi_sweeps(p.ptr, d.ptr, t.ptr, nx, ny, nz, a.sweeps, -1.0, 1.0 / 6.0)
             lib.fl_event_record(e1)
