@@ -12,8 +12,10 @@
 
 namespace bq {
 
-// z-slab context of a launch: local plane k is global plane k + koff; nkg = global cell planes.
-struct Slab { int koff, nkg; };
+// z-slab context of a launch: local plane k is global plane k + koff; nkg = global cell planes;
+// [klo, khi): optional restriction of a stencil launch to a range of LOCAL planes (used to sweep the
+// slab interior while the ghost planes are still in flight).
+struct Slab { int koff, nkg, klo, khi; };
 
 // ---- divergence_kernel (GPU_kernel.cu:967-985) --------------------------------------------
 __global__ __launch_bounds__(256) void divergence_kernel(const float *__restrict__ u, const float *__restrict__ v,
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void jacobi_generic_kernel(const float *__rest
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     const int kg = k + sl.koff;
-    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1 && kg > 0 && kg < sl.nkg - 1)) return;
+    if (!(i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1 && kg > 0 && kg < sl.nkg - 1 && k >= sl.klo && k < sl.khi)) return;
     const size_t sj = ni, sk = (size_t)ni * nj;
     const size_t id = (size_t)i + sj * j + sk * k;
     out[id] = (p[id - 1] + p[id + 1] + p[id - sj] + p[id + sj] + p[id - sk] + p[id + sk] + alpha * div[id]) * beta;
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256) void jacobi_tile_kernel(const float *__restric
     const int lx = tid % TXV, rp = tid / TXV;
     const int x0 = blockIdx.x * T::TX, j0 = blockIdx.y * T::TY;
     // local planes 1..nz-2 that are interior planes of the GLOBAL grid
-    const int kbeg = max(max(1, 1 - sl.koff), (int)blockIdx.z * kchunk);
-    const int kend = min(min(nz - 1, sl.nkg - 1 - sl.koff), (int)blockIdx.z * kchunk + kchunk);
+    const int kbeg = max(max(max(1, 1 - sl.koff), sl.klo), (int)blockIdx.z * kchunk);
+    const int kend = min(min(min(nz - 1, sl.nkg - 1 - sl.koff), sl.khi), (int)blockIdx.z * kchunk + kchunk);
     if (kbeg >= kend) return;
 
     const int x = x0 + 4 * lx;                  // first column of this thread's float4 (nx % 4 == 0)
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
     const int rows = (WAVES * 64) / cw;             // rows of the tile (cw float4 columns each)
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
     const int x = (bx * cw + c) * 4, j = by * rows + r;
-    const int kbeg = max(max(1, 1 - sl.koff), bz * kchunk), kend = min(min(nz - 1, sl.nkg - 1 - sl.koff), bz * kchunk + kchunk);
+    const int kbeg = max(max(max(1, 1 - sl.koff), sl.klo), bz * kchunk);
+    const int kend = min(min(min(nz - 1, sl.nkg - 1 - sl.koff), sl.khi), bz * kchunk + kchunk);
     if (kbeg >= kend) return;
     const bool active = x < nx && j >= 1 && j <= ny - 2;
     const size_t sj = nx, sk = (size_t)nx * ny;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                    float *__restrict__ out, int nx, int ny, int nz,
-                                                                   int cw, int nby, int kchunk, float alpha, float beta)
+                                                                   int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
 {
     const int nblk = gridDim.x;
     int b = blockIdx.x;
@@ -298,7 +301,10 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     const int rows = (WAVES * 64) / cw;
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
     const int x = 4 * c, j = by * rows + r;
-    const int kbeg = max(1, bz * kchunk), kend = min(nz - 1, bz * kchunk + kchunk);
+    // local planes a sweep may update: inside the array AND inside the global domain (z-slab ranks);
+    // everything else counts as boundary and keeps its input value in L1
+    const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
     if (kbeg >= kend) return;
     const bool xok = x < nx;
     const bool active = xok && j >= 1 && j <= ny - 2;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
             Hb2 = ld4(p, j + 2, q + 1);
         }
         // L1 on plane q for rows j-1, j, j+1
-        const bool qb = q <= 0 || q >= nz - 1;
+        const bool qb = q < kA || q >= kB;
         float4 M[3];
         M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], qb || j - 1 <= 0 || j - 1 >= ny - 1);
         M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], qb || j <= 0 || j >= ny - 1);
@@ -472,11 +478,13 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
     return true;
 }
 
+static int g_klo = 0, g_khi = 1 << 30;      // plane range of the next sweep launches (gpu_jacobi_sweep_range)
+
 static inline Slab slab_of(int nk)
 {
     const Runtime &r = rt();
-    if (r.slab_on) return Slab{r.slab_koff, r.slab_nkg};
-    return Slab{0, nk};
+    if (r.slab_on) return Slab{r.slab_koff, r.slab_nkg, g_klo, g_khi};
+    return Slab{0, nk, g_klo, g_khi};
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
@@ -544,7 +552,6 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     if (ni < 3 || nj < 3 || nk < 3) return false;
     const int variant = rt().opt_jacobi_variant;
     if (variant != 0 && variant != 3) return false;
-    if (rt().slab_on) return false;
     if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
     int cw = 16;
     while (cw * 4 < ni) cw *= 2;                         // <= 64: one row per wave at most
@@ -553,7 +560,7 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 32;
     while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
     const int nbz = (nk + kchunk - 1) / kchunk;
-    jacobi_march2_kernel<4><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta);
+    jacobi_march2_kernel<4><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
     return true;
 }
@@ -628,6 +635,18 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *p_temp, int ni, int nj,
         float *t = in; in = out; out = t;
     }
     return in == p ? 0 : 1;
+}
+
+// one sweep in -> out restricted to the local planes [k_begin, k_end) (clipped to the interior)
+void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                            int k_begin, int k_end, float alpha, float beta)
+{
+    BQ_ENTER("gpu_jacobi_sweep_range", in, div, out)
+    BQ_REQUIRE(in != out, "gpu_jacobi_sweep_range");
+    if (k_begin >= k_end) return;
+    g_klo = k_begin; g_khi = k_end;
+    jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta);
+    g_klo = 0; g_khi = 1 << 30;
 }
 
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float halfrdx)

@@ -170,11 +170,29 @@ void BimocqGPUSolver::projection()
     gs.produced(div, std::min({ VelocityU.valid, VelocityV.valid, VelocityW.valid - 1 }));
     DeviceField *cur = &p, *oth = &p_temp;
     gs.produced(*cur, G);                                                // zeros everywhere
+    // p and p_temp carry the same (zero) boundary layer: gpu_jacobi_sweeps may fuse sweeps pairwise
+    const int fuse_was = fl_get_option(FL_OPT_JACOBI_FUSE);
+    if (fuse_was == 1) fl_set_option(FL_OPT_JACOBI_FUSE, 2);
     int left = jacobi_iters - 1;                                         // iterate iter-1 is applied
     while (left > 0) {
         const int chunk = std::min(left, G);
-        gs.require({ cur }, chunk);
-        const int where = gpu_jacobi_sweeps(*cur, div, *oth, g.ni, g.nj, g.nk, chunk, alpha, beta);
+        int where;
+        if (cur->valid < chunk) {
+            // exchange the ghost planes of `cur` on the halo stream and meanwhile sweep the planes whose
+            // stencil stays inside the owned planes; the rest of the first sweep follows the exchange
+            const int own0 = G, own1 = g.nk - G;                 // local owned planes [own0, own1)
+            float *ptr = cur->get(); size_t pe = cur->plane; int ex = 0;
+            fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0);
+            gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own0 + 1, own1 - 1, alpha, beta);
+            fl_halo_wait();
+            gs.produced(*cur, G);
+            gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, 0, own0 + 1, alpha, beta);
+            gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own1 - 1, g.nk, alpha, beta);
+            // remaining sweeps of the chunk start from `oth`
+            where = 1 - (chunk > 1 ? gpu_jacobi_sweeps(*oth, div, *cur, g.ni, g.nj, g.nk, chunk - 1, alpha, beta) : 0);
+        } else {
+            where = gpu_jacobi_sweeps(*cur, div, *oth, g.ni, g.nj, g.nk, chunk, alpha, beta);
+        }
         int v = cur->valid;
         for (int s = 0; s < chunk; s++) v = std::min(v - 1, div.valid);     // each sweep reaches one plane
         if (where) std::swap(cur, oth);
@@ -182,6 +200,7 @@ void BimocqGPUSolver::projection()
         gs.produced(*oth, 0);
         left -= chunk;
     }
+    fl_set_option(FL_OPT_JACOBI_FUSE, fuse_was);
     if (cur != &p) p.copy_from(*cur);
     gs.require({ &p }, 1);
     gpu_gradient(VelocityU, VelocityV, VelocityW, p, g.ni, g.nj, g.nk, halfrdx);

@@ -256,6 +256,10 @@ int  gpu_jacobi_sweeps(float *p, const float *div, float *p_temp,
                        int ni, int nj, int nk, int sweeps, float alpha, float beta);
 void gpu_gradient(float *u, float *v, float *w, const float *p,
                   int ni, int nj, int nk, float halfrdx);
+/* one Jacobi sweep in -> out over the local planes [k_begin, k_end) only: lets a z-slab host sweep the
+ * planes that do not depend on ghost planes while those are still being exchanged */
+void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                            int k_begin, int k_end, float alpha, float beta);
 /* exact sum r^2 (double) and max|r| of r = div - (sum6 p - 6p) over interior cells; blocking */
 void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk,
                         double *sum_sq, float *max_abs);

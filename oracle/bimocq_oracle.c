@@ -715,9 +715,16 @@ void orc_divergence(const float *u, const float *v, const float *w, float *div,
 void orc_jacobi_sweep(const float *p, const float *div, float *out,
                       int ni, int nj, int nk, float alpha, float beta)
 {
+    orc_jacobi_sweep_range(p, div, out, ni, nj, nk, 0, nk, alpha, beta);
+}
+
+/* the same sweep restricted to the local planes [k_begin, k_end) (slab hosts: interior first) */
+void orc_jacobi_sweep_range(const float *p, const float *div, float *out,
+                            int ni, int nj, int nk, int k_begin, int k_end, float alpha, float beta)
+{
     long sj = ni, sk = (long)ni * nj;
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int k = imax(1, KLO(1)); k < imin(nk - 1, KHI(NKG(nk) - 1, nk)); k++)
+    for (int k = imax(imax(1, KLO(1)), k_begin); k < imin(imin(nk - 1, KHI(NKG(nk) - 1, nk)), k_end); k++)
         for (int j = 1; j < nj - 1; j++)
             for (int i = 1; i < ni - 1; i++) {
                 long id = IDX3(i, j, k, ni, nj);

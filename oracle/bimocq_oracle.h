@@ -116,6 +116,8 @@ void orc_divergence(const float *u, const float *v, const float *w, float *div,
                     int ni, int nj, int nk, float halfrdx);
 void orc_jacobi_sweep(const float *p, const float *div, float *out,
                       int ni, int nj, int nk, float alpha, float beta);
+void orc_jacobi_sweep_range(const float *p, const float *div, float *out,
+                            int ni, int nj, int nk, int k_begin, int k_end, float alpha, float beta);
 void orc_gradient(float *field, const float *p, int nbi, int nbj, int nbk,
                   int dimx, int dimy, int dimz, float halfrdx);
 /* residual r = div - (sum6 p - 6p) over interior cells: returns sum r^2 (double

@@ -178,6 +178,9 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *pt, int ni, int nj, int
     for (int s = 0; s < sweeps; s++) { orc_jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta); float *t = in; in = out; out = t; }
     return in == p ? 0 : 1;
 }
+void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                            int k_begin, int k_end, float alpha, float beta)
+{ orc_jacobi_sweep_range(in, div, out, ni, nj, nk, k_begin, k_end, alpha, beta); }
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float hr)
 {
     orc_gradient(u, p, ni + 1, nj, nk, 1, 0, 0, hr);

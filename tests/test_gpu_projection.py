@@ -173,3 +173,27 @@ def test_fused_two_sweep_kernel(hip, ni, nj, nk, sweeps):
     newest = dt if where else dp
     assert F.same(a, newest.numpy()), (ni, nj, nk, sweeps)
     bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk", [(24, 20, 16), (64, 48, 40), (256, 32, 24)])
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_jacobi_sweep_range(hip, ni, nj, nk, variant):
+    """a sweep split into plane ranges (interior first, boundary planes after the exchange) touches exactly
+    the requested planes and composes to the full sweep"""
+    import gpufluidsimulation_amd as bq
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, variant)
+    p0, div, t0 = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2), F.scalar(ni, nj, nk, 2.9)
+    full = t0.copy()
+    oracle().orc_jacobi_sweep(fp(p0), fp(div), fp(full), ni, nj, nk, ALPHA, BETA)
+    dp, dd, dt = dev(p0, div, t0)
+    g = 3
+    hip.gpu_jacobi_sweep_range(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, g + 1, nk - g - 1, ALPHA, BETA)
+    part = dt.numpy().reshape(nk, nj, ni)
+    want = t0.copy().reshape(nk, nj, ni)
+    want[g + 1:nk - g - 1] = full.reshape(nk, nj, ni)[g + 1:nk - g - 1]
+    assert F.same(want, part)
+    hip.gpu_jacobi_sweep_range(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 0, g + 1, ALPHA, BETA)
+    hip.gpu_jacobi_sweep_range(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, nk - g - 1, nk, ALPHA, BETA)
+    hip.gpu_jacobi_sweep_range(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 5, 5, ALPHA, BETA)      # empty range
+    assert F.same(full, dt.numpy())
+    bq.check()
