@@ -196,6 +196,47 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
     if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, g_ev_done, 0));
 }
 
+// Exercises every RCCL entry point this file binds on a throw-away ONE-rank communicator: unique id,
+// init, in-place all-reduces with the data types/operators comm_allreduce uses, a grouped
+// ncclSend/ncclRecv pair (to self) on the halo stream, destroy.  Lets a single-GPU box verify the
+// dlopen'ed binding (symbols, enum values, call signatures) that the multi-GPU path depends on.
+int fl_comm_selftest(void)
+{
+    if (!ensure_ready("fl_comm_selftest") || !load_rccl()) return fl_last_error();
+    Runtime &r = rt();
+    ncclUniqueId id;
+    ncclComm_t comm = nullptr;
+    if (!BQ_NCCL(GetUniqueId(&id)) || !BQ_NCCL(CommInitRank(&comm, 1, id, 0))) return FL_ERR_COMM;
+    const int n = 1024;
+    float *buf = (float *)fl_malloc(sizeof(float) * 2 * n + sizeof(double) * 2);
+    int rc = FL_OK;
+    if (buf) {
+        float host[2 * n];
+        for (int i = 0; i < n; i++) { host[i] = 0.25f * i - 3.f; host[n + i] = -1.f; }
+        double hd[2] = { 1.0 / 3.0, -7.5 };
+        double *dd = (double *)(buf + 2 * n);
+        bool ok = BQ_HIP(hipMemcpy(buf, host, sizeof host, hipMemcpyHostToDevice)) && BQ_HIP(hipMemcpy(dd, hd, sizeof hd, hipMemcpyHostToDevice));
+        ok = ok && nccl_ok(g_rccl.AllReduce(dd, dd, 2, ncclDouble, ncclSum, comm, r.halo), "selftest AllReduce(double,sum)");
+        ok = ok && nccl_ok(g_rccl.AllReduce(buf, buf, 8, ncclFloat, ncclMax, comm, r.halo), "selftest AllReduce(float,max)");
+        ok = ok && BQ_NCCL(GroupStart());
+        ok = ok && nccl_ok(g_rccl.Send(buf, n, ncclFloat, 0, comm, r.halo), "selftest Send");
+        ok = ok && nccl_ok(g_rccl.Recv(buf + n, n, ncclFloat, 0, comm, r.halo), "selftest Recv");
+        ok = ok && BQ_NCCL(GroupEnd());
+        ok = ok && BQ_HIP(hipStreamSynchronize(r.halo));
+        float back[2 * n]; double bd[2];
+        ok = ok && BQ_HIP(hipMemcpy(back, buf, sizeof back, hipMemcpyDeviceToHost)) && BQ_HIP(hipMemcpy(bd, dd, sizeof bd, hipMemcpyDeviceToHost));
+        if (ok) {
+            for (int i = 0; i < n && ok; i++) ok = back[i] == host[i] && back[n + i] == host[i];
+            ok = ok && bd[0] == hd[0] && bd[1] == hd[1];
+            if (!ok) latch(FL_ERR_COMM, "fl_comm_selftest", "data mismatch after all-reduce / send-recv");
+        }
+        if (!ok) rc = FL_ERR_COMM;
+        fl_free(buf);
+    } else rc = fl_last_error();
+    g_rccl.CommDestroy(comm);
+    return rc;
+}
+
 void fl_halo_wait(void)
 {
     if (g_nranks <= 1 || !g_ev_done) return;

@@ -291,6 +291,9 @@ void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local);
 int  fl_comm_unique_id(void *id128);
 int  fl_comm_init(const void *id128, int rank, int nranks);
 void fl_comm_destroy(void);
+/* runs every RCCL call of this library on a temporary one-rank communicator (single-GPU check of the
+ * dlopen'ed binding); FL_OK or an error code with fl_last_error_string() set */
+int  fl_comm_selftest(void);
 int  fl_comm_rank(void);
 int  fl_comm_size(void);
 /* refresh `depth` (<= G) ghost planes per side of n fields with the z-neighbours, one RCCL group on

@@ -1,0 +1,44 @@
+"""Committed vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the CPU oracle):
+the oracle still reproduces them (CPU), and the HIP path reproduces them on the GPU box without the
+oracle in the loop.  Bit-exact (value equality)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import fields as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_golden import FIELDS, SCENES, run_oracle          # noqa: E402
+
+
+def load(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_oracle_reproduces_golden(name):
+    want, got = load(name), run_oracle(SCENES[name])
+    assert sorted(want.files) == sorted(got)
+    for key in want.files:
+        assert F.same(np.asarray(want[key]), np.asarray(got[key])), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_hip_reproduces_golden(name):
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps = SCENES[name]
+    want = load(name)
+    s = BimocqGPUSolver(*dims, L, visc, blend)
+    s.setSmoke(drop, rise, emitters)
+    s.setProjection(iters, hr)
+    dt = dt_cells * float(np.float32(L) / np.float32(dims[0]))
+    for f in range(steps):
+        s.advance(f, dt)
+        assert np.float32(s.cfldt) == want[f"cfldt_{f}"], f
+    for key in FIELDS:
+        assert F.same(want[key], s.field(key)), (key, F.maxdiff(want[key], s.field(key)))
+    s.close()

@@ -299,3 +299,15 @@ def test_unsupported_and_bad_arguments():
     lib.gpu_solve_forward(None, None, None, None, None, None, 0.1, 8, 8, 8, 0.1, 0.1)
     assert lib.fl_last_error() == bq._lib.FL_ERR_BAD_ARGUMENT
     lib.fl_clear_error()
+
+
+def test_rccl_binding_selftest():
+    """the dlopen'ed RCCL binding (ids, init, all-reduce dtypes/ops, grouped send/recv on the halo
+    stream, destroy) on a one-rank communicator -- the only part of the multi-GPU transport a one-GPU
+    box can execute"""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    assert hip.fl_init(0) == 0, hip.fl_last_error_string()
+    rc = hip.fl_comm_selftest()
+    assert rc == 0, hip.fl_last_error_string()
+    bq.check()
