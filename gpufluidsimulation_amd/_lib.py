@@ -73,6 +73,11 @@ HIP_SIGS = {
     "gpu_clamp_extrema_box_w": (None, [VP, VP, c_i, c_i, c_i]),
     "gpu_compensate_error_velocity": (None, [VP] * 12 + _G + [c_b]),
     "gpu_compensate_error_field": (None, [VP] * 6 + _G + [c_b]),
+    "gpu_advect_field2": (None, [VP] * 7 + _G + [c_b]),
+    "gpu_compensate_error_field2": (None, [VP] * 9 + _G + [c_b]),
+    "gpu_accumulate_field2": (None, [VP, VP, c_f, VP, VP, c_f] + [VP] * 3 + _G + [c_b]),
+    "gpu_accumulate_velocity2": (None, [VP] * 3 + [c_f] + [VP] * 3 + [c_f] + [VP] * 6 + _G + [c_b]),
+    "gpu_accumulate_velocity_identity": (None, [VP] * 9 + _G + [c_b, c_f]),
     "fl_report_error": (None, [c_i, C.c_char_p]),
     # 4. multi-GPU
     "fl_set_slab": (None, [c_i, c_i, c_i, c_i, c_i]),
@@ -107,7 +112,7 @@ def hip_lib():
             raise BimocqLibraryMissing(
                 f"{HIP_SO} not found: build it with `make` (or __graft_entry__.build()); "
                 "there is no CPU fallback for the product path")
-        lib = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(HIP_SO)
         for name, (res, args) in HIP_SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -7,6 +7,8 @@
 #include "bq_device.hip.h"
 #include "bq_host.h"
 
+#include <type_traits>
+
 namespace bq {
 
 #define BQ_IJK(nbi, nbj, nbk)                                   \
@@ -110,9 +112,37 @@ __device__ __forceinline__ void mapped9(const Map3 &m, const Spacing &sp, const 
     }
 }
 
+// The same 9 positions when the map is the identity map written by gpu_init_maps (node n holds n*h):
+// a component then varies along its own axis only, the lerps along the other two axes combine equal
+// values (lerp(a, a, c) == a for the weights 0, 1/4, 1/2, 3/4), and what is left of map9 is ONE lerp per
+// axis and tap between two node coordinates that need no load.  (i, j, kg): GLOBAL node indices.
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ void identity9(float h, int i, int j, int kg, f3 out[9])
+{
+    float tx[3], ty[3], tz[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int rx = tap_rel(SX, t), ry = tap_rel(SY, t), rz = tap_rel(SZ, t);
+        const float cx = tap_frac(SX, t), cy = tap_frac(SY, t), cz = tap_frac(SZ, t);
+        tx[t] = lerp_const((float)(i - 1 + rx) * h, (float)(i + rx) * h, cx, 1.0 - (double)cx);
+        ty[t] = lerp_const((float)(j - 1 + ry) * h, (float)(j + ry) * h, cy, 1.0 - (double)cy);
+        tz[t] = lerp_const((float)(kg - 1 + rz) * h, (float)(kg + rz) * h, cz, 1.0 - (double)cz);
+    }
+#pragma unroll
+    for (int ii = 0; ii < 8; ii++) out[ii] = mk3(tx[(ii >> 2) & 1], ty[(ii >> 1) & 1], tz[ii & 1]);
+    out[8] = mk3(tx[2], ty[2], tz[2]);
+}
+
+// Batches: NF fields that live on the same nodes share one map look-up (density + temperature; the
+// two velocity-change fields accumulated back to back).  Results per field are what NF single
+// launches in the same order produce.
+template <int NF> struct AdvectArgs { float *field[NF]; const float *init[NF]; };
+template <int NF> struct CumulateArgs { const float *src[NF]; float *dst[NF]; float coeff[NF]; };
+template <int NF> struct CompensateArgs { const float *src[NF]; const float *init[NF]; float *err[NF]; };
+
 // ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
-template <bool P2, bool PT, int SD>
-__global__ __launch_bounds__(256) void advect_kernel(float *field, const float *field_init,
+template <bool P2, bool PT, int SD, int NF>
+__global__ __launch_bounds__(256) void advect_kernel(AdvectArgs<NF> a,
                                                      const float *bx, const float *by, const float *bz,
                                                      Spacing sp, Grid g, int dx, int dy, int dz)
 {
@@ -121,21 +151,26 @@ __global__ __launch_bounds__(256) void advect_kernel(float *field, const float *
     if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < kg && kg < g.nkg + dz - 3)) return;
     const float h = sp.h;
     Map3 back{make_field(bx, g.ni, g.nj, g.nk, g.koff), make_field(by, g.ni, g.nj, g.nk, g.koff), make_field(bz, g.ni, g.nj, g.nk, g.koff)};
-    Field src = make_field(field_init, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
     f3 c = nine_centre(n, i, j, kg);
     f3 mp[9];
     mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
-    float sum = 0.f;
-    if (PT) {
-        sum += 1.0f * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
-    } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, clamp3(mp[ii], lo, hi));
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        Field src = make_field(a.init[f], nbi, nbj, nbk, g.koff);
+        float sum = 0.f;
+        if (PT) {
+            sum += 1.0f * sample<P2>(src, sp, n.org, mp[8]);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, mp[ii]);
+        }
+        float value = sample<P2>(src, sp, n.org, mp[8]);
+        a.field[f][(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum + 0.5f * value;
     }
-    float value = sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
-    field[(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum + 0.5f * value;
 }
 
 // ---- A7: doubleAdvect_kernel (GPU_kernel.cu:236-310) --------------------------------------
@@ -186,38 +221,50 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 }
 
 // ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
-template <bool P2, bool PT, int SD>
-__global__ __launch_bounds__(256) void cumulate_kernel(const float *srcp, float *dst,
+// ID: the map is the identity map of gpu_init_maps (mx/my/mz are not read).
+template <bool P2, bool PT, int SD, int NF, bool ID>
+__global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
                                                        const float *mx, const float *my, const float *mz,
-                                                       Spacing sp, Grid g, int dx, int dy, int dz, float coeff)
+                                                       Spacing sp, Grid g, int dx, int dy, int dz)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
     if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
     const float h = sp.h;
     Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
-    Field src = make_field(srcp, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
     f3 mp[9];
-    mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
-    float sum = 0.f;
-    if (PT) {
-        sum += 1.0f * coeff * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
+    if constexpr (ID) {
+        static_assert(P2 && !PT && SD >= 0, "identity shortcut: structured power-of-two path only");
+        identity9<SD == 1, SD == 2, SD == 3>(h, i, j, kg, mp);
     } else {
-#pragma unroll
-        for (int ii = 0; ii < 8; ii++) sum += 0.125f * coeff * sample<P2>(src, sp, n.org, clamp3(mp[ii], lo, hi));
+        mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
     }
-    float value = coeff * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
-    sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
-    size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
-    dst[id] += sum;
+#pragma unroll
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
+        const float coeff = a.coeff[f];
+        float sum = 0.f;
+        if (PT) {
+            sum += 1.0f * coeff * sample<P2>(src, sp, n.org, mp[8]);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) sum += 0.125f * coeff * sample<P2>(src, sp, n.org, mp[ii]);
+        }
+        float value = coeff * sample<P2>(src, sp, n.org, mp[8]);
+        sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+        a.dst[f][id] += sum;            // dst[0] == dst[1] is allowed: applied in order
+    }
 }
 
 // ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
-template <bool P2, bool PT, int SD>
-__global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, const float *init, float *err,
+template <bool P2, bool PT, int SD, int NF>
+__global__ __launch_bounds__(256) void compensate_kernel(CompensateArgs<NF> a,
                                                          const float *mx, const float *my, const float *mz,
                                                          Spacing sp, Grid g, int dx, int dy, int dz)
 {
@@ -226,23 +273,28 @@ __global__ __launch_bounds__(256) void compensate_kernel(const float *srcp, cons
     if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
     const float h = sp.h;
     Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
-    Field src = make_field(srcp, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
     f3 mp[9];
     mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
-    float sum = 0.f;
-    if (PT) {
-        sum += 1.0f * sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
-    } else {
 #pragma unroll
-        for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, clamp3(mp[ii], lo, hi));
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
+        float sum = 0.f;
+        if (PT) {
+            sum += 1.0f * sample<P2>(src, sp, n.org, mp[8]);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, mp[ii]);
+        }
+        float value = sample<P2>(src, sp, n.org, mp[8]);
+        sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+        a.err[f][id] = sum - a.init[f][id];
     }
-    float value = sample<P2>(src, sp, n.org, clamp3(mp[8], lo, hi));
-    sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
-    size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
-    err[id] = sum - init[id];
 }
 
 // ---- A6: clampExtrema_kernel (GPU_kernel.cu:146-167) --------------------------------------
@@ -357,20 +409,83 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
         BQ_LAUNCH_CHECK(#KERNEL);                                                                           \
     } while (0)
 
+// Runtime (pow2 spacing, point sampling, staggered axis) -> compile-time <P2, PT, SD>; fn receives three
+// integral_constant tags.  Returns whether the structured power-of-two path was taken.
+template <class Fn>
+static bool dispatch_sd(bool p2, bool pt, int sd, Fn &&fn)
+{
+    using T = std::true_type; using F = std::false_type;
+    bool structured = false;
+    if (p2 && !pt && rt().opt_structured_maps) {
+        structured = true;
+        switch (sd) {
+        case 0:  fn(T{}, F{}, std::integral_constant<int, 0>{}); break;
+        case 1:  fn(T{}, F{}, std::integral_constant<int, 1>{}); break;
+        case 2:  fn(T{}, F{}, std::integral_constant<int, 2>{}); break;
+        default: fn(T{}, F{}, std::integral_constant<int, 3>{}); break;
+        }
+    }
+    else if (p2) { if (pt) fn(T{}, T{}, std::integral_constant<int, -1>{}); else fn(T{}, F{}, std::integral_constant<int, -1>{}); }
+    else         { if (pt) fn(F{}, T{}, std::integral_constant<int, -1>{}); else fn(F{}, F{}, std::integral_constant<int, -1>{}); }
+    return structured;
+}
+static inline int stag_axis(int dx, int dy, int dz) { return dx ? 1 : dy ? 2 : dz ? 3 : 0; }
+
+template <int NF>
+static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, const float *bz,
+                         Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
+{
+    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
+    hipStream_t st = rt().compute;
+    dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
+        advect_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz);
+    });
+    BQ_LAUNCH_CHECK("advect_kernel");
+}
+// identity: the caller vouches that mx/my/mz hold the identity map of gpu_init_maps; the shortcut is
+// taken on the structured power-of-two path, otherwise the map is read like any other
+template <int NF>
+static void cumulate_multi(CumulateArgs<NF> a, const float *mx, const float *my, const float *mz,
+                           Spacing sp, Grid g, int dx, int dy, int dz, bool pt, bool identity)
+{
+    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
+    hipStream_t st = rt().compute;
+    dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
+        constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
+        constexpr int sd = decltype(SD)::value;
+        if constexpr (p2 && !ptc && sd >= 0) {
+            if (identity) { cumulate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz); return; }
+        }
+        cumulate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz);
+    });
+    BQ_LAUNCH_CHECK("cumulate_kernel");
+}
+template <int NF>
+static void compensate_multi(CompensateArgs<NF> a, const float *mx, const float *my, const float *mz,
+                             Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
+{
+    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
+    hipStream_t st = rt().compute;
+    dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
+        compensate_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz);
+    });
+    BQ_LAUNCH_CHECK("compensate_kernel");
+}
+
 static void advect_comp(float *f, const float *init, const float *bx, const float *by, const float *bz,
                         Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
-    BQ_DISPATCH2(advect_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, init, bx, by, bz, sp, g, dx, dy, dz);
+    advect_multi<1>(AdvectArgs<1>{{f}, {init}}, bx, by, bz, sp, g, dx, dy, dz, pt);
 }
 static void cumulate_comp(const float *src, float *dst, const float *mx, const float *my, const float *mz,
-                          Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float coeff)
+                          Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float coeff, bool identity = false)
 {
-    BQ_DISPATCH2(cumulate_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, dst, mx, my, mz, sp, g, dx, dy, dz, coeff);
+    cumulate_multi<1>(CumulateArgs<1>{{src}, {dst}, {coeff}}, mx, my, mz, sp, g, dx, dy, dz, pt, identity);
 }
 static void compensate_comp(const float *src, const float *init, float *err, const float *mx, const float *my, const float *mz,
                             Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
-    BQ_DISPATCH2(compensate_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), src, init, err, mx, my, mz, sp, g, dx, dy, dz);
+    compensate_multi<1>(CompensateArgs<1>{{src}, {init}, {err}}, mx, my, mz, sp, g, dx, dy, dz, pt);
 }
 static void double_comp(float *f, const float *prev, const float *bx, const float *by, const float *bz,
                         const float *px, const float *py, const float *pz,
@@ -485,6 +600,65 @@ void gpu_accumulate_field(float *field_change, float *dfield_init, float *forwar
     BQ_ENTER("gpu_accumulate_field", field_change, dfield_init, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     cumulate_comp(field_change, dfield_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point, coeff);
+}
+
+// ---- batched / shortcut forms of the entry points above (additive; same arithmetic) ----------------
+void gpu_advect_field2(float *field1, float *field1_init, float *field2, float *field2_init,
+                       float *backward_x, float *backward_y, float *backward_z,
+                       float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_advect_field2", field1, field1_init, field2, field2_init, backward_x, backward_y, backward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    advect_multi<2>(AdvectArgs<2>{{field1, field2}, {field1_init, field2_init}}, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point);
+}
+
+void gpu_compensate_error_field2(float *u1, float *du1, float *u1_src, float *u2, float *du2, float *u2_src,
+                                 float *forward_x, float *forward_y, float *forward_z,
+                                 float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_compensate_error_field2", u1, du1, u1_src, u2, du2, u2_src, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    compensate_multi<2>(CompensateArgs<2>{{u1, u2}, {du1, du2}, {u1_src, u2_src}}, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point);
+}
+
+void gpu_accumulate_field2(float *change1, float *dinit1, float coeff1, float *change2, float *dinit2, float coeff2,
+                           float *forward_x, float *forward_y, float *forward_z,
+                           float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_accumulate_field2", change1, dinit1, change2, dinit2, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    cumulate_multi<2>(CumulateArgs<2>{{change1, change2}, {dinit1, dinit2}, {coeff1, coeff2}}, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point, false);
+}
+
+// du_init += blend9(coeff1 * change1(psi(x))), then += blend9(coeff2 * change2(psi(x))): two
+// gpu_accumulate_velocity calls with one map look-up
+void gpu_accumulate_velocity2(float *u_change1, float *v_change1, float *w_change1, float coeff1,
+                              float *u_change2, float *v_change2, float *w_change2, float coeff2,
+                              float *du_init, float *dv_init, float *dw_init,
+                              float *forward_x, float *forward_y, float *forward_z,
+                              float h, int ni, int nj, int nk, bool is_point)
+{
+    BQ_ENTER("gpu_accumulate_velocity2", u_change1, v_change1, w_change1, u_change2, v_change2, w_change2,
+             du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    cumulate_multi<2>(CumulateArgs<2>{{u_change1, u_change2}, {du_init, du_init}, {coeff1, coeff2}}, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point, false);
+    cumulate_multi<2>(CumulateArgs<2>{{v_change1, v_change2}, {dv_init, dv_init}, {coeff1, coeff2}}, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point, false);
+    cumulate_multi<2>(CumulateArgs<2>{{w_change1, w_change2}, {dw_init, dw_init}, {coeff1, coeff2}}, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, false);
+}
+
+// gpu_accumulate_velocity for a forward map that IS the identity map of gpu_init_maps (right after a
+// re-initialisation): the caller vouches for that; the map buffers are still passed and are read on every
+// path without the shortcut (spacing not a power of two, FL_OPT_STRUCTURED_MAPS off).
+void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w_change,
+                                      float *du_init, float *dv_init, float *dw_init,
+                                      float *forward_x, float *forward_y, float *forward_z,
+                                      float h, int ni, int nj, int nk, bool is_point, float coeff)
+{
+    BQ_ENTER("gpu_accumulate_velocity_identity", u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    cumulate_comp(u_change, du_init, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point, coeff, true);
+    cumulate_comp(v_change, dv_init, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point, coeff, true);
+    cumulate_comp(w_change, dw_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, coeff, true);
 }
 
 void gpu_estimate_distortion(float *du, float *x_init, float *y_init, float *z_init,

@@ -247,8 +247,8 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     // :143-145
     VelocityAdvector.advectVelocity(VelocityU, VelocityV, VelocityW, VelocityUInit, VelocityVInit, VelocityWInit,
                                     VelocityUPrev, VelocityVPrev, VelocityWPrev);
-    ScalarAdvector.advectField(Density, DensityInit, DensityPrev);
-    ScalarAdvector.advectField(Temperature, TemperatureInit, TemperaturePrev);
+    // density and temperature live on the same nodes and use the same maps: batched (one map look-up)
+    ScalarAdvector.advectFields2(Density, DensityInit, DensityPrev, Temperature, TemperatureInit, TemperaturePrev);
     trace_stage(*this, "advect", framenum);
 
     // :157-159
@@ -301,8 +301,8 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     }
 
     // :213-214
-    VelocityAdvector.accumulateVelocity(VelocityUInit, VelocityVInit, VelocityWInit, duExtern, dvExtern, dwExtern, 1.f);
-    VelocityAdvector.accumulateVelocity(VelocityUInit, VelocityVInit, VelocityWInit, duProj, dvProj, dwProj, proj_coeff);
+    VelocityAdvector.accumulateVelocity2(VelocityUInit, VelocityVInit, VelocityWInit,
+                                         duExtern, dvExtern, dwExtern, 1.f, duProj, dvProj, dwProj, proj_coeff);
     trace_stage(*this, "accumulate", framenum);
 
     // :218-223 `if (1)`: re-initialise every frame

@@ -93,6 +93,7 @@ void MapperBaseGPU::updateForward(DeviceField &U, DeviceField &V, DeviceField &W
                            gpuMapper::minValid({ &U, &V, &W }) - reach);
     gs.producedAll({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, v);
     m.Dfwd += dcells;
+    m.fwdIdentity = false;
 }
 
 // Mapping.cpp:375-391.  gpu_compensate_velocity is issued as its four stages (GPU_kernel.cu:652-665)
@@ -205,6 +206,65 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
                                   fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
 }
 
+// Two scalar fields through the same sequence as advectField, stage by stage, with the batched
+// operators (one map look-up per stage for both fields).  u_src / v_src are the two error scratches.
+void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceField &f1Prev,
+                                  DeviceField &f2, DeviceField &f2Init, DeviceField &f2Prev)
+{
+    MapSet &m = *maps;
+    gpuMapper &gs = *gpuSolver;
+    const float h = g.h;
+    const int ni = g.ni, nj = g.nj, nk = g.nk;
+    const auto back = [&] { return gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }); };
+    const auto fwd = [&] { return gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }); };
+
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+    gs.require({ &f1Init, &f2Init }, reachField(m.Dback));
+    f1.zero(); f2.zero();                                                   // GPU_Advection.h:507
+    gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+    gs.produced(f1, std::min(back() - kReachMap, f1Init.valid - reachField(m.Dback)));
+    gs.produced(f2, std::min(back() - kReachMap, f2Init.valid - reachField(m.Dback)));
+
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    gs.require({ &f1, &f2 }, reachField(m.Dfwd));
+    DeviceField &e1 = gs.u_src, &e2 = gs.v_src;                             // scalar-sized use of the scratches
+    fl_memset(e1, 0, g.n() * sizeof(float)); fl_memset(e2, 0, g.n() * sizeof(float));
+    gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    const size_t plane1 = e1.plane, plane2 = e2.plane;
+    e1.plane = e2.plane = (size_t)ni * nj;
+    gs.produced(e1, std::min({ fwd() - kReachMap, f1.valid - reachField(m.Dfwd), f1Init.valid }));
+    gs.produced(e2, std::min({ fwd() - kReachMap, f2.valid - reachField(m.Dfwd), f2Init.valid }));
+    f1Init.copy_from(f1); f2Init.copy_from(f2);
+    gs.require({ &e1, &e2 }, reachField(m.Dback));
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+    gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+    gs.produced(f1, std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) }));
+    gs.produced(f2, std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) }));
+    e1.plane = plane1; e2.plane = plane2;
+    gs.require({ &f1Init, &f2Init }, 1);
+    gpu_clamp_extrema_box(f1Init, f1, ni, nj, nk);
+    gpu_clamp_extrema_box(f2Init, f2, ni, nj, nk);
+    gs.produced(f1, std::min(f1.valid, f1Init.valid - 1));
+    gs.produced(f2, std::min(f2.valid, f2Init.valid - 1));
+
+    const float blend = (TotalReinitCount != 0) ? BlendCoeff : 1.f;
+    DeviceField *fs[2] = { &f1, &f2 }, *ps[2] = { &f1Prev, &f2Prev };
+    for (int a = 0; a < 2; a++) {
+        DeviceField &f = *fs[a], &fPrev = *ps[a];
+        if (blend != 1.f) {
+            gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
+            gs.require({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }, reachField(m.Dback));
+            gs.require({ &fPrev }, reachField(m.Dback + m.DbackPrev));
+        }
+        gs.advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
+                             m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+        if (blend != 1.f)
+            gs.produced(f, std::min({ f.valid, back() - kReachMap,
+                                      gpuMapper::minValid({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }) - reachField(m.Dback),
+                                      fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
+    }
+}
+
 // Mapping.cpp:420-428 (note the Init/Change order swap towards the gpuMapper)
 void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
                                        DeviceField &Uc, DeviceField &Vc, DeviceField &Wc, float coeff)
@@ -213,10 +273,28 @@ void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, Devic
     gpuMapper &gs = *gpuSolver;
     gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
     gs.require({ &Uc, &Vc, &Wc }, reachField(m.Dfwd));
-    gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
+    if (m.fwdIdentity)
+        gpu_accumulate_velocity_identity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false, coeff);
+    else
+        gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc, &Vc, &Wc }) - reachField(m.Dfwd) }));
+}
+
+void MapperBaseGPU::accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
+                                        DeviceField &Uc1, DeviceField &Vc1, DeviceField &Wc1, float coeff1,
+                                        DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2)
+{
+    MapSet &m = *maps;
+    gpuMapper &gs = *gpuSolver;
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    gs.require({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd));
+    gpu_accumulate_velocity2(Uc1, Vc1, Wc1, coeff1, Uc2, Vc2, Wc2, coeff2, dUi, dVi, dWi,
+                             m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false);
+    gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
+                                                    gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
+                                                    gpuMapper::minValid({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
 }
 
 void MapperBaseGPU::accumulateField(DeviceField &dfInit, DeviceField &fChange)
@@ -242,6 +320,7 @@ void MapperBaseGPU::reinitializeMapping()
     m.DbackPrev = m.Dback;
     m.Dback = 0;
     m.Dfwd = 0;
+    m.fwdIdentity = true;
 }
 
 } // namespace bqhost

@@ -24,6 +24,8 @@ struct MapSet {
     // upper bounds (in cells) of |map(x) - x| along any axis: how far a mapped position can sit from
     // the node it belongs to.  Grow by the step's CFL travel, reset by reinitializeMapping().
     int Dfwd = 0, Dback = 0, DbackPrev = 0;
+    // Forward* still hold exactly what gpu_init_maps wrote (fresh or just re-initialised, not yet updated)
+    bool fwdIdentity = true;
     bool alloc(const gpuMapper &m);
 };
 
@@ -45,8 +47,15 @@ public:
                         DeviceField &Ui, DeviceField &Vi, DeviceField &Wi,
                         DeviceField &Up, DeviceField &Vp, DeviceField &Wp);
     void advectField(DeviceField &f, DeviceField &fInit, DeviceField &fPrev);
+    // advectField(f1..) ; advectField(f2..) with the map look-ups shared between the two fields
+    void advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceField &f1Prev,
+                       DeviceField &f2, DeviceField &f2Init, DeviceField &f2Prev);
     void accumulateVelocity(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
                             DeviceField &Uc, DeviceField &Vc, DeviceField &Wc, float coeff);
+    // accumulateVelocity(change 1, coeff1) ; accumulateVelocity(change 2, coeff2), one map look-up
+    void accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
+                             DeviceField &Uc1, DeviceField &Vc1, DeviceField &Wc1, float coeff1,
+                             DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2);
     void accumulateField(DeviceField &dfInit, DeviceField &fChange);
     void reinitializeMapping();
 

@@ -54,7 +54,7 @@ def host_lib():
         _lib.hip_lib()
         if not os.path.exists(_lib.HOST_SO):
             raise _lib.BimocqLibraryMissing(f"{_lib.HOST_SO} not found: run `make`")
-        _host = bind_host(C.CDLL(_lib.HOST_SO, mode=C.RTLD_GLOBAL))
+        _host = bind_host(C.CDLL(_lib.HOST_SO))
     return _host
 
 

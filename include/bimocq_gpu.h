@@ -274,6 +274,36 @@ void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, floa
 void gpu_compensate_error_field(float *u, float *du, float *u_src,
                                 float *forward_x, float *forward_y, float *forward_z,
                                 float h, int ni, int nj, int nk, bool is_point);
+/* Batched forms: fields that live on the same nodes share ONE map look-up (the look-up is ~70 % of a
+ * gather kernel's arithmetic).  Each is, result for result, the two single calls it names, in order.
+ *   gpu_advect_field2            = gpu_advect_field(field1..) ; gpu_advect_field(field2..)
+ *   gpu_compensate_error_field2  = gpu_compensate_error_field(u1..) ; (u2..)
+ *   gpu_accumulate_field2        = gpu_accumulate_field(change1, dinit1, coeff1) ; (change2, dinit2, coeff2)
+ *   gpu_accumulate_velocity2     = gpu_accumulate_velocity(change1 -> d*_init, coeff1) ; (change2 -> d*_init, coeff2)
+ * (BimocqGPUSolver.cpp:144-145 advects rho and T back to back; :213-214 accumulates the force and the
+ * projection change back to back.) */
+void gpu_advect_field2(float *field1, float *field1_init, float *field2, float *field2_init,
+                       float *backward_x, float *backward_y, float *backward_z,
+                       float h, int ni, int nj, int nk, bool is_point);
+void gpu_compensate_error_field2(float *u1, float *du1, float *u1_src, float *u2, float *du2, float *u2_src,
+                                 float *forward_x, float *forward_y, float *forward_z,
+                                 float h, int ni, int nj, int nk, bool is_point);
+void gpu_accumulate_field2(float *change1, float *dinit1, float coeff1, float *change2, float *dinit2, float coeff2,
+                           float *forward_x, float *forward_y, float *forward_z,
+                           float h, int ni, int nj, int nk, bool is_point);
+void gpu_accumulate_velocity2(float *u_change1, float *v_change1, float *w_change1, float coeff1,
+                              float *u_change2, float *v_change2, float *w_change2, float coeff2,
+                              float *du_init, float *dv_init, float *dw_init,
+                              float *forward_x, float *forward_y, float *forward_z,
+                              float h, int ni, int nj, int nk, bool is_point);
+/* gpu_accumulate_velocity when the caller KNOWS the forward map is the identity map gpu_init_maps wrote
+ * (BimocqGPUSolver.cpp:222-223: accumulate right after reinitializeMapping): with power-of-two spacing
+ * the mapped positions follow from the node indices alone, by the same lerps, and the map is not read.
+ * Same results as gpu_accumulate_velocity on that map. */
+void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w_change,
+                                      float *du_init, float *dv_init, float *dw_init,
+                                      float *forward_x, float *forward_y, float *forward_z,
+                                      float h, int ni, int nj, int nk, bool is_point, float coeff);
 /* clamp_extrema_box for a staggered buffer: dz = 1 for the w component (nk+1 planes) */
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
 /* clampExtrema_kernel (GPU_kernel.cu:146-167) on its own: after = clamp(after, min/max27(before)) */

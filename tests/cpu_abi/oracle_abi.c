@@ -168,6 +168,26 @@ void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, floa
 void gpu_compensate_error_field(float *u, float *du, float *us, float *fx, float *fy, float *fz,
                                 float h, int ni, int nj, int nk, bool pt)
 { orc_compensate_error_field(u, du, us, fx, fy, fz, h, ni, nj, nk, pt); }
+/* batched / shortcut forms: by definition the single operators in order */
+void gpu_advect_field2(float *f1, float *f1i, float *f2, float *f2i, float *bx, float *by, float *bz,
+                       float h, int ni, int nj, int nk, bool pt)
+{ orc_advect_field(f1, f1i, bx, by, bz, h, ni, nj, nk, pt); orc_advect_field(f2, f2i, bx, by, bz, h, ni, nj, nk, pt); }
+void gpu_compensate_error_field2(float *u1, float *du1, float *us1, float *u2, float *du2, float *us2,
+                                 float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt)
+{ orc_compensate_error_field(u1, du1, us1, fx, fy, fz, h, ni, nj, nk, pt); orc_compensate_error_field(u2, du2, us2, fx, fy, fz, h, ni, nj, nk, pt); }
+void gpu_accumulate_field2(float *c1, float *d1, float k1, float *c2, float *d2, float k2,
+                           float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt)
+{ orc_accumulate_field(c1, d1, fx, fy, fz, h, ni, nj, nk, pt, k1); orc_accumulate_field(c2, d2, fx, fy, fz, h, ni, nj, nk, pt, k2); }
+void gpu_accumulate_velocity2(float *u1, float *v1, float *w1, float k1, float *u2, float *v2, float *w2, float k2,
+                              float *du, float *dv, float *dw, float *fx, float *fy, float *fz,
+                              float h, int ni, int nj, int nk, bool pt)
+{
+    orc_accumulate_velocity(u1, v1, w1, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, k1);
+    orc_accumulate_velocity(u2, v2, w2, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, k2);
+}
+void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du, float *dv, float *dw,
+                                      float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt, float coeff)
+{ orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
 { orc_clamp_extrema_box_w(before, after, ni, nj, nk); }
 void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float hr)

@@ -45,6 +45,9 @@ _SIGS = {
     "orc_add": (None, [FP, FP, c_f, c_i]),
     "orc_compensate_velocity": (None, [FP] * 15 + [c_f, c_i, c_i, c_i, c_i]),
     "orc_compensate_field": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_compensate_error_velocity": (None, [FP] * 12 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_compensate_error_field": (None, [FP] * 6 + [c_f, c_i, c_i, c_i, c_i]),
+    "orc_jacobi_sweep_range": (None, [FP] * 3 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "orc_semilag": (None, [FP] * 5 + [c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_f]),
     "orc_emit_smoke": (None, [FP] * 5 + [c_f, c_i, c_i, c_i] + [c_f] * 7),
     "orc_add_buoyancy": (None, [FP] * 3 + [c_i, c_i, c_i, c_f, c_f, c_f]),

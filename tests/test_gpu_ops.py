@@ -311,3 +311,77 @@ def test_rccl_binding_selftest():
     rc = hip.fl_comm_selftest()
     assert rc == 0, hip.fl_last_error_string()
     bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS + [(40, 24, 16, 1.0 / 64)])
+@pytest.mark.parametrize("is_point", [False, True])
+def test_batched_scalar_ops(gm, ni, nj, nk, h, is_point):
+    """gpu_advect_field2 / gpu_compensate_error_field2 / gpu_accumulate_field2 == the two single oracle
+    calls each of them stands for"""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    h, _, fwd, back, _ = setup(ni, nj, nk, h)
+    n = ni * nj * nk
+    a_init, b_init = F.scalar(ni, nj, nk, 0.4), F.scalar(ni, nj, nk, 1.9, amp=2.0)
+    ra, rb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oracle().orc_advect_field(fp(ra), fp(a_init), *map(fp, back), h, ni, nj, nk, int(is_point))
+    oracle().orc_advect_field(fp(rb), fp(b_init), *map(fp, back), h, ni, nj, nk, int(is_point))
+    gm(ni, nj, nk, h)
+    da, db, dai, dbi = dev(np.zeros(n, np.float32), np.zeros(n, np.float32), a_init, b_init)
+    dback, dfwd = dev(*back), dev(*fwd)
+    hip.gpu_advect_field2(da.ptr, dai.ptr, db.ptr, dbi.ptr, *[x.ptr for x in dback], h, ni, nj, nk, is_point)
+    assert F.same(ra, da.numpy()) and F.same(rb, db.numpy())
+    # error stage
+    ea, eb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oracle().orc_compensate_error_field(fp(ra), fp(a_init), fp(ea), *map(fp, fwd), h, ni, nj, nk, int(is_point))
+    oracle().orc_compensate_error_field(fp(rb), fp(b_init), fp(eb), *map(fp, fwd), h, ni, nj, nk, int(is_point))
+    dea, deb = dev(np.zeros(n, np.float32), np.zeros(n, np.float32))
+    hip.gpu_compensate_error_field2(da.ptr, dai.ptr, dea.ptr, db.ptr, dbi.ptr, deb.ptr, *[x.ptr for x in dfwd], h, ni, nj, nk, is_point)
+    assert F.same(ea, dea.numpy()) and F.same(eb, deb.numpy())
+    # accumulate, different targets and coefficients
+    oracle().orc_accumulate_field(fp(ea), fp(ra), *map(fp, back), h, ni, nj, nk, int(is_point), -0.5)
+    oracle().orc_accumulate_field(fp(eb), fp(rb), *map(fp, back), h, ni, nj, nk, int(is_point), 2.0)
+    hip.gpu_accumulate_field2(dea.ptr, da.ptr, -0.5, deb.ptr, db.ptr, 2.0, *[x.ptr for x in dback], h, ni, nj, nk, is_point)
+    assert F.same(ra, da.numpy()) and F.same(rb, db.numpy())
+    # same target twice: applied in order
+    oracle().orc_accumulate_field(fp(ea), fp(ra), *map(fp, fwd), h, ni, nj, nk, int(is_point), 1.0)
+    oracle().orc_accumulate_field(fp(eb), fp(ra), *map(fp, fwd), h, ni, nj, nk, int(is_point), 0.75)
+    hip.gpu_accumulate_field2(dea.ptr, da.ptr, 1.0, deb.ptr, da.ptr, 0.75, *[x.ptr for x in dfwd], h, ni, nj, nk, is_point)
+    assert F.same(ra, da.numpy())
+    bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS + [(40, 24, 16, 1.0 / 64)])
+def test_accumulate_velocity_batched_and_identity(gm, ni, nj, nk, h):
+    """gpu_accumulate_velocity2 == two gpu_accumulate_velocity; gpu_accumulate_velocity_identity == the
+    plain operator on the map gpu_init_maps writes (with and without the structured path)"""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    h, vel, fwd, _, _ = setup(ni, nj, nk, h)
+    c2 = [F.scalar(ni + 1, nj, nk, 2.1), F.scalar(ni, nj + 1, nk, 2.2), F.scalar(ni, nj, nk + 1, 2.3)]
+    init = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    ref = [a.copy() for a in init]
+    oracle().orc_accumulate_velocity(*map(fp, vel), *map(fp, ref), *map(fp, fwd), h, ni, nj, nk, 0, 1.0)
+    oracle().orc_accumulate_velocity(*map(fp, c2), *map(fp, ref), *map(fp, fwd), h, ni, nj, nk, 0, 2.0)
+    gm(ni, nj, nk, h)
+    d, dv1, dv2, dfwd = dev(*init), dev(*vel), dev(*c2), dev(*fwd)
+    hip.gpu_accumulate_velocity2(*[x.ptr for x in dv1], 1.0, *[x.ptr for x in dv2], 2.0, *[x.ptr for x in d],
+                                 *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+    for r, g in zip(ref, d):
+        assert F.same(r, g.numpy())
+    # identity map
+    n = ni * nj * nk
+    ident = dev(np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32))
+    hip.gpu_init_maps(*[x.ptr for x in ident], h, ni, nj, nk)
+    imaps = [x.numpy() for x in ident]
+    ref = [a.copy() for a in init]
+    oracle().orc_accumulate_velocity(*map(fp, vel), *map(fp, ref), *map(fp, imaps), h, ni, nj, nk, 0, 1.5)
+    for structured in (1, 0):
+        hip.fl_set_option(bq._lib.FL_OPT_STRUCTURED_MAPS, structured)
+        d = dev(*init)
+        hip.gpu_accumulate_velocity_identity(*[x.ptr for x in dv1], *[x.ptr for x in d], *[x.ptr for x in ident],
+                                             h, ni, nj, nk, False, 1.5)
+        for r, g in zip(ref, d):
+            assert F.same(r, g.numpy()), structured
+    hip.fl_set_option(bq._lib.FL_OPT_STRUCTURED_MAPS, 1)
+    bq.check()
