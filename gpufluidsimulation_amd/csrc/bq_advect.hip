@@ -112,27 +112,6 @@ __device__ __forceinline__ void mapped9(const Map3 &m, const Spacing &sp, const 
     }
 }
 
-// The same 9 positions when the map is the identity map written by gpu_init_maps (node n holds n*h):
-// a component then varies along its own axis only, the lerps along the other two axes combine equal
-// values (lerp(a, a, c) == a for the weights 0, 1/4, 1/2, 3/4), and what is left of map9 is ONE lerp per
-// axis and tap between two node coordinates that need no load.  (i, j, kg): GLOBAL node indices.
-template <int SX, int SY, int SZ>
-__device__ __forceinline__ void identity9(float h, int i, int j, int kg, f3 out[9])
-{
-    float tx[3], ty[3], tz[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const int rx = tap_rel(SX, t), ry = tap_rel(SY, t), rz = tap_rel(SZ, t);
-        const float cx = tap_frac(SX, t), cy = tap_frac(SY, t), cz = tap_frac(SZ, t);
-        tx[t] = lerp_const((float)(i - 1 + rx) * h, (float)(i + rx) * h, cx, 1.0 - (double)cx);
-        ty[t] = lerp_const((float)(j - 1 + ry) * h, (float)(j + ry) * h, cy, 1.0 - (double)cy);
-        tz[t] = lerp_const((float)(kg - 1 + rz) * h, (float)(kg + rz) * h, cz, 1.0 - (double)cz);
-    }
-#pragma unroll
-    for (int ii = 0; ii < 8; ii++) out[ii] = mk3(tx[(ii >> 2) & 1], ty[(ii >> 1) & 1], tz[ii & 1]);
-    out[8] = mk3(tx[2], ty[2], tz[2]);
-}
-
 // Batches: NF fields that live on the same nodes share one map look-up (density + temperature; the
 // two velocity-change fields accumulated back to back).  Results per field are what NF single
 // launches in the same order produce.
@@ -235,16 +214,35 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
-    f3 mp[9];
+    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     if constexpr (ID) {
+        // Identity map (node n holds n*h), power-of-two spacing.  A map component then varies along its
+        // own axis only; map9's lerps along the other two axes combine equal values (lerp(a, a, c) == a
+        // for the weights 0, 1/4, 1/2, 3/4) and the remaining one, between n*h and (n+1)*h, is exact in
+        // fp32: the mapped positions ARE the node's 9 sample points, inside the clamp box.  In the
+        // SOURCE field's own index space those are (i +- 1/4, j +- 1/4, k +- 1/4) and the centre: the
+        // structured look-up with compile-time cells and weights (map9_component, unstaggered pattern)
+        // applied to the field itself performs the very lerps locate() + gather() would.
         static_assert(P2 && !PT && SD >= 0, "identity shortcut: structured power-of-two path only");
-        identity9<SD == 1, SD == 2, SD == 3>(h, i, j, kg, mp);
-    } else {
-        mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
+            const float coeff = a.coeff[f];
+            float s9[9];
+            map9_component<0, 0, 0>(src, i, j, k, s9);
+            float sum = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) sum += 0.125f * coeff * s9[ii];
+            float value = coeff * s9[8];
+            sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+            a.dst[f][id] += sum;
+        }
+        return;
     }
+    f3 mp[9];
+    mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
-    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
         Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
