@@ -112,6 +112,38 @@ __device__ __forceinline__ void mapped9(const Map3 &m, const Spacing &sp, const 
     }
 }
 
+// The 9-point blend of NF co-located fields at the (clamped) positions mp[0..8]: per field
+//     sum = sum_ii w * field(mp[ii])  (ii = 0..7 in order; point mode: the centre alone),  value = field(mp[8])
+// with the tap's cell and weights located once for all fields (they share dims and origin).
+template <bool P2, bool PT, int NF>
+__device__ __forceinline__ void blend9_gather_w(const Field (&src)[NF], const Spacing &sp, f3 org, const f3 (&mp)[9],
+                                                const float (&w)[NF], float (&sum)[NF], float (&value)[NF])
+{
+    if (!PT) {
+#pragma unroll
+        for (int ii = 0; ii < 8; ii++) {
+            const Cell c = locate<P2>(src[0], sp, org, mp[ii]);
+#pragma unroll
+            for (int f = 0; f < NF; f++) sum[f] += w[f] * gather(src[f], c);
+        }
+    }
+    const Cell c = locate<P2>(src[0], sp, org, mp[8]);
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        value[f] = gather(src[f], c);
+        if (PT) sum[f] += w[f] * value[f];
+    }
+}
+template <bool P2, bool PT, int NF>
+__device__ __forceinline__ void blend9_gather(const Field (&src)[NF], const Spacing &sp, f3 org, const f3 (&mp)[9],
+                                              float (&sum)[NF], float (&value)[NF])
+{
+    float w[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) w[f] = PT ? 1.0f : 0.125f;
+    blend9_gather_w<P2, PT, NF>(src, sp, org, mp, w, sum, value);
+}
+
 // Batches: NF fields that live on the same nodes share one map look-up (density + temperature; the
 // two velocity-change fields accumulated back to back).  Results per field are what NF single
 // launches in the same order produce.
@@ -137,19 +169,15 @@ __global__ __launch_bounds__(256) void advect_kernel(AdvectArgs<NF> a,
     mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    // taps outermost: cell and weights of a tap are found once and serve every field of the batch
+    Field src[NF];
+    float sum[NF], value[NF];
 #pragma unroll
-    for (int f = 0; f < NF; f++) {
-        Field src = make_field(a.init[f], nbi, nbj, nbk, g.koff);
-        float sum = 0.f;
-        if (PT) {
-            sum += 1.0f * sample<P2>(src, sp, n.org, mp[8]);
-        } else {
+    for (int f = 0; f < NF; f++) { src[f] = make_field(a.init[f], nbi, nbj, nbk, g.koff); sum[f] = 0.f; }
+    blend9_gather<P2, PT, NF>(src, sp, n.org, mp, sum, value);
 #pragma unroll
-            for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, mp[ii]);
-        }
-        float value = sample<P2>(src, sp, n.org, mp[8]);
-        a.field[f][(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum + 0.5f * value;
-    }
+    for (int f = 0; f < NF; f++)
+        a.field[f][(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum[f] + 0.5f * value[f];
 }
 
 // ---- A7: doubleAdvect_kernel (GPU_kernel.cu:236-310) --------------------------------------
@@ -243,20 +271,19 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
     mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    Field src[NF];
+    float sum[NF], value[NF], w[NF];
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
-        const float coeff = a.coeff[f];
-        float sum = 0.f;
-        if (PT) {
-            sum += 1.0f * coeff * sample<P2>(src, sp, n.org, mp[8]);
-        } else {
+        src[f] = make_field(a.src[f], nbi, nbj, nbk, g.koff);
+        sum[f] = 0.f;
+        w[f] = (PT ? 1.0f : 0.125f) * a.coeff[f];   // (0.125f * coeff) * sample: the reference's left-to-right product
+    }
+    blend9_gather_w<P2, PT, NF>(src, sp, n.org, mp, w, sum, value);
 #pragma unroll
-            for (int ii = 0; ii < 8; ii++) sum += 0.125f * coeff * sample<P2>(src, sp, n.org, mp[ii]);
-        }
-        float value = coeff * sample<P2>(src, sp, n.org, mp[8]);
-        sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
-        a.dst[f][id] += sum;            // dst[0] == dst[1] is allowed: applied in order
+    for (int f = 0; f < NF; f++) {
+        const float v = a.coeff[f] * value[f];
+        a.dst[f][id] += (float)(0.5 * (double)sum[f] + 0.5 * (double)v);     // dst[0] == dst[1] is allowed: applied in order
     }
 }
 
@@ -279,20 +306,14 @@ __global__ __launch_bounds__(256) void compensate_kernel(CompensateArgs<NF> a,
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
     const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    Field src[NF];
+    float sum[NF], value[NF];
 #pragma unroll
-    for (int f = 0; f < NF; f++) {
-        Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
-        float sum = 0.f;
-        if (PT) {
-            sum += 1.0f * sample<P2>(src, sp, n.org, mp[8]);
-        } else {
+    for (int f = 0; f < NF; f++) { src[f] = make_field(a.src[f], nbi, nbj, nbk, g.koff); sum[f] = 0.f; }
+    blend9_gather<P2, PT, NF>(src, sp, n.org, mp, sum, value);
 #pragma unroll
-            for (int ii = 0; ii < 8; ii++) sum += 0.125f * sample<P2>(src, sp, n.org, mp[ii]);
-        }
-        float value = sample<P2>(src, sp, n.org, mp[8]);
-        sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
-        a.err[f][id] = sum - a.init[f][id];
-    }
+    for (int f = 0; f < NF; f++)
+        a.err[f][id] = (float)(0.5 * (double)sum[f] + 0.5 * (double)value[f]) - a.init[f][id];
 }
 
 // ---- A6: clampExtrema_kernel (GPU_kernel.cu:146-167) --------------------------------------
