@@ -31,8 +31,8 @@ JACOBI_BYTES_PER_VOXEL = 12.0   # read p + read div + write p'  
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=180)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", dest="n", type=int, default=256, help="grid is size^3 (per rank when --gpus > 1)")
     ap.add_argument("--jacobi-iters", type=int, default=200)
     ap.add_argument("--halfrdx", type=float, default=0.5)
@@ -45,15 +45,36 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a port: the reference has no runnable CPU path for bimocq3D) on this box's
-    host cores, on a bounded sample of the same scene: smaller grid, same algorithm and settings."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def usable_cores():
+    """CPU threads this job may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    hands a one-GPU job a share of the host's cores; more OpenMP threads than that only thrash)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = int(os.environ.get("BENCH_CPU_THREADS", min(cores, 64)))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read().split()[0])
+            if quota not in ("max", "-1"):
+                cores = min(cores, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(cores, 64))
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port: the reference has no runnable CPU path for bimocq3D) on this box's
+    host cores, on a bounded sample of the same scene: smaller grid, same algorithm and settings."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = int(os.environ.get("BENCH_CPU_THREADS", usable_cores()))
     os.environ["OMP_NUM_THREADS"] = str(cores)                  # read by libgomp when the oracle is loaded
     import oracle_lib
     oracle_lib.lib(march="native", out="_build_native")        # rebuilt for this host's ISA
