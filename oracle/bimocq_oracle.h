@@ -116,6 +116,28 @@ void orc_divergence(const float *u, const float *v, const float *w, float *div,
                     int ni, int nj, int nk, float halfrdx);
 void orc_jacobi_sweep(const float *p, const float *div, float *out,
                       int ni, int nj, int nk, float alpha, float beta);
+/* ---- fp64 multigrid-CG projection (mgcg_oracle.c; GPU_kernel.cu:1420-1815) ---- */
+typedef struct OrcCoarseLevel {          /* layout of SCoarseLevelInfo, GPU_Advection.h:15-24 */
+    int ni, nj, nk;
+    int number;
+    double alpha;
+    double beta;
+    double *b;
+    double *x;
+    double *r;
+} OrcCoarseLevel;
+void orc_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div, double *p, double *dir,
+                                       double *residual, double *temp0, double *temp1, double *tempResult,
+                                       OrcCoarseLevel *levels, int levelNum, int iter, double halfrdx);
+void orc_mg_divergence(const float *u, const float *v, const float *w, double *div, int ni, int nj, int nk, double halfrdx);
+void orc_mg_poisson(const double *x, double *b, int ni, int nj, int nk);
+void orc_mg_residual(double *r, const double *b, const double *x, int ni, int nj, int nk);
+void orc_mg_dot_partials(const double *v0, const double *v1, double *output, long count);
+void orc_mg_calc_sum(const double *v, double *output, long count, long per_thread, int iter_index);
+void orc_mg_calc_max(const double *v, double *output, long count, int iter_index);
+void orc_mg_smooth(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter);
+void orc_mg_restrict(const double *residual, double *coarse, int ni, int nj, int nk, int ci, int cj, int ck);
+void orc_mg_prolong(double *x, const double *coarse, int ni, int nj, int nk, int ci, int cj, int ck);
 void orc_jacobi_sweep_range(const float *p, const float *div, float *out,
                             int ni, int nj, int nk, int k_begin, int k_end, float alpha, float beta);
 void orc_gradient(float *field, const float *p, int nbi, int nbj, int nbk,

@@ -18,10 +18,34 @@ c_f, c_i = C.c_float, C.c_int
 def build(march="x86-64", out="_build"):
     """(re)build liboracle.so with gcc; returns its path."""
     so = os.path.join(ORACLE_DIR, out, "liboracle.so")
-    src = [os.path.join(ORACLE_DIR, f) for f in ("bimocq_oracle.c", "bimocq_oracle.h", "Makefile")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("bimocq_oracle.c", "mgcg_oracle.c", "bimocq_oracle.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, f"MARCH={march}", f"OUT={out}"])
     return so
+
+
+class CoarseLevel(C.Structure):
+    """SCoarseLevelInfo (GPU_Advection.h:15-24)"""
+    _fields_ = [("ni", c_i), ("nj", c_i), ("nk", c_i), ("number", c_i), ("alpha", C.c_double), ("beta", C.c_double),
+                ("b", C.c_void_p), ("x", C.c_void_p), ("r", C.c_void_p)]
+
+
+DP = C.POINTER(C.c_double)
+
+
+def dp(a):
+    """double* of a contiguous float64 numpy array"""
+    assert a.dtype.name == "float64" and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(DP)
+
+
+def level_dims(ni, nj, nk, count):
+    """the reference's level pyramid (BimocqGPUSolver.cpp:68-90): n -> (n - 1) / 2"""
+    dims = [(ni, nj, nk)]
+    for _ in range(1, count):
+        a, b, c = dims[-1]
+        dims.append(((a - 1) // 2, (b - 1) // 2, (c - 1) // 2))
+    return dims
 
 
 class Emitter(C.Structure):
@@ -48,6 +72,16 @@ _SIGS = {
     "orc_compensate_error_velocity": (None, [FP] * 12 + [c_f, c_i, c_i, c_i, c_i]),
     "orc_compensate_error_field": (None, [FP] * 6 + [c_f, c_i, c_i, c_i, c_i]),
     "orc_jacobi_sweep_range": (None, [FP] * 3 + [c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "orc_multi_grid_conjugate_gradient": (None, [FP] * 3 + [DP] * 7 + [C.POINTER(CoarseLevel), c_i, c_i, C.c_double]),
+    "orc_mg_divergence": (None, [FP] * 3 + [DP, c_i, c_i, c_i, C.c_double]),
+    "orc_mg_poisson": (None, [DP, DP, c_i, c_i, c_i]),
+    "orc_mg_residual": (None, [DP, DP, DP, c_i, c_i, c_i]),
+    "orc_mg_dot_partials": (None, [DP, DP, DP, C.c_long]),
+    "orc_mg_calc_sum": (None, [DP, DP, C.c_long, C.c_long, c_i]),
+    "orc_mg_calc_max": (None, [DP, DP, C.c_long, c_i]),
+    "orc_mg_smooth": (None, [DP, DP, DP, C.c_double, C.c_double, c_i, c_i, c_i, c_i]),
+    "orc_mg_restrict": (None, [DP, DP] + [c_i] * 6),
+    "orc_mg_prolong": (None, [DP, DP] + [c_i] * 6),
     "orc_semilag": (None, [FP] * 5 + [c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_f]),
     "orc_emit_smoke": (None, [FP] * 5 + [c_f, c_i, c_i, c_i] + [c_f] * 7),
     "orc_add_buoyancy": (None, [FP] * 3 + [c_i, c_i, c_i, c_f, c_f, c_f]),
