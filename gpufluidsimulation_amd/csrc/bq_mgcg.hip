@@ -1,0 +1,388 @@
+// bq_mgcg.hip -- fp64 multigrid-corrected CG pressure projection:
+// gpu_multi_grid_conjugate_gradient, src/bimocq3D/GPU_kernel.cu:1764-1815 and everything it launches
+// (:1043-1338 CG helpers, :1420-1707 smoothing / restriction / prolongation / V_Cycle).
+//
+// Same buffers, same launch order, same arithmetic as the reference, so the stale boundary entries the
+// interior-only kernels leave behind (oracle/mgcg_oracle.c, M5) carry the same values.  The quirks that
+// change values are kept (M1 the float-narrowed, mis-indexed block dot product; M2 float lerps inside
+// the fp64 transfer operators; M3 alpha*8 on level 1 only; M4 unclamped coarse look-ups, with reads past
+// the end of an array returning 0).  What is ours: launch geometry (3-D grids, x fastest), the reductions'
+// work split where the order does not matter (calc_max), one stream, no per-call allocation.
+//
+// Bounds: every kernel here streams fp64 arrays -- 24 B/cell per smoothing sweep (x, b in, x' out).  At
+// 256^3 the three level-0 arrays (402 MB) exceed the 256 MiB Infinity Cache, so the level-0 sweeps are
+// HBM-bound; levels >= 1 (<= 50 MB) live in the cache.
+#include "bq_host.h"
+
+#include <cstdint>
+
+namespace bq {
+
+// ---- index helpers ------------------------------------------------------------------------------
+static const dim3 kBlk(64, 4, 1);
+static inline dim3 grid_of(int ni, int nj, int nk) { return dim3((ni + 63) / 64, (nj + 3) / 4, nk); }
+#define MG_IJK(NI, NJ, NK)                                                                   \
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z; \
+    if (i >= (NI) || j >= (NJ) || k >= (NK)) return;
+#define MG_INTERIOR(NI, NJ, NK) (i > 0 && i < (NI) - 1 && j > 0 && j < (NJ) - 1 && k > 0 && k < (NK) - 1)
+
+__device__ __forceinline__ size_t id3(int i, int j, int k, int ni, int nj) { return (size_t)i + (size_t)ni * j + (size_t)ni * nj * k; }
+
+// calc_poisson_value (:1048-1060): (l + r + f + b + d + u) - c*6
+__device__ __forceinline__ double poisson_value(const double *x, size_t id, size_t sj, size_t sk)
+{
+    return (x[id - 1] + x[id + 1] + x[id - sj] + x[id + sj] + x[id - sk] + x[id + sk]) - x[id] * 6;
+}
+
+// divergence_kernel, double overload (:991-1007): every cell
+__global__ __launch_bounds__(256) void mg_divergence_kernel(const float *__restrict__ u, const float *__restrict__ v,
+                                                            const float *__restrict__ w, double *__restrict__ div,
+                                                            int ni, int nj, int nk, double halfrdx)
+{
+    MG_IJK(ni, nj, nk)
+    const double ul = u[id3(i, j, k, ni + 1, nj)], ur = u[id3(i + 1, j, k, ni + 1, nj)];
+    const double vf = v[id3(i, j, k, ni, nj + 1)], vb = v[id3(i, j + 1, k, ni, nj + 1)];
+    const double wd = w[id3(i, j, k, ni, nj)],     wu = w[id3(i, j, k + 1, ni, nj)];
+    div[id3(i, j, k, ni, nj)] = halfrdx * ((ur - ul) + (vb - vf) + (wu - wd));
+}
+
+// calc_poisson_kernel (:1075-1085) and update_residual_kernel (:1251-1261), double, interior only
+__global__ __launch_bounds__(256) void mg_poisson_kernel(const double *__restrict__ x, double *__restrict__ b, int ni, int nj, int nk)
+{
+    MG_IJK(ni, nj, nk)
+    if (!MG_INTERIOR(ni, nj, nk)) return;
+    const size_t id = id3(i, j, k, ni, nj);
+    b[id] = poisson_value(x, id, ni, (size_t)ni * nj);
+}
+__global__ __launch_bounds__(256) void mg_residual_kernel(double *__restrict__ r, const double *__restrict__ b,
+                                                          const double *__restrict__ x, int ni, int nj, int nk)
+{
+    MG_IJK(ni, nj, nk)
+    if (!MG_INTERIOR(ni, nj, nk)) return;
+    const size_t id = id3(i, j, k, ni, nj);
+    r[id] = b[id] - poisson_value(x, id, ni, (size_t)ni * nj);
+}
+
+// dot_vector_kernel (:1087-1126), M1: one block per 256 elements, the reference's summation tree
+__global__ __launch_bounds__(256) void mg_dot_kernel(const double *__restrict__ v0, const double *__restrict__ v1,
+                                                     double *__restrict__ output, size_t count)
+{
+    __shared__ double sh[272];
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    sh[threadIdx.x] = id < count ? v0[id] * v1[id] : 0.0;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        double s = sh[t * 16];
+#pragma unroll
+        for (int q = 1; q < 16; q++) s = s + sh[t * 16 + q];
+        sh[256 + t] = (double)(float)s;                     // `float sum0`
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = sh[256 + 0] + sh[256 + 1] + sh[256 + 2] + sh[3] +
+                   sh[256 + 4] + sh[256 + 5] + sh[256 + 6] + sh[7] +
+                   sh[256 + 8] + sh[256 + 9] + sh[256 + 10] + sh[11] +
+                   sh[256 + 12] + sh[256 + 13] + sh[256 + 14] + sh[15];
+        output[blockIdx.x] = (double)(float)s;              // `float sum`
+    }
+}
+
+// calc_sum_kernel<<<1,256>>> (:1134-1183): thread t sums `per_thread` consecutive partials, then 16x16
+__global__ __launch_bounds__(256) void mg_calc_sum_kernel(const double *__restrict__ v, double *__restrict__ output,
+                                                          size_t count, size_t per_thread, int iter_index)
+{
+    __shared__ double sh[272];
+    double s = 0;
+    const size_t start = (size_t)threadIdx.x * per_thread;
+    for (size_t q = 0; q < per_thread; q++)
+        if (start + q < count) s += v[start + q];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        double a = sh[t * 16];
+#pragma unroll
+        for (int q = 1; q < 16; q++) a = a + sh[t * 16 + q];
+        sh[256 + t] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sh[256];
+#pragma unroll
+        for (int q = 1; q < 16; q++) a = a + sh[256 + q];
+        output[iter_index] = a;
+    }
+}
+
+// calc_max (:1185-1237): max(v, 0) over the array -- order-free, so split over many blocks
+__global__ __launch_bounds__(256) void mg_max_partial_kernel(const double *__restrict__ v, size_t count, double *__restrict__ part)
+{
+    double m = 0;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) m = fmax(m, v[q]);
+    __shared__ double sh[256];
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void mg_max_final_kernel(const double *__restrict__ part, int nparts, double *output, int iter_index)
+{
+    double m = 0;
+    for (int q = threadIdx.x; q < nparts; q += 256) m = fmax(m, part[q]);
+    __shared__ double sh[256];
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) output[iter_index] = sh[0];
+}
+
+// update_x_kernel / update_dir_kernel / mul_kernel / add_kernel (:1275-1338), double
+__global__ __launch_bounds__(256) void mg_update_x_kernel(double *__restrict__ x, const double *__restrict__ dir,
+                                                          const double *__restrict__ alpha, size_t count, int r_index, int d_index)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < count) x[id] += dir[id] * alpha[r_index] / alpha[d_index];
+}
+__global__ __launch_bounds__(256) void mg_update_dir_kernel(double *__restrict__ dir, const double *__restrict__ residual,
+                                                            const double *__restrict__ beta, size_t count, int r_index, int rplus_index)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < count) dir[id] = residual[id] + dir[id] * beta[rplus_index] / beta[r_index];
+}
+__global__ __launch_bounds__(256) void mg_mul_kernel(double *__restrict__ result, const double *__restrict__ field, double constant, size_t count)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < count) result[id] = field[id] * constant;
+}
+__global__ __launch_bounds__(256) void mg_add_kernel(double *__restrict__ f0, const double *__restrict__ f1, double coef, size_t count)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < count) f0[id] += f1[id] * coef;
+}
+
+// smoothing_jacobi_kernel, double (:1443-1461): interior only
+__global__ __launch_bounds__(256) void mg_smooth_kernel(const double *__restrict__ x, const double *__restrict__ b,
+                                                        double *__restrict__ out, double alpha, double beta, int ni, int nj, int nk)
+{
+    MG_IJK(ni, nj, nk)
+    if (!MG_INTERIOR(ni, nj, nk)) return;
+    const size_t sj = ni, sk = (size_t)ni * nj, id = id3(i, j, k, ni, nj);
+    out[id] = ((x[id - 1] + x[id + 1] + x[id - sj] + x[id + sj] + x[id - sk] + x[id + sk]) + alpha * b[id]) * beta;
+}
+
+// GPU_kernel.cu:22-25 on float operands (M2)
+__device__ __forceinline__ float lerp_f(float a, float b, float c)
+{
+    const float cb = c * b;
+    return (float)((1.0 - (double)c) * (double)a + (double)cb);
+}
+
+// sample_buffer<double> (:1527-1549): no clamping (M4); `count` = elements of the array
+__device__ __forceinline__ double sample_t(const double *b, int nx, int ny, long long count, float px, float py, float pz)
+{
+    const int i = (int)floorf(px), j = (int)floorf(py), k = (int)floorf(pz);
+    const float a = px - (float)i, bb = py - (float)j, c = pz - (float)k;
+    const long long sj = nx, sk = (long long)nx * ny;
+    const long long base = (long long)i + sj * j + sk * k;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const long long id = base + (q & 1) + ((q >> 1) & 1) * sj + ((q >> 2) & 1) * sk;
+        v[q] = (id >= 0 && id < count) ? (float)b[id] : 0.f;
+    }
+    return (double)lerp_f(lerp_f(lerp_f(v[0], v[1], a), lerp_f(v[2], v[3], a), bb),
+                          lerp_f(lerp_f(v[4], v[5], a), lerp_f(v[6], v[7], a), bb), c);
+}
+
+// restriction_kernel, double (:1551-1603): every coarse cell = mean of 8 samples at the fine cell centres
+__global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restrict__ residual, double *__restrict__ coarse,
+                                                          int ni, int nj, int nk, int ci, int cj, int ck)
+{
+    MG_IJK(ci, cj, ck)
+    const long long count = (long long)ni * nj * nk;
+    const float x0 = (float)(2 * i + 0.5), x1 = (float)(2 * i + 1.5);
+    const float y0 = (float)(2 * j + 0.5), y1 = (float)(2 * j + 1.5);
+    const float z0 = (float)(2 * k + 0.5), z1 = (float)(2 * k + 1.5);
+    const double v0 = sample_t(residual, ni, nj, count, x0, y0, z0);
+    const double v1 = sample_t(residual, ni, nj, count, x0, y0, z1);
+    const double v2 = sample_t(residual, ni, nj, count, x0, y1, z0);
+    const double v3 = sample_t(residual, ni, nj, count, x0, y1, z1);
+    const double v4 = sample_t(residual, ni, nj, count, x1, y0, z0);
+    const double v5 = sample_t(residual, ni, nj, count, x1, y0, z1);
+    const double v6 = sample_t(residual, ni, nj, count, x1, y1, z0);
+    const double v7 = sample_t(residual, ni, nj, count, x1, y1, z1);
+    coarse[id3(i, j, k, ci, cj)] = (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7) / 8;
+}
+
+// prolongation_kernel, double (:1610-1621): fine interior += trilinear sample of the coarse correction
+__global__ __launch_bounds__(256) void mg_prolong_kernel(double *__restrict__ x, const double *__restrict__ coarse,
+                                                         int ni, int nj, int nk, int ci, int cj, int ck)
+{
+    MG_IJK(ni, nj, nk)
+    if (!MG_INTERIOR(ni, nj, nk)) return;
+    const float px = (float)((double)((float)i / 2.f) - 0.5);
+    const float py = (float)((double)((float)j / 2.f) - 0.5);
+    const float pz = (float)((double)((float)k / 2.f) - 0.5);
+    x[id3(i, j, k, ni, nj)] += sample_t(coarse, ci, cj, (long long)ci * cj * ck, px, py, pz);
+}
+
+// gradient_kernel, double p (:1009-1023): the three components in one launch
+__global__ __launch_bounds__(256) void mg_gradient_kernel(float *__restrict__ u, float *__restrict__ v, float *__restrict__ w,
+                                                          const double *__restrict__ p, int ni, int nj, int nk, double halfrdx)
+{
+    MG_IJK(ni + 1, nj + 1, nk + 1)
+    const size_t sj = ni, sk = (size_t)ni * nj;
+    // component c: buffer dims (ni+dx, nj+dy, nk+dz); window 2 <= idx < p-dims on every axis
+    if (i > 1 && i < ni && j > 1 && j < nj && k > 1 && k < nk) {
+        const size_t id = id3(i, j, k, ni, nj);
+        const double p0 = p[id];
+        u[id3(i, j, k, ni + 1, nj)] -= (float)(halfrdx * (p0 - p[id - 1]));
+        v[id3(i, j, k, ni, nj + 1)] -= (float)(halfrdx * (p0 - p[id - sj]));
+        w[id3(i, j, k, ni, nj)]     -= (float)(halfrdx * (p0 - p[id - sk]));
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static inline unsigned blocks1d(size_t count) { return (unsigned)((count + 255) / 256); }
+
+static void mg_zero(double *p, size_t count) { BQ_HIP(hipMemsetAsync(p, 0, count * sizeof(double), rt().compute)); }
+
+// smoothing_jacobi (:1464-1483): odd counts are rounded up, so the newest iterate always ends in x
+static void mg_smooth(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
+{
+    if (iter % 2 == 1) iter += 1;
+    if (ni < 3 || nj < 3 || nk < 3) return;             // no interior: every sweep is a no-op
+    double *in = x, *out = temp;
+    for (int s = 0; s < iter; s++) {
+        mg_smooth_kernel<<<grid_of(ni, nj, nk), kBlk, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk);
+        double *t = in; in = out; out = t;
+    }
+    BQ_LAUNCH_CHECK("mg_smooth_kernel");
+}
+
+static void mg_residual(double *r, const double *b, const double *x, int ni, int nj, int nk)
+{
+    mg_residual_kernel<<<grid_of(ni, nj, nk), kBlk, 0, rt().compute>>>(r, b, x, ni, nj, nk);
+    BQ_LAUNCH_CHECK("mg_residual_kernel");
+}
+
+static void mg_dot(const double *v0, const double *v1, double *partials, double *result, size_t count, int iter_index)
+{
+    const unsigned nb = blocks1d(count);
+    mg_dot_kernel<<<nb, 256, 0, rt().compute>>>(v0, v1, partials, count);
+    mg_calc_sum_kernel<<<1, 256, 0, rt().compute>>>(partials, result, nb, (nb + 255) / 256, iter_index);
+    BQ_LAUNCH_CHECK("mg_dot");
+}
+
+static void mg_max(const double *v, double *result, size_t count, int iter_index)
+{
+    const int nparts = 1024;
+    double *part = (double *)scratch(nparts * sizeof(double));
+    if (!part) return;
+    mg_max_partial_kernel<<<nparts, 256, 0, rt().compute>>>(v, count, part);
+    mg_max_final_kernel<<<1, 256, 0, rt().compute>>>(part, nparts, result, iter_index);
+    BQ_LAUNCH_CHECK("mg_max");
+}
+
+// V_Cycle, multi-level form (:1636-1707), `else` branch
+static void v_cycle(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+{
+    double scale[LEVEL_COUNT] = { 1.0, 1.0, 1.0, 1.0, 1.0, 1.0 };
+    scale[1] = 8.0;                                                                          // M3
+    hipStream_t st = rt().compute;
+    const size_t n0 = (size_t)L[0].number;
+    BQ_HIP(hipMemcpyAsync(L[0].b, residual, n0 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    // The reference clears all n0 entries of temp0 before every smoothing call; a level-l smoothing only
+    // ever touches the first L[l].number of them, so that is what is cleared.  (What stays behind in the
+    // rest of temp0 is later seen only at boundary indices of the level-0 product dir*A(dir), where dir
+    // is 0: no value depends on it.)
+    for (int l = 0; l < levelnum - 1; l++) {
+        mg_zero(temp0, (size_t)L[l].number);
+        mg_zero(L[l].x, (size_t)L[l].number);
+        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, 32);
+        mg_residual(L[l].r, L[l].b, L[l].x, L[l].ni, L[l].nj, L[l].nk);
+        mg_restrict_kernel<<<grid_of(L[l + 1].ni, L[l + 1].nj, L[l + 1].nk), kBlk, 0, st>>>(
+            L[l].r, L[l + 1].b, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
+        BQ_LAUNCH_CHECK("mg_restrict_kernel");
+    }
+    const int c = levelnum - 1;
+    mg_zero(temp0, (size_t)L[c].number);
+    mg_zero(L[c].x, (size_t)L[c].number);
+    mg_smooth(L[c].x, L[c].b, temp0, L[c].alpha * scale[c], L[c].beta, L[c].ni, L[c].nj, L[c].nk, 32);
+    for (int l = levelnum - 2; l >= 0; --l) {
+        mg_prolong_kernel<<<grid_of(L[l].ni, L[l].nj, L[l].nk), kBlk, 0, st>>>(
+            L[l].x, L[l + 1].x, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
+        BQ_LAUNCH_CHECK("mg_prolong_kernel");
+        mg_zero(temp0, (size_t)L[l].number);
+        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, 4);
+    }
+    mg_add_kernel<<<blocks1d(n0), 256, 0, st>>>(x, L[0].x, 1.0, n0);
+    BQ_LAUNCH_CHECK("mg_add_kernel");
+    mg_residual(residual, b, x, L[0].ni, L[0].nj, L[0].nk);
+}
+
+} // namespace bq
+
+using namespace bq;
+
+extern "C" {
+
+void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div, double *p,
+                                       double *dir, double *residual, double *temp0, double *temp1,
+                                       double *tempResult, struct SCoarseLevelInfo *levels,
+                                       int levelNum, int iter, double halfrdx)
+{
+    const char *op = "gpu_multi_grid_conjugate_gradient";
+    if (!ensure_ready(op)) return;
+    BQ_REQUIRE(u && v && w && div && p && dir && residual && temp0 && temp1 && tempResult && levels, op);
+    BQ_REQUIRE(levelNum >= 1 && levelNum <= LEVEL_COUNT && iter >= 0, op);
+    BQ_REQUIRE(2 * iter + 2 < 2000 && 2001 + iter <= 4096, op);         // tempResult layout: [0, 2*iter+2], [2000, 2000+iter]
+    if (rt().slab_on) { latch(FL_ERR_UNSUPPORTED, op, "not built for z-slab ranks yet (use the Jacobi projection)"); return; }
+    for (int l = 0; l < levelNum; l++) {
+        const SCoarseLevelInfo &L = levels[l];
+        BQ_REQUIRE(L.ni >= 1 && L.nj >= 1 && L.nk >= 1 && L.nk < 65535 && L.b && L.x && L.r, op);
+        BQ_REQUIRE((long long)L.ni * L.nj * L.nk == (long long)L.number, op);
+    }
+    const int ni = levels[0].ni, nj = levels[0].nj, nk = levels[0].nk;
+    const size_t number = (size_t)levels[0].number;
+    hipStream_t st = rt().compute;
+
+    mg_divergence_kernel<<<grid_of(ni, nj, nk), kBlk, 0, st>>>(u, v, w, div, ni, nj, nk, halfrdx);
+    BQ_LAUNCH_CHECK("mg_divergence_kernel");
+    mg_zero(p, number);
+    mg_residual(residual, div, p, ni, nj, nk);
+    mg_mul_kernel<<<blocks1d(number), 256, 0, st>>>(dir, residual, 1, number);
+    BQ_LAUNCH_CHECK("mg_mul_kernel");
+    mg_max(residual, tempResult, number, 2000);
+    mg_dot(residual, residual, temp0, tempResult, number, 0);                               // r.r
+
+    for (int it = 0; it < iter; it++) {
+        const int off = it * 2;
+        // smoothing_conjugate_gradient (:1485-1495): aMulDir = temp0, dotDir = temp1
+        mg_poisson_kernel<<<grid_of(ni, nj, nk), kBlk, 0, st>>>(dir, temp0, ni, nj, nk);
+        BQ_LAUNCH_CHECK("mg_poisson_kernel");
+        mg_dot(dir, temp0, temp1, tempResult, number, off + 1);
+        mg_update_x_kernel<<<blocks1d(number), 256, 0, st>>>(p, dir, tempResult, number, off, off + 1);
+        BQ_LAUNCH_CHECK("mg_update_x_kernel");
+        mg_residual(residual, div, p, ni, nj, nk);
+
+        v_cycle(div, p, residual, levels, temp0, levelNum);
+        mg_max(residual, tempResult, number, 2001 + it);
+
+        // updateDir (:1497-1503)
+        mg_dot(residual, residual, temp0, tempResult, number, off + 2);
+        mg_update_dir_kernel<<<blocks1d(number), 256, 0, st>>>(dir, residual, tempResult, number, off, off + 2);
+        BQ_LAUNCH_CHECK("mg_update_dir_kernel");
+    }
+    mg_gradient_kernel<<<grid_of(ni + 1, nj + 1, nk + 1), kBlk, 0, st>>>(u, v, w, p, ni, nj, nk, halfrdx);
+    BQ_LAUNCH_CHECK("mg_gradient_kernel");
+}
+
+} // extern "C"

@@ -753,10 +753,6 @@ void gpu_conjugate_gradient(float *, float *, float *, float *, float *, float *
     latch(FL_ERR_UNSUPPORTED, "gpu_conjugate_gradient", "out of scope: alternative solver compiled out in the reference");
 }
 
-void gpu_multi_grid_conjugate_gradient(float *, float *, float *, double *, double *, double *, double *, double *, double *,
-                                       double *, struct SCoarseLevelInfo *, int, int, double)
-{
-    latch(FL_ERR_UNSUPPORTED, "gpu_multi_grid_conjugate_gradient", "not built yet (SURVEY 8f N1)");
-}
+// gpu_multi_grid_conjugate_gradient: bq_mgcg.hip
 
 } // extern "C"

@@ -178,7 +178,13 @@ void gpu_conjugate_gradient(float *u, float *v, float *w, float *div, float *p,
                             float *residual, float *dir, float *dotR,
                             int ni, int nj, int nk, int iter, float halfrdx);
 
-/* GPU_Advection.h:107-108 -- NEXT, not built yet.  Latches FL_ERR_UNSUPPORTED. */
+/* GPU_Advection.h:107-108 / GPU_kernel.cu:1764-1815 -- fp64 multigrid-corrected CG projection (what the
+ * reference's shipped binary runs, BimocqGPUSolver.cpp:443-446: iter = 50, LEVEL_COUNT levels, halfrdx 0.5).
+ * `levels` is a HOST array of levelNum entries holding DEVICE pointers (level l has dims (n-1)/2 of level
+ * l-1, BimocqGPUSolver.cpp:68-90); div, p, dir, residual, temp0, temp1: levels[0].number doubles each;
+ * tempResult: 4096 doubles -- [2i], [2i+1], [2i+2] the CG sums of outer iteration i, [2000+i] the largest
+ * positive residual before iteration i.  p is cleared here; the caller owns and zero-allocates the rest
+ * (boundary entries are never written).  Single GPU only: latches FL_ERR_UNSUPPORTED on a z-slab rank. */
 void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div, double *p,
                                        double *dir, double *residual, double *temp0, double *temp1,
                                        double *tempResult, struct SCoarseLevelInfo *levels,
