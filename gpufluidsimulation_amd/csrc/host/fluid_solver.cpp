@@ -151,10 +151,56 @@ void BimocqGPUSolver::diffuseField(float *field, float *t0, float *t1, int ni, i
 }
 
 // :406-467, the Jacobi branch (:409-410): alpha = -1, beta = 1/6
+// BimocqGPUSolver.cpp:60-90: p, dir, residual, div, temp0, temp1 (N doubles each), tempResult (4096), and
+// LEVEL_COUNT levels of b/x/r with dims n -> (n - 1) / 2.  Levels without a single cell are left out (the
+// reference launches empty grids for them).
+bool BimocqGPUSolver::allocMgcg()
+{
+    if (mg.ready) return true;
+    const size_t n = g.n();
+    DeviceBytes *full[] = { &mg.div, &mg.p, &mg.dir, &mg.residual, &mg.temp0, &mg.temp1 };
+    for (DeviceBytes *f : full)
+        if (!f->alloc(n * sizeof(double))) return false;
+    if (!mg.result.alloc(4096 * sizeof(double))) return false;
+    int ni = g.ni, nj = g.nj, nk = g.nk;
+    for (int l = 0; l < LEVEL_COUNT; l++) {
+        if (l) { ni = (ni - 1) / 2; nj = (nj - 1) / 2; nk = (nk - 1) / 2; }
+        if (ni < 1 || nj < 1 || nk < 1) break;
+        SCoarseLevelInfo L{};
+        L.ni = ni; L.nj = nj; L.nk = nk; L.number = ni * nj * nk;
+        L.alpha = -1.0; L.beta = 1.0 / 6.0;
+        mg.b.emplace_back(); mg.x.emplace_back(); mg.r.emplace_back();
+        const size_t bytes = (size_t)L.number * sizeof(double);
+        if (!mg.b.back().alloc(bytes) || !mg.x.back().alloc(bytes) || !mg.r.back().alloc(bytes)) return false;
+        L.b = mg.b.back().f64(); L.x = mg.x.back().f64(); L.r = mg.r.back().f64();
+        mg.levels.push_back(L);
+    }
+    mg.ready = true;
+    return true;
+}
+
+std::vector<double> BimocqGPUSolver::mgHistory() const
+{
+    std::vector<double> h(4096, 0.0);
+    if (mg.ready) fl_memcpy_d2h(h.data(), mg.result.f64(), h.size() * sizeof(double));
+    return h;
+}
+
 void BimocqGPUSolver::projection()
 {
     gpuMapper &gs = *GpuSolver;
     const float alpha = -1.f, beta = (float)(1.0 / 6.0);
+    if (projection_kind == BQ_PROJECTION_MGCG) {            // :443-446
+        if (gs.slab.on && gs.slab.nranks > 1) {
+            fl_report_error(FL_ERR_UNSUPPORTED, "the multigrid-CG projection is single-GPU (use the Jacobi projection on z-slabs)");
+            return;
+        }
+        if (!allocMgcg()) return;
+        gpu_multi_grid_conjugate_gradient(VelocityU, VelocityV, VelocityW, mg.div.f64(), mg.p.f64(), mg.dir.f64(),
+                                          mg.residual.f64(), mg.temp0.f64(), mg.temp1.f64(), mg.result.f64(),
+                                          mg.levels.data(), (int)mg.levels.size(), mg_iters, (double)halfrdx);
+        return;
+    }
     if (!gs.slab.on || gs.slab.nranks <= 1) {
         gs.projectionJacobi(VelocityU, VelocityV, VelocityW, div, p, p_temp, debugParam, jacobi_iters, halfrdx, alpha, beta);
         return;

@@ -48,6 +48,8 @@ public:
     long dump(unsigned frame, const std::string &filepath) { return outputResult(frame, filepath); }
 
     // projection variant (compile-time `#if` in the reference, BimocqGPUSolver.cpp:408-466)
+    int   projection_kind = 0;          // BQ_PROJECTION_JACOBI / BQ_PROJECTION_MGCG
+    int   mg_iters = 50;                // :444
     int   jacobi_iters = 100;           // :409
     float halfrdx = 0.5f;               // :410 (quarter-strength projection; 1.0 is the physical value)
     bool  verbose = false;              // print "[Bimocq GPU Time: ...]" like the reference (:126)
@@ -69,6 +71,15 @@ public:
     DeviceField Temperature, TemperatureInit, TemperaturePrev;
     DeviceField div, p, p_temp;         // the reference lends DensityTemp/TemperatureTemp/TempSrcV here (:410)
     DeviceField debugParam;             // 4096 floats, residual history (:412-417)
+    // fp64 work arrays + level pyramid of the multigrid-CG projection (:60-90), allocated on first use
+    struct Mgcg {
+        DeviceBytes div, p, dir, residual, temp0, temp1, result;
+        std::vector<DeviceBytes> b, x, r;
+        std::vector<SCoarseLevelInfo> levels;
+        bool ready = false;
+    } mg;
+    bool allocMgcg();
+    std::vector<double> mgHistory() const;          // tempResult (4096 doubles), downloaded
 
     std::vector<float> host_density, host_u, host_v, host_w;    // outputResult staging (:538-541)
 

@@ -15,6 +15,28 @@
 
 namespace bqhost {
 
+// untyped zero-filled device allocation (the fp64 arrays of the multigrid projection), RAII
+class DeviceBytes {
+public:
+    DeviceBytes() = default;
+    DeviceBytes(const DeviceBytes &) = delete;
+    DeviceBytes &operator=(const DeviceBytes &) = delete;
+    DeviceBytes(DeviceBytes &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceBytes &operator=(DeviceBytes &&o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DeviceBytes() { release(); }
+    bool alloc(size_t bytes) { release(); p_ = fl_malloc(bytes ? bytes : 8); n_ = p_ ? bytes : 0; return p_ != nullptr; }
+    void release() { if (p_) fl_free(p_); p_ = nullptr; n_ = 0; }
+    double *f64() const { return static_cast<double *>(p_); }
+    size_t bytes() const { return n_; }
+private:
+    void *p_ = nullptr;
+    size_t n_ = 0;
+};
+
 // allocGPUBuffer (GPU_Advection.h:322-326): zero-filled device allocation, RAII.
 class DeviceField {
 public:

@@ -68,8 +68,17 @@ void bq_solver_set_smoke(bq_solver *s, float drop, float rise, const bq_emitter 
 
 void bq_solver_set_projection(bq_solver *s, int kind, int iters, float halfrdx)
 {
-    if (!s || kind != BQ_PROJECTION_JACOBI) return;
-    s->solver->jacobi_iters = iters;
+    if (!s) return;
+    if (kind == BQ_PROJECTION_MGCG) {
+        s->solver->projection_kind = kind;
+        s->solver->mg_iters = iters;
+    } else if (kind == BQ_PROJECTION_JACOBI) {
+        s->solver->projection_kind = kind;
+        s->solver->jacobi_iters = iters;
+    } else {
+        fl_report_error(FL_ERR_BAD_ARGUMENT, "bq_solver_set_projection: unknown projection kind");
+        return;
+    }
     s->solver->halfrdx = halfrdx;
 }
 
@@ -116,6 +125,15 @@ void bq_solver_slab_info(const bq_solver *s, int out[8])
     const SlabCtx &sl = s->mapper->slab;
     out[0] = sl.on; out[1] = sl.rank; out[2] = sl.nranks; out[3] = sl.on ? sl.nkg : s->mapper->g.nk;
     out[4] = sl.on ? sl.own0 : 0; out[5] = sl.on ? sl.own1 : s->mapper->g.nk; out[6] = sl.G; out[7] = s->mapper->g.nk;
+}
+
+long bq_solver_mg_history(const bq_solver *s, double *host, long capacity)
+{
+    if (!s || !s->solver->mg.ready) return 0;
+    const std::vector<double> h = s->solver->mgHistory();
+    if (host)
+        for (long a = 0; a < capacity && a < (long)h.size(); a++) host[a] = h[(size_t)a];
+    return (long)h.size();
 }
 
 float bq_solver_last_cfldt(const bq_solver *s) { return s ? s->solver->last_cfldt : 0.f; }

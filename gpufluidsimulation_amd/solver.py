@@ -32,6 +32,7 @@ HOST_SIGS = {
     "bq_solver_advance": (None, [C.c_void_p, C.c_int, C.c_float]),
     "bq_solver_output_result": (C.c_long, [C.c_void_p, C.c_uint, C.c_char_p]),
     "bq_solver_download": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
+    "bq_solver_mg_history": (C.c_long, [C.c_void_p, C.POINTER(C.c_double), C.c_long]),
     "bq_solver_last_cfldt": (C.c_float, [C.c_void_p]),
     "bq_solver_last_ms": (C.c_float, [C.c_void_p]),
     "bq_solver_reinit_count": (C.c_int, [C.c_void_p]),
@@ -94,8 +95,19 @@ class BimocqGPUSolver:
             arr[i] = Emitter(*e)
         self.lib.bq_solver_set_smoke(self.s, drop, rise, arr, len(emitters))
 
-    def setProjection(self, iters, halfrdx):
-        self.lib.bq_solver_set_projection(self.s, 0, iters, halfrdx)
+    def setProjection(self, iters, halfrdx, kind=0):
+        """kind 0: Jacobi, iters sweeps; kind 1: fp64 multigrid-CG, iters outer iterations (reference: 50)"""
+        self.lib.bq_solver_set_projection(self.s, kind, iters, halfrdx)
+        self._check()
+
+    def mgHistory(self):
+        """tempResult of the last multigrid-CG projection (4096 doubles), or None before the first one"""
+        n = self.lib.bq_solver_mg_history(self.s, None, 0)
+        if not n:
+            return None
+        out = np.zeros(n, dtype=np.float64)
+        self.lib.bq_solver_mg_history(self.s, out.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return out
 
     def setOption(self, option, value):
         """option 1 = BQ_OPT_KEEP_DMC_BORDER"""

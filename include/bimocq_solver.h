@@ -24,7 +24,10 @@ typedef struct bq_emitter {
 } bq_emitter;
 
 enum { BQ_SCHEME_BIMOCQ = 0 };          /* enum Scheme, BimocqSolver.h:29 (others: out of scope) */
-enum { BQ_PROJECTION_JACOBI = 0 };      /* the `#if 0` branch of BimocqGPUSolver::projection     */
+enum {
+    BQ_PROJECTION_JACOBI = 0,           /* the `#if 0` branch of BimocqGPUSolver::projection (:408-417); iters = sweeps      */
+    BQ_PROJECTION_MGCG = 1              /* the `#else` branch (:443-446): fp64 multigrid-CG; iters = outer iterations (50)  */
+};
 
 /* which-ids for bq_solver_download */
 enum {
@@ -62,6 +65,10 @@ long  bq_solver_output_result(bq_solver *s, unsigned frame, const char *path);
 /* copy one device field to host (blocking).  Returns its element count (0 on bad id); copies
  * min(count, capacity) elements when host != NULL. */
 long  bq_solver_download(bq_solver *s, int which, float *host, long capacity);
+/* tempResult of the last multigrid-CG projection (4096 doubles: CG sums at [0..2*iters+2], largest positive
+ * residual per outer iteration at [2000..2000+iters] -- what the reference prints, BimocqGPUSolver.cpp:447-452).
+ * Returns the count (0 before the first MGCG projection); copies min(count, capacity). */
+long  bq_solver_mg_history(const bq_solver *s, double *host, long capacity);
 float bq_solver_last_cfldt(const bq_solver *s);
 float bq_solver_last_ms(const bq_solver *s);          /* event time of the last advance()        */
 int   bq_solver_reinit_count(const bq_solver *s);

@@ -829,6 +829,10 @@ struct orc_solver {
     size_t n, nu, nv, nw;
     float h, viscosity, blend, alpha, beta;
     int jacobi_iters; float halfrdx;
+    /* projection(): 0 = Jacobi (`#if 0` branch), 1 = fp64 multigrid-CG (the `#else` branch, :443-446) */
+    int projection_kind, mg_iters, mg_levels;
+    double *mg_div, *mg_p, *mg_dir, *mg_res, *mg_t0, *mg_t1, *mg_result;
+    OrcCoarseLevel mg_level[6];
     /* BimocqGPUSolver.h:74-87 buffer roles */
     float *U, *V, *W, *Ui, *Vi, *Wi, *Up, *Vp, *Wp, *Ut, *Vt, *Wt;
     float *dUp, *dVp, *dWp, *dUe, *dVe, *dWe, *Su, *Sv, *Sw;
@@ -901,6 +905,8 @@ void orc_solver_destroy(orc_solver *s)
                      s->div, s->p, s->pt, s->u_src, s->v_src, s->w_src, s->xo, s->yo, s->zo };
     for (size_t a = 0; a < sizeof all / sizeof *all; a++) free(all[a]);
     mapper_free(&s->vel); mapper_free(&s->scal);
+    free(s->mg_div); free(s->mg_p); free(s->mg_dir); free(s->mg_res); free(s->mg_t0); free(s->mg_t1); free(s->mg_result);
+    for (int l = 0; l < s->mg_levels; l++) { free(s->mg_level[l].b); free(s->mg_level[l].x); free(s->mg_level[l].r); }
     free(s->em);
     free(s);
 }
@@ -920,6 +926,39 @@ void orc_solver_set_option(orc_solver *s, int option, int value)
 {
     if (option == 1) s->keep_dmc_border = value != 0;
 }
+
+/* BimocqGPUSolver.cpp:60-90: the fp64 work arrays and the level pyramid n -> (n - 1) / 2.  Levels that
+ * would have no cell at all are left out (the reference launches empty grids for them). */
+static void mg_alloc(orc_solver *s)
+{
+    if (s->mg_div) return;
+    size_t n = s->n;
+    s->mg_div = calloc(n, sizeof(double)); s->mg_p = calloc(n, sizeof(double)); s->mg_dir = calloc(n, sizeof(double));
+    s->mg_res = calloc(n, sizeof(double)); s->mg_t0 = calloc(n, sizeof(double)); s->mg_t1 = calloc(n, sizeof(double));
+    s->mg_result = calloc(4096, sizeof(double));
+    int ni = s->ni, nj = s->nj, nk = s->nk;
+    s->mg_levels = 0;
+    for (int l = 0; l < 6; l++) {
+        if (l) { ni = (ni - 1) / 2; nj = (nj - 1) / 2; nk = (nk - 1) / 2; }
+        if (ni < 1 || nj < 1 || nk < 1) break;
+        OrcCoarseLevel *L = &s->mg_level[l];
+        L->ni = ni; L->nj = nj; L->nk = nk; L->number = ni * nj * nk;
+        L->alpha = -1.0; L->beta = 1.0 / 6.0;
+        L->b = calloc((size_t)L->number, sizeof(double)); L->x = calloc((size_t)L->number, sizeof(double));
+        L->r = calloc((size_t)L->number, sizeof(double));
+        s->mg_levels = l + 1;
+    }
+}
+
+void orc_solver_set_projection_kind(orc_solver *s, int kind, int iters)
+{
+    s->projection_kind = kind;
+    if (kind == 1) { s->mg_iters = iters; mg_alloc(s); }
+    else s->jacobi_iters = iters;
+}
+
+int orc_solver_mg_levels(const orc_solver *s) { return s->mg_levels; }
+const double *orc_solver_mg_history(const orc_solver *s) { return s->mg_result; }
 
 void orc_solver_set_projection(orc_solver *s, int jacobi_iters, float halfrdx)
 {
@@ -1027,9 +1066,15 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
     memcpy(s->Ut, s->U, bu); memcpy(s->Vt, s->V, bv); memcpy(s->Wt, s->W, bw);   /* :179-181 */
 
     /* projection(): GPU_Advection.h:602-608 zeroes div, p, p_temp first */
-    memset(s->div, 0, bs); memset(s->p, 0, bs); memset(s->pt, 0, bs);
-    orc_projection_jacobi(s->U, s->V, s->W, s->div, s->p, s->pt, NULL, ni, nj, nk,
-                          s->jacobi_iters, s->halfrdx, -1.f, (float)(1.0 / 6.0));
+    if (s->projection_kind == 1) {
+        /* :443-446 projectionMultiGrid(U, V, W, div, p, dir, residual, temp0, temp1, tempResult, levels, ...) */
+        orc_multi_grid_conjugate_gradient(s->U, s->V, s->W, s->mg_div, s->mg_p, s->mg_dir, s->mg_res, s->mg_t0, s->mg_t1,
+                                          s->mg_result, s->mg_level, s->mg_levels, s->mg_iters, (double)s->halfrdx);
+    } else {
+        memset(s->div, 0, bs); memset(s->p, 0, bs); memset(s->pt, 0, bs);
+        orc_projection_jacobi(s->U, s->V, s->W, s->div, s->p, s->pt, NULL, ni, nj, nk,
+                              s->jacobi_iters, s->halfrdx, -1.f, (float)(1.0 / 6.0));
+    }
 
     memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs);               /* :185-186 */
     memcpy(s->dUp, s->U, bu); memcpy(s->dVp, s->V, bv); memcpy(s->dWp, s->W, bw);  /* :188-190 */

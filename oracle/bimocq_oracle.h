@@ -167,6 +167,11 @@ void  orc_solver_set_smoke(orc_solver *s, float drop_alpha, float rise_beta,
                            const orc_emitter *emitters, int n_emitters);
 void  orc_solver_set_projection(orc_solver *s, int jacobi_iters, float halfrdx);
 /* option 1: keep the backward map's border through the DMC update (0 = reference behaviour) */
+/* projection kind: 0 = Jacobi (iters = sweeps), 1 = fp64 multigrid-CG (iters = outer iterations; 50 in
+ * the reference, BimocqGPUSolver.cpp:444) */
+void  orc_solver_set_projection_kind(orc_solver *s, int kind, int iters);
+int   orc_solver_mg_levels(const orc_solver *s);
+const double *orc_solver_mg_history(const orc_solver *s);
 void  orc_solver_set_option(orc_solver *s, int option, int value);
 void  orc_solver_advance(orc_solver *s, int framenum, float dt);
 /* which: 0 rho, 1 T, 2 u, 3 v, 4 w, 5 uinit, 6 vinit, 7 winit, 8 rhoinit, 9 Tinit,

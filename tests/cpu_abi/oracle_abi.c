@@ -112,8 +112,8 @@ void gpu_conjugate_gradient(float *a, float *b, float *c, float *d, float *e, fl
   latch(FL_ERR_UNSUPPORTED, "gpu_conjugate_gradient"); }
 void gpu_multi_grid_conjugate_gradient(float *a, float *b, float *c, double *d, double *e, double *f, double *g,
                                        double *h, double *i, double *j, struct SCoarseLevelInfo *k, int l, int m, double n)
-{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m; (void)n;
-  latch(FL_ERR_UNSUPPORTED, "gpu_multi_grid_conjugate_gradient"); }
+{ /* SCoarseLevelInfo and OrcCoarseLevel share their layout (GPU_Advection.h:15-24) */
+  orc_multi_grid_conjugate_gradient(a, b, c, d, e, f, g, h, i, j, (OrcCoarseLevel *)k, l, m, n); }
 
 /* ---- slab context + communicator (mirrors csrc/bq_halo.hip with the custom transport only) ---- */
 static int s_on, s_koff, s_nkg;

@@ -99,6 +99,9 @@ _SIGS = {
     "orc_solver_destroy": (None, [C.c_void_p]),
     "orc_solver_set_smoke": (None, [C.c_void_p, c_f, c_f, C.POINTER(Emitter), c_i]),
     "orc_solver_set_projection": (None, [C.c_void_p, c_i, c_f]),
+    "orc_solver_set_projection_kind": (None, [C.c_void_p, c_i, c_i]),
+    "orc_solver_mg_levels": (c_i, [C.c_void_p]),
+    "orc_solver_mg_history": (DP, [C.c_void_p]),
     "orc_solver_set_option": (None, [C.c_void_p, c_i, c_i]),
     "orc_solver_advance": (None, [C.c_void_p, c_i, c_f]),
     "orc_solver_field": (FP, [C.c_void_p, c_i, C.POINTER(C.c_long)]),
@@ -145,8 +148,13 @@ class OracleSolver:
             arr[i] = Emitter(*e)
         self.l.orc_solver_set_smoke(self.s, drop, rise, arr, len(emitters))
 
-    def set_projection(self, iters, halfrdx):
-        self.l.orc_solver_set_projection(self.s, iters, halfrdx)
+    def set_projection(self, iters, halfrdx, kind=0):
+        self.l.orc_solver_set_projection(self.s, iters if kind == 0 else 100, halfrdx)
+        self.l.orc_solver_set_projection_kind(self.s, kind, iters)
+
+    def mg_history(self):
+        p = self.l.orc_solver_mg_history(self.s)
+        return np.ctypeslib.as_array(p, shape=(4096,)).copy() if p else None
 
     def set_option(self, option, value):
         self.l.orc_solver_set_option(self.s, option, value)
