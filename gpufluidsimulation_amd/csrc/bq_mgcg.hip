@@ -177,6 +177,175 @@ __global__ __launch_bounds__(256) void mg_smooth_kernel(const double *__restrict
     out[id] = ((x[id - 1] + x[id + 1] + x[id - sj] + x[id + sj] + x[id - sk] + x[id + sk]) + alpha * b[id]) * beta;
 }
 
+// ---- two smoothing sweeps per launch (temporal fusion, register marching) -----------------------------
+// The fp64 counterpart of jacobi_march2_kernel (bq_project.hip): L1 = S(L0), L2 = S(L1) with L1 kept in
+// registers.  A thread owns VEC (1 or 2) consecutive cells of row j and marches along k holding L0 of the
+// rows j-1, j, j+1 on three planes; it evaluates L1 on those rows (the outer two redundantly) and L2 on
+// row j one plane behind.  x-neighbours come from the neighbouring lanes by wave64 shuffle.  A row may
+// span several waves (256 doubles = 2 waves of double2): at a wave boundary lane 0 / lane 63 fetch the
+// L0 values just outside the wave from memory and evaluate the one L1 value there themselves (a few
+// one-lane loads per plane, no LDS, no barrier).  Every value is produced by the reference's expression
+// ((l + r + f + b + d + u) + alpha*rhs) * beta, so two launches of mg_smooth_kernel give the same bits.
+// Preconditions (checked by the launcher): both ping-pong buffers carry the same boundary layer (V_Cycle
+// clears x and temp0 before every smoothing call); VEC == 2 needs an even nx.
+template <int VEC> struct DV { double c[VEC]; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void mg_smooth2_kernel(const double *__restrict__ x, const double *__restrict__ rhs,
+                                                         double *__restrict__ out, double alpha, double beta,
+                                                         int nx, int ny, int nz, int lpr, int nby, int kchunk)
+{
+    const int nblk = gridDim.x;
+    int blk = blockIdx.x;
+    if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);          // XCD-contiguous block order
+    const int by = blk % nby, bz = blk / nby;
+    const int rows = 256 / lpr;
+    const int c = threadIdx.x % lpr, r = threadIdx.x / lpr;
+    const int x0 = VEC * c, j = by * rows + r;
+    const int lane = threadIdx.x & 63;
+    const int kbeg = max(1, bz * kchunk), kend = min(nz - 1, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;
+    const bool xok = x0 < nx;
+    const bool active = xok && j >= 1 && j <= ny - 2;
+    const long long sj = nx, sk = (long long)nx * ny;
+    const bool edgeL = lane == 0 && xok && x0 > 0;                 // a cell x0-1 exists outside this wave
+    const bool edgeR = lane == 63 && x0 + VEC < nx;                // a cell x0+VEC exists outside this wave
+    const int xl = x0 - 1, xr = x0 + VEC;
+
+    auto ldv = [&](const double *ptr, int row, int pl) -> DV<VEC> {
+        DV<VEC> v;
+#pragma unroll
+        for (int a = 0; a < VEC; a++) v.c[a] = 0.0;
+        if (!xok || row < 0 || row >= ny || pl < 0 || pl >= nz) return v;
+        const double *q = ptr + x0 + sj * row + sk * pl;
+        if constexpr (VEC == 2) { const double2 t = *reinterpret_cast<const double2 *>(q); v.c[0] = t.x; v.c[1] = t.y; }
+        else v.c[0] = q[0];
+        return v;
+    };
+    auto lds = [&](const double *ptr, int xx, int row, int pl) -> double {
+        if (xx < 0 || xx >= nx || row < 0 || row >= ny || pl < 0 || pl >= nz) return 0.0;
+        return ptr[xx + sj * row + sk * pl];
+    };
+    // one smoothing evaluation on the thread's cells; lo/ro: the values just outside the wave (edge lanes)
+    auto jac = [&](const DV<VEC> &ce, const DV<VEC> &fr, const DV<VEC> &bk, const DV<VEC> &dn, const DV<VEC> &up,
+                   const DV<VEC> &dv, double lo, double ro, bool boundary) -> DV<VEC> {
+        double left = __shfl_up(ce.c[VEC - 1], 1, 64), right = __shfl_down(ce.c[0], 1, 64);
+        if (lane == 0) left = lo;
+        if (lane == 63) right = ro;
+        DV<VEC> o;
+        if constexpr (VEC == 2) {
+            o.c[0] = ((left + ce.c[1] + fr.c[0] + bk.c[0] + dn.c[0] + up.c[0]) + alpha * dv.c[0]) * beta;
+            o.c[1] = ((ce.c[0] + right + fr.c[1] + bk.c[1] + dn.c[1] + up.c[1]) + alpha * dv.c[1]) * beta;
+        } else {
+            o.c[0] = ((left + right + fr.c[0] + bk.c[0] + dn.c[0] + up.c[0]) + alpha * dv.c[0]) * beta;
+        }
+        if (boundary) return ce;
+        if (x0 == 0) o.c[0] = ce.c[0];
+        if (x0 + VEC - 1 == nx - 1) o.c[VEC - 1] = ce.c[VEC - 1];
+        return o;
+    };
+
+    // L0 of rows j-1, j, j+1 on planes q-1 (Lm), q (Lc), q+1 (Ln); q = plane whose L1 is being built
+    DV<VEC> Lm[3], Lc[3], Ln[3], Dv[3];
+    int q = kbeg - 1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        Lm[a] = ldv(x, j - 1 + a, q - 1);
+        Lc[a] = ldv(x, j - 1 + a, q);
+        Ln[a] = ldv(x, j - 1 + a, q + 1);
+        Dv[a] = ldv(rhs, j - 1 + a, q);
+    }
+    DV<VEC> Hf = ldv(x, j - 2, q), Hb = ldv(x, j + 2, q);
+    // outside-the-wave values (edge lanes only): L0 of the outer cell on rows j-1..j+1 at plane q (E*),
+    // on row j at plane q-1 (E*m) and q+1 (E*n), its own outer x-neighbour (E*o) and its rhs (E*b)
+    double ELc[3] = { 0, 0, 0 }, ERc[3] = { 0, 0, 0 }, ELm = 0, ERm = 0, ELn = 0, ERn = 0, ELo = 0, ERo = 0, ELb = 0, ERb = 0;
+    if (edgeL) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) ELc[a] = lds(x, xl, j - 1 + a, q);
+        ELm = lds(x, xl, j, q - 1); ELn = lds(x, xl, j, q + 1); ELo = lds(x, xl - 1, j, q); ELb = lds(rhs, xl, j, q);
+    }
+    if (edgeR) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) ERc[a] = lds(x, xr, j - 1 + a, q);
+        ERm = lds(x, xr, j, q - 1); ERn = lds(x, xr, j, q + 1); ERo = lds(x, xr + 1, j, q); ERb = lds(rhs, xr, j, q);
+    }
+
+    DV<VEC> Mc[3], Mm, Dprev;                    // L1 on plane q-1 (rows j-1..j+1), L1 of row j on plane q-2, rhs of row j on q-1
+#pragma unroll
+    for (int a = 0; a < VEC; a++) { Mc[0].c[a] = Mc[1].c[a] = Mc[2].c[a] = 0.0; Mm.c[a] = 0.0; Dprev.c[a] = 0.0; }
+    double XLp = 0, XRp = 0;                     // L1 of the outside cells on row j, plane q-1
+
+    for (; q <= kend; q++) {
+        // prefetch what plane q+1 needs
+        DV<VEC> Ln2[3], Dv2[3], Hf2, Hb2;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int e = 0; e < VEC; e++) { Ln2[a].c[e] = 0.0; Dv2[a].c[e] = 0.0; }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { Hf2.c[e] = 0.0; Hb2.c[e] = 0.0; }
+        double EL2[3] = { 0, 0, 0 }, ER2[3] = { 0, 0, 0 }, ELn2 = 0, ERn2 = 0, ELo2 = 0, ERo2 = 0, ELb2 = 0, ERb2 = 0;
+        if (q < kend) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                Ln2[a] = ldv(x, j - 1 + a, q + 2);
+                Dv2[a] = ldv(rhs, j - 1 + a, q + 1);
+            }
+            Hf2 = ldv(x, j - 2, q + 1);
+            Hb2 = ldv(x, j + 2, q + 1);
+            if (edgeL) {
+                EL2[0] = lds(x, xl, j - 1, q + 1); EL2[2] = lds(x, xl, j + 1, q + 1);
+                ELn2 = lds(x, xl, j, q + 2); ELo2 = lds(x, xl - 1, j, q + 1); ELb2 = lds(rhs, xl, j, q + 1);
+            }
+            if (edgeR) {
+                ER2[0] = lds(x, xr, j - 1, q + 1); ER2[2] = lds(x, xr, j + 1, q + 1);
+                ERn2 = lds(x, xr, j, q + 2); ERo2 = lds(x, xr + 1, j, q + 1); ERb2 = lds(rhs, xr, j, q + 1);
+            }
+        }
+        EL2[1] = ELn; ER2[1] = ERn;              // row j of the outer cell at plane q+1 was fetched as "next"
+
+        // L1 on plane q for rows j-1, j, j+1
+        const bool qb = q <= 0 || q >= nz - 1;
+        DV<VEC> M[3];
+        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], ELc[0], ERc[0], qb || j - 1 <= 0 || j - 1 >= ny - 1);
+        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], ELc[1], ERc[1], qb || j <= 0 || j >= ny - 1);
+        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], ELc[2], ERc[2], qb || j + 1 <= 0 || j + 1 >= ny - 1);
+        // L1 of the two outside cells on row j, plane q (edge lanes; boundary cells keep L0)
+        const bool rowb = qb || j <= 0 || j >= ny - 1;
+        double XL = ELc[1], XR = ERc[1];
+        if (edgeL && !rowb && xl > 0)
+            XL = ((ELo + Lc[1].c[0] + ELc[0] + ELc[2] + ELm + ELn) + alpha * ELb) * beta;
+        if (edgeR && !rowb && xr < nx - 1)
+            XR = ((Lc[1].c[VEC - 1] + ERo + ERc[0] + ERc[2] + ERm + ERn) + alpha * ERb) * beta;
+
+        // L2 on plane q-1 for row j
+        const int k = q - 1;
+        const DV<VEC> o = jac(Mc[1], Mc[0], Mc[2], Mm, M[1], Dprev, XLp, XRp, false);
+        if (active && k >= kbeg && k < kend) {
+            double *dst = out + x0 + sj * j + sk * k;
+            if constexpr (VEC == 2) {
+                if (x0 >= 2 && x0 + 2 < nx) *reinterpret_cast<double2 *>(dst) = make_double2(o.c[0], o.c[1]);
+                else {                              // touches the x boundary: interior cells only
+                    if (x0 >= 1) dst[0] = o.c[0];
+                    if (x0 + 1 < nx - 1) dst[1] = o.c[1];
+                }
+            } else {
+                if (x0 >= 1 && x0 < nx - 1) dst[0] = o.c[0];
+            }
+        }
+        // rotate
+        Mm = Mc[1]; Dprev = Dv[1];
+        XLp = XL; XRp = XR;
+        ELm = ELc[1]; ERm = ERc[1]; ELn = ELn2; ERn = ERn2; ELo = ELo2; ERo = ERo2; ELb = ELb2; ERb = ERb2;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            Mc[a] = M[a]; Lm[a] = Lc[a]; Lc[a] = Ln[a]; Ln[a] = Ln2[a]; Dv[a] = Dv2[a];
+            ELc[a] = EL2[a]; ERc[a] = ER2[a];
+        }
+        Hf = Hf2; Hb = Hb2;
+    }
+}
+
 // GPU_kernel.cu:22-25 on float operands (M2)
 __device__ __forceinline__ float lerp_f(float a, float b, float c)
 {
@@ -260,7 +429,31 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
     if (iter % 2 == 1) iter += 1;
     if (ni < 3 || nj < 3 || nk < 3) return;             // no interior: every sweep is a no-op
     double *in = x, *out = temp;
-    for (int s = 0; s < iter; s++) {
+    int s = 0;
+    // two sweeps per launch where the fused kernel applies (FL_OPT_JACOBI_FUSE != 0): rows of at most 256
+    // lanes; double2 lanes when the rows are 16-byte aligned (even nx), else one cell per lane
+    if (rt().opt_jacobi_fuse && ni >= 8) {
+        const int vec = (ni % 2 == 0 && (((uintptr_t)x | (uintptr_t)temp | (uintptr_t)b) & 15u) == 0) ? 2 : 1;
+        const int lanes = (ni + vec - 1) / vec;
+        const int lpr = ((lanes + 63) / 64) * 64;
+        if (lpr <= 256) {
+            const int rows = 256 / lpr;
+            const int nby = (nj + rows - 1) / rows;
+            int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 32;
+            while (kchunk > 4 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
+            const int nbz = (nk + kchunk - 1) / kchunk;
+            // launches come in pairs (x -> temp -> x) so that the newest iterate still ends where the
+            // reference leaves it; 32 and 4 sweeps (V_Cycle) are all pairs
+            for (; s + 4 <= iter; s += 4)
+                for (int h = 0; h < 2; h++) {
+                    if (vec == 2) mg_smooth2_kernel<2><<<nby * nbz, 256, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk, lpr, nby, kchunk);
+                    else          mg_smooth2_kernel<1><<<nby * nbz, 256, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk, lpr, nby, kchunk);
+                    double *t = in; in = out; out = t;
+                }
+            BQ_LAUNCH_CHECK("mg_smooth2_kernel");
+        }
+    }
+    for (; s < iter; s++) {
         mg_smooth_kernel<<<grid_of(ni, nj, nk), kBlk, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk);
         double *t = in; in = out; out = t;
     }
@@ -333,6 +526,15 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
 using namespace bq;
 
 extern "C" {
+
+void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta,
+                          int ni, int nj, int nk, int iter)
+{
+    const char *op = "gpu_smoothing_jacobi";
+    if (!ensure_ready(op)) return;
+    BQ_REQUIRE(x && b && temp && x != temp && ni >= 1 && nj >= 1 && nk >= 1 && nk < 65535 && iter >= 0, op);
+    mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter);
+}
 
 void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div, double *p,
                                        double *dir, double *residual, double *temp0, double *temp1,

@@ -310,6 +310,11 @@ void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w
                                       float *du_init, float *dv_init, float *dw_init,
                                       float *forward_x, float *forward_y, float *forward_z,
                                       float h, int ni, int nj, int nk, bool is_point, float coeff);
+/* smoothing_jacobi<double> (GPU_kernel.cu:1464-1483) on its own: `iter` (rounded up to even) sweeps of
+ * x' = ((sum6 x) + alpha*b) * beta on interior cells, ping-ponging x <-> temp; the newest iterate ends in x.
+ * x and temp must carry the same boundary layer (V_Cycle clears both): sweeps are fused pairwise. */
+void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta,
+                          int ni, int nj, int nk, int iter);
 /* clamp_extrema_box for a staggered buffer: dz = 1 for the w component (nk+1 planes) */
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
 /* clampExtrema_kernel (GPU_kernel.cu:146-167) on its own: after = clamp(after, min/max27(before)) */

@@ -188,6 +188,8 @@ void gpu_accumulate_velocity2(float *u1, float *v1, float *w1, float k1, float *
 void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du, float *dv, float *dw,
                                       float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt, float coeff)
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
+void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
+{ orc_mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter); }
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
 { orc_clamp_extrema_box_w(before, after, ni, nj, nk); }
 void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float hr)
