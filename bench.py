@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--size", dest="n", type=int, default=256, help="grid is size^3 (per rank when --gpus > 1)")
     ap.add_argument("--jacobi-iters", type=int, default=200)
     ap.add_argument("--halfrdx", type=float, default=0.5)
+    ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi",
+                    help="jacobi: BASELINE's headline config; mgcg: the fp64 multigrid-CG projection the reference's "
+                         "shipped binary runs (SURVEY 8f N1), --mg-iters outer iterations, single GPU")
+    ap.add_argument("--mg-iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -81,7 +85,8 @@ def cpu_baseline(args):
     n = args.cpu_n
     s = oracle_lib.OracleSolver(n, n, n, 1.0, 0.0, 1.0)
     s.set_smoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
-    s.set_projection(args.jacobi_iters, args.halfrdx)
+    mg = args.projection == "mgcg"
+    s.set_projection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
     dt = 2.0 / n
     s.advance(0, dt)                                            # untimed: first-touch + emission
     t0 = time.perf_counter()
@@ -91,8 +96,9 @@ def cpu_baseline(args):
     s.close()
     return {"value": round(n ** 3 * args.cpu_steps / el / 1e6, 4), "unit": "Mvoxels/s", "cores": cores,
             "kind": "port",
-            "sample": f"{args.cpu_steps} steps of {n}^3 rising smoke ({args.jacobi_iters} Jacobi iters), "
-                      f"OpenMP C oracle (-O2 -march=native), {el:.1f} s"}
+            "sample": f"{args.cpu_steps} steps of {n}^3 rising smoke ("
+                      + (f"fp64 multigrid-CG, {args.mg_iters} outer iterations" if mg else f"{args.jacobi_iters} Jacobi iters")
+                      + f"), OpenMP C oracle (-O2 -march=native), {el:.1f} s"}
 
 
 def pmc_traffic(n, sweeps_per_launch=1.0):
@@ -152,7 +158,10 @@ def main():
     else:
         s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
     s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(world)])
-    s.setProjection(args.jacobi_iters, args.halfrdx)
+    mg = args.projection == "mgcg"
+    if mg and world > 1:
+        sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
+    s.setProjection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
     dt = 2.0 / n
 
     def barrier():
@@ -187,16 +196,31 @@ def main():
     ms_per_step = el / args.steps * 1e3
     value = voxels * args.steps / el / 1e6
     line = {
-        "metric": "Mvoxels/s per step (bimocq3D rising smoke)", "value": round(value, 2), "unit": "Mvoxels/s",
+        "metric": "Mvoxels/s per step (bimocq3D rising smoke" + (", multigrid-CG projection)" if mg else ")"),
+        "value": round(value, 2), "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"bimocq3D {n}^3 rising smoke, {args.jacobi_iters} Jacobi iters, fp32, "
-                               f"halfrdx {args.halfrdx}, reinit every step",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if mg else "f32", "data": "synthetic",
+        "config": {"workload": f"bimocq3D {n}^3 rising smoke, "
+                               + (f"fp64 multigrid-CG projection ({args.mg_iters} outer iterations, 6 levels), fp32 advection, "
+                                  if mg else f"{args.jacobi_iters} Jacobi iters, fp32, ")
+                               + f"halfrdx {args.halfrdx}, reinit every step",
                    "grid_per_gpu": [n, n, n], "global_grid": [n, n, n * world], "dt": dt,
                    "parallelism": "1 GPU" if world == 1 else
                    f"{world} z-slabs of {n} planes, {args.ghost} ghost planes, neighbour exchange over {args.transport}"},
     }
-    if launches.value > 0:
+    if launches.value > 0 and mg:
+        # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_smooth2_kernel:
+        # 24 B/cell/sweep (x, rhs in, x' out)
+        us = ms.value * 1e3 / launches.value
+        spl = sweeps.value / launches.value
+        alg = 24 * n ** 3 * spl
+        achieved = alg / (us * 1e-6) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": "mg_smooth2_kernel (level 0)", "achieved": round(achieved, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
+                            "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3),
+                            "algorithmic_bytes_per_launch": int(alg)}
+    elif launches.value > 0:
         # dominant kernel: the Jacobi sweep.  A launch of jacobi_march2_kernel performs two sweeps, so the
         # algorithmic bytes of a launch are 12 B/voxel x voxels x sweeps-per-launch.
         us = ms.value * 1e3 / launches.value

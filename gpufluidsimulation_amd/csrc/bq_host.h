@@ -43,6 +43,11 @@ void *pinned(size_t bytes);
 // bq_halo.hip: in-stream all-reduce of device values across slab ranks (no-op on one rank)
 bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStream_t st);
 int  comm_ranks();
+// bq_project.hip: FL_OPT_PROFILE_JACOBI spans -- an event pair around a loop of sweep launches on the compute
+// stream, summed by fl_jacobi_profile().  profile_begin returns false when profiling is off.
+struct ProfileSpan { hipEvent_t a = nullptr, b = nullptr; };
+bool profile_begin(ProfileSpan &sp);
+void profile_end(ProfileSpan &sp, long long launches, long long sweeps);
 
 inline bool hip_ok(hipError_t e, const char *what)
 {

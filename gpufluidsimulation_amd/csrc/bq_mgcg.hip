@@ -190,48 +190,53 @@ __global__ __launch_bounds__(256) void mg_smooth_kernel(const double *__restrict
 // clears x and temp0 before every smoothing call); VEC == 2 needs an even nx.
 template <int VEC> struct DV { double c[VEC]; };
 
-template <int VEC>
-__global__ __launch_bounds__(256) void mg_smooth2_kernel(const double *__restrict__ x, const double *__restrict__ rhs,
-                                                         double *__restrict__ out, double alpha, double beta,
-                                                         int nx, int ny, int nz, int lpr, int nby, int kchunk)
+template <int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void mg_smooth2_kernel(const double *__restrict__ x, const double *__restrict__ rhs,
+                                                             double *__restrict__ out, double alpha, double beta,
+                                                             int nx, int ny, int nz, int lpr, int nby, int kchunk)
 {
     const int nblk = gridDim.x;
     int blk = blockIdx.x;
     if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);          // XCD-contiguous block order
     const int by = blk % nby, bz = blk / nby;
-    const int rows = 256 / lpr;
+    const int rows = THREADS / lpr;
     const int c = threadIdx.x % lpr, r = threadIdx.x / lpr;
-    const int x0 = VEC * c, j = by * rows + r;
+    const int xraw = VEC * c, j = by * rows + r;
     const int lane = threadIdx.x & 63;
     const int kbeg = max(1, bz * kchunk), kend = min(nz - 1, bz * kchunk + kchunk);
     if (kbeg >= kend) return;
-    const bool xok = x0 < nx;
+    const bool xok = xraw < nx;
     const bool active = xok && j >= 1 && j <= ny - 2;
+    // Out-of-range rows, planes and lanes are CLAMPED into the array instead of being zero-filled: whatever
+    // they load only ever feeds cells that are boundary (kept from L0) or not stored at all.
+    const int x0 = xok ? xraw : nx - VEC;
     const long long sj = nx, sk = (long long)nx * ny;
-    const bool edgeL = lane == 0 && xok && x0 > 0;                 // a cell x0-1 exists outside this wave
-    const bool edgeR = lane == 63 && x0 + VEC < nx;                // a cell x0+VEC exists outside this wave
-    const int xl = x0 - 1, xr = x0 + VEC;
+    auto rowoff = [&](int row) -> long long { return (long long)x0 + sj * min(max(row, 0), ny - 1); };
+    const long long o_m2 = rowoff(j - 2), o_m1 = rowoff(j - 1), o_0 = rowoff(j), o_p1 = rowoff(j + 1), o_p2 = rowoff(j + 2);
+    auto plane = [&](int pl) -> long long { return sk * min(max(pl, 0), nz - 1); };
+    // edge lanes: lane 0 looks after the cell just left of the wave, lane 63 after the cell just right of it
+    const bool edgeL = lane == 0 && xok && xraw > 0, edgeR = lane == 63 && xraw + VEC < nx;
+    const bool edge = edgeL || edgeR;
+    const int xe = edgeL ? xraw - 1 : xraw + VEC;                      // the outside cell
+    const int xo = edgeL ? xe - 1 : xe + 1;                            // its own outer x-neighbour
+    const long long e_m1 = (long long)xe + sj * min(max(j - 1, 0), ny - 1), e_0 = (long long)xe + sj * min(max(j, 0), ny - 1),
+                    e_p1 = (long long)xe + sj * min(max(j + 1, 0), ny - 1),
+                    e_o = (long long)min(max(xo, 0), nx - 1) + sj * min(max(j, 0), ny - 1);
+    const bool rowb_m1 = j - 1 <= 0 || j - 1 >= ny - 1, rowb_0 = j <= 0 || j >= ny - 1, rowb_p1 = j + 1 <= 0 || j + 1 >= ny - 1;
+    const bool xe_boundary = xe <= 0 || xe >= nx - 1;
 
-    auto ldv = [&](const double *ptr, int row, int pl) -> DV<VEC> {
+    auto ldv = [&](const double *ptr, long long off) -> DV<VEC> {
         DV<VEC> v;
-#pragma unroll
-        for (int a = 0; a < VEC; a++) v.c[a] = 0.0;
-        if (!xok || row < 0 || row >= ny || pl < 0 || pl >= nz) return v;
-        const double *q = ptr + x0 + sj * row + sk * pl;
-        if constexpr (VEC == 2) { const double2 t = *reinterpret_cast<const double2 *>(q); v.c[0] = t.x; v.c[1] = t.y; }
-        else v.c[0] = q[0];
+        if constexpr (VEC == 2) { const double2 t = *reinterpret_cast<const double2 *>(ptr + off); v.c[0] = t.x; v.c[1] = t.y; }
+        else v.c[0] = ptr[off];
         return v;
-    };
-    auto lds = [&](const double *ptr, int xx, int row, int pl) -> double {
-        if (xx < 0 || xx >= nx || row < 0 || row >= ny || pl < 0 || pl >= nz) return 0.0;
-        return ptr[xx + sj * row + sk * pl];
     };
     // one smoothing evaluation on the thread's cells; lo/ro: the values just outside the wave (edge lanes)
     auto jac = [&](const DV<VEC> &ce, const DV<VEC> &fr, const DV<VEC> &bk, const DV<VEC> &dn, const DV<VEC> &up,
-                   const DV<VEC> &dv, double lo, double ro, bool boundary) -> DV<VEC> {
+                   const DV<VEC> &dv, double outside, bool boundary) -> DV<VEC> {
         double left = __shfl_up(ce.c[VEC - 1], 1, 64), right = __shfl_down(ce.c[0], 1, 64);
-        if (lane == 0) left = lo;
-        if (lane == 63) right = ro;
+        if (lane == 0) left = outside;
+        if (lane == 63) right = outside;
         DV<VEC> o;
         if constexpr (VEC == 2) {
             o.c[0] = ((left + ce.c[1] + fr.c[0] + bk.c[0] + dn.c[0] + up.c[0]) + alpha * dv.c[0]) * beta;
@@ -248,79 +253,57 @@ __global__ __launch_bounds__(256) void mg_smooth2_kernel(const double *__restric
     // L0 of rows j-1, j, j+1 on planes q-1 (Lm), q (Lc), q+1 (Ln); q = plane whose L1 is being built
     DV<VEC> Lm[3], Lc[3], Ln[3], Dv[3];
     int q = kbeg - 1;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        Lm[a] = ldv(x, j - 1 + a, q - 1);
-        Lc[a] = ldv(x, j - 1 + a, q);
-        Ln[a] = ldv(x, j - 1 + a, q + 1);
-        Dv[a] = ldv(rhs, j - 1 + a, q);
+    {
+        const long long pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
+        Lm[0] = ldv(x, pm + o_m1); Lm[1] = ldv(x, pm + o_0); Lm[2] = ldv(x, pm + o_p1);
+        Lc[0] = ldv(x, pc + o_m1); Lc[1] = ldv(x, pc + o_0); Lc[2] = ldv(x, pc + o_p1);
+        Ln[0] = ldv(x, pn + o_m1); Ln[1] = ldv(x, pn + o_0); Ln[2] = ldv(x, pn + o_p1);
+        Dv[0] = ldv(rhs, pc + o_m1); Dv[1] = ldv(rhs, pc + o_0); Dv[2] = ldv(rhs, pc + o_p1);
     }
-    DV<VEC> Hf = ldv(x, j - 2, q), Hb = ldv(x, j + 2, q);
-    // outside-the-wave values (edge lanes only): L0 of the outer cell on rows j-1..j+1 at plane q (E*),
-    // on row j at plane q-1 (E*m) and q+1 (E*n), its own outer x-neighbour (E*o) and its rhs (E*b)
-    double ELc[3] = { 0, 0, 0 }, ERc[3] = { 0, 0, 0 }, ELm = 0, ERm = 0, ELn = 0, ERn = 0, ELo = 0, ERo = 0, ELb = 0, ERb = 0;
-    if (edgeL) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) ELc[a] = lds(x, xl, j - 1 + a, q);
-        ELm = lds(x, xl, j, q - 1); ELn = lds(x, xl, j, q + 1); ELo = lds(x, xl - 1, j, q); ELb = lds(rhs, xl, j, q);
-    }
-    if (edgeR) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) ERc[a] = lds(x, xr, j - 1 + a, q);
-        ERm = lds(x, xr, j, q - 1); ERn = lds(x, xr, j, q + 1); ERo = lds(x, xr + 1, j, q); ERb = lds(rhs, xr, j, q);
+    DV<VEC> Hf = ldv(x, plane(q) + o_m2), Hb = ldv(x, plane(q) + o_p2);
+    // the outside cell (edge lanes only): L0 on rows j-1..j+1 at plane q (Ec), on row j at planes q-1 (Em)
+    // and q+1 (En), its outer x-neighbour at plane q (Eo), its rhs (Eb)
+    double Ec[3] = { 0, 0, 0 }, Em = 0, En = 0, Eo = 0, Eb = 0;
+    if (edge) {
+        const long long pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
+        Ec[0] = x[pc + e_m1]; Ec[1] = x[pc + e_0]; Ec[2] = x[pc + e_p1];
+        Em = x[pm + e_0]; En = x[pn + e_0]; Eo = x[pc + e_o]; Eb = rhs[pc + e_0];
     }
 
     DV<VEC> Mc[3], Mm, Dprev;                    // L1 on plane q-1 (rows j-1..j+1), L1 of row j on plane q-2, rhs of row j on q-1
 #pragma unroll
     for (int a = 0; a < VEC; a++) { Mc[0].c[a] = Mc[1].c[a] = Mc[2].c[a] = 0.0; Mm.c[a] = 0.0; Dprev.c[a] = 0.0; }
-    double XLp = 0, XRp = 0;                     // L1 of the outside cells on row j, plane q-1
+    double Xp = 0;                               // L1 of the outside cell on row j, plane q-1
 
     for (; q <= kend; q++) {
-        // prefetch what plane q+1 needs
-        DV<VEC> Ln2[3], Dv2[3], Hf2, Hb2;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int e = 0; e < VEC; e++) { Ln2[a].c[e] = 0.0; Dv2[a].c[e] = 0.0; }
-#pragma unroll
-        for (int e = 0; e < VEC; e++) { Hf2.c[e] = 0.0; Hb2.c[e] = 0.0; }
-        double EL2[3] = { 0, 0, 0 }, ER2[3] = { 0, 0, 0 }, ELn2 = 0, ERn2 = 0, ELo2 = 0, ERo2 = 0, ELb2 = 0, ERb2 = 0;
-        if (q < kend) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                Ln2[a] = ldv(x, j - 1 + a, q + 2);
-                Dv2[a] = ldv(rhs, j - 1 + a, q + 1);
-            }
-            Hf2 = ldv(x, j - 2, q + 1);
-            Hb2 = ldv(x, j + 2, q + 1);
-            if (edgeL) {
-                EL2[0] = lds(x, xl, j - 1, q + 1); EL2[2] = lds(x, xl, j + 1, q + 1);
-                ELn2 = lds(x, xl, j, q + 2); ELo2 = lds(x, xl - 1, j, q + 1); ELb2 = lds(rhs, xl, j, q + 1);
-            }
-            if (edgeR) {
-                ER2[0] = lds(x, xr, j - 1, q + 1); ER2[2] = lds(x, xr, j + 1, q + 1);
-                ERn2 = lds(x, xr, j, q + 2); ERo2 = lds(x, xr + 1, j, q + 1); ERb2 = lds(rhs, xr, j, q + 1);
-            }
+        // prefetch what plane q+1 needs (clamped: past the chunk's last plane the values are not used)
+        const long long p1 = plane(q + 1), p2 = plane(q + 2);
+        DV<VEC> Ln2[3], Dv2[3];
+        Ln2[0] = ldv(x, p2 + o_m1); Ln2[1] = ldv(x, p2 + o_0); Ln2[2] = ldv(x, p2 + o_p1);
+        Dv2[0] = ldv(rhs, p1 + o_m1); Dv2[1] = ldv(rhs, p1 + o_0); Dv2[2] = ldv(rhs, p1 + o_p1);
+        const DV<VEC> Hf2 = ldv(x, p1 + o_m2), Hb2 = ldv(x, p1 + o_p2);
+        double E2[3] = { 0, En, 0 }, En2 = 0, Eo2 = 0, Eb2 = 0;
+        if (edge) {
+            E2[0] = x[p1 + e_m1]; E2[2] = x[p1 + e_p1];
+            En2 = x[p2 + e_0]; Eo2 = x[p1 + e_o]; Eb2 = rhs[p1 + e_0];
         }
-        EL2[1] = ELn; ER2[1] = ERn;              // row j of the outer cell at plane q+1 was fetched as "next"
 
         // L1 on plane q for rows j-1, j, j+1
         const bool qb = q <= 0 || q >= nz - 1;
         DV<VEC> M[3];
-        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], ELc[0], ERc[0], qb || j - 1 <= 0 || j - 1 >= ny - 1);
-        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], ELc[1], ERc[1], qb || j <= 0 || j >= ny - 1);
-        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], ELc[2], ERc[2], qb || j + 1 <= 0 || j + 1 >= ny - 1);
-        // L1 of the two outside cells on row j, plane q (edge lanes; boundary cells keep L0)
-        const bool rowb = qb || j <= 0 || j >= ny - 1;
-        double XL = ELc[1], XR = ERc[1];
-        if (edgeL && !rowb && xl > 0)
-            XL = ((ELo + Lc[1].c[0] + ELc[0] + ELc[2] + ELm + ELn) + alpha * ELb) * beta;
-        if (edgeR && !rowb && xr < nx - 1)
-            XR = ((Lc[1].c[VEC - 1] + ERo + ERc[0] + ERc[2] + ERm + ERn) + alpha * ERb) * beta;
+        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], Ec[0], qb || rowb_m1);
+        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], Ec[1], qb || rowb_0);
+        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], Ec[2], qb || rowb_p1);
+        // L1 of the outside cell on row j, plane q (edge lanes; a boundary cell keeps L0)
+        double X = Ec[1];
+        if (edge && !(qb || rowb_0 || xe_boundary)) {
+            const double l = edgeL ? Eo : Lc[1].c[VEC - 1], rr = edgeL ? Lc[1].c[0] : Eo;
+            X = ((l + rr + Ec[0] + Ec[2] + Em + En) + alpha * Eb) * beta;
+        }
 
         // L2 on plane q-1 for row j
         const int k = q - 1;
-        const DV<VEC> o = jac(Mc[1], Mc[0], Mc[2], Mm, M[1], Dprev, XLp, XRp, false);
+        const DV<VEC> o = jac(Mc[1], Mc[0], Mc[2], Mm, M[1], Dprev, Xp, false);
         if (active && k >= kbeg && k < kend) {
             double *dst = out + x0 + sj * j + sk * k;
             if constexpr (VEC == 2) {
@@ -335,12 +318,12 @@ __global__ __launch_bounds__(256) void mg_smooth2_kernel(const double *__restric
         }
         // rotate
         Mm = Mc[1]; Dprev = Dv[1];
-        XLp = XL; XRp = XR;
-        ELm = ELc[1]; ERm = ERc[1]; ELn = ELn2; ERn = ERn2; ELo = ELo2; ERo = ERo2; ELb = ELb2; ERb = ERb2;
+        Xp = X;
+        Em = Ec[1]; En = En2; Eo = Eo2; Eb = Eb2;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             Mc[a] = M[a]; Lm[a] = Lc[a]; Lc[a] = Ln[a]; Ln[a] = Ln2[a]; Dv[a] = Dv2[a];
-            ELc[a] = EL2[a]; ERc[a] = ER2[a];
+            Ec[a] = E2[a];
         }
         Hf = Hf2; Hb = Hb2;
     }
@@ -432,24 +415,35 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
     int s = 0;
     // two sweeps per launch where the fused kernel applies (FL_OPT_JACOBI_FUSE != 0): rows of at most 256
     // lanes; double2 lanes when the rows are 16-byte aligned (even nx), else one cell per lane
-    if (rt().opt_jacobi_fuse && ni >= 8) {
+    // Worth it on large levels only (measured at 256^3: 60 vs 92 us per sweep; at 127^3 and below the
+    // k-marching pipeline is too short per block and the plain kernel wins: 11.5 vs 13.5 us, 2.5 vs 3.8 us).
+    // FL_OPT_JACOBI_FUSE = 2 forces the fused kernel wherever it applies (tests).
+    const bool big = (long long)ni * nj * nk >= (1ll << 21);
+    if (((rt().opt_jacobi_fuse == 1 && big) || rt().opt_jacobi_fuse >= 2) && ni >= 8) {
         const int vec = (ni % 2 == 0 && (((uintptr_t)x | (uintptr_t)temp | (uintptr_t)b) & 15u) == 0) ? 2 : 1;
         const int lanes = (ni + vec - 1) / vec;
         const int lpr = ((lanes + 63) / 64) * 64;
-        if (lpr <= 256) {
-            const int rows = 256 / lpr;
+        const int threads = rt().opt_jacobi_rows == 8 ? 512 : 256;      // FL_OPT_JACOBI_ROWS: waves per block (4 or 8)
+        if (lpr <= threads) {
+            const int rows = threads / lpr;
             const int nby = (nj + rows - 1) / rows;
-            int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 32;
+            int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 64;
             while (kchunk > 4 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
             const int nbz = (nk + kchunk - 1) / kchunk;
             // launches come in pairs (x -> temp -> x) so that the newest iterate still ends where the
             // reference leaves it; 32 and 4 sweeps (V_Cycle) are all pairs
+            ProfileSpan span;
+            const bool prof = big && iter >= 4 && profile_begin(span);
+            const int s_begin = s;
             for (; s + 4 <= iter; s += 4)
                 for (int h = 0; h < 2; h++) {
-                    if (vec == 2) mg_smooth2_kernel<2><<<nby * nbz, 256, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk, lpr, nby, kchunk);
-                    else          mg_smooth2_kernel<1><<<nby * nbz, 256, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk, lpr, nby, kchunk);
+#define MG_S2(V, T) mg_smooth2_kernel<V, T><<<nby * nbz, T, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk, lpr, nby, kchunk)
+                    if (vec == 2) { if (threads == 512) MG_S2(2, 512); else MG_S2(2, 256); }
+                    else          { if (threads == 512) MG_S2(1, 512); else MG_S2(1, 256); }
+#undef MG_S2
                     double *t = in; in = out; out = t;
                 }
+            if (prof) profile_end(span, (s - s_begin) / 2, s - s_begin);
             BQ_LAUNCH_CHECK("mg_smooth2_kernel");
         }
     }

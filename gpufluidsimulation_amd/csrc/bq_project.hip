@@ -596,6 +596,19 @@ static void residual_norms_async(const float *div, const float *p, int ni, int n
 struct SweepSpan { hipEvent_t a, b; long long launches, sweeps; };
 static std::vector<SweepSpan> g_spans;
 
+bool profile_begin(ProfileSpan &sp)
+{
+    if (!rt().opt_profile_jacobi) return false;
+    if (!BQ_HIP(hipEventCreate(&sp.a)) || !BQ_HIP(hipEventCreate(&sp.b))) return false;
+    return BQ_HIP(hipEventRecord(sp.a, rt().compute));
+}
+void profile_end(ProfileSpan &sp, long long launches, long long sweeps)
+{
+    if (!sp.a || !sp.b) return;
+    BQ_HIP(hipEventRecord(sp.b, rt().compute));
+    g_spans.push_back(SweepSpan{sp.a, sp.b, launches, sweeps});
+}
+
 } // namespace bq
 
 using namespace bq;

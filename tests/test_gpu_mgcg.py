@@ -91,6 +91,18 @@ def test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, hr):
         assert c.result[2000 + iters] < c.result[2000]      # the positive residual peak went down
 
 
+def test_mgcg_with_fused_smoothing_on_every_level(hip):
+    """the fused two-sweep smoother is chosen by size (level 0 of big grids only); forced on here so that the
+    whole operator runs through it on 64^3, 31^3, 15^3 (one cell per lane, odd rows) and stays bit-identical"""
+    import gpufluidsimulation_amd as bq
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    try:
+        test_mgcg_matches_oracle(hip, 64, 64, 64, 4, 2, 0.5)
+        test_mgcg_matches_oracle(hip, 40, 36, 32, 3, 2, 1.0)
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+
+
 def test_mgcg_rejects_bad_arguments(hip):
     import gpufluidsimulation_amd as bq
     c = HostCase(8, 8, 8, 1)
@@ -127,7 +139,7 @@ def test_smoothing_fused_pairs(hip, ni, nj, nk, iters):
     for arr in (t0,):
         arr[0], arr[-1], arr[:, 0], arr[:, -1], arr[:, :, 0], arr[:, :, -1] = x0[0], x0[-1], x0[:, 0], x0[:, -1], x0[:, :, 0], x0[:, :, -1]
     x0, t0 = x0.ravel().copy(), t0.ravel().copy()
-    for fuse in (1, 0):
+    for fuse in (2, 0):                                  # 2: fused wherever it applies, whatever the size
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, fuse)
         xr, tr = x0.copy(), t0.copy()
         oracle().orc_mg_smooth(dp(xr), dp(b), dp(tr), -8.0, 1.0 / 6.0, ni, nj, nk, iters)
