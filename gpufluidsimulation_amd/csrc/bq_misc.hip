@@ -238,4 +238,24 @@ float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int n
     return host[0];
 }
 
+// max(0, max f) of one field: the host scan of MapperBaseGPU::estimateDistortion (Mapping.cpp:500-516,
+// starts from 0 and keeps values that compare greater: NaNs are skipped) as a device reduction; blocking.
+float gpu_max_field(const float *field, size_t count)
+{
+    if (!ensure_ready("gpu_max_field")) return 0.f;
+    if (!field) { latch(FL_ERR_BAD_ARGUMENT, "gpu_max_field", "null pointer"); return 0.f; }
+    if (rt().slab_on) { latch(FL_ERR_UNSUPPORTED, "gpu_max_field", "not slab-aware (owned planes / all-reduce) yet"); return 0.f; }
+    const int blocks = 1024;
+    float *part = (float *)scratch((blocks + 16) * sizeof(float));
+    float *host = (float *)pinned(64);
+    if (!part || !host) return 0.f;
+    hipStream_t st = rt().compute;
+    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(field, count, field, 0, field, 0, part);    // values are >= 0 or skipped
+    max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 0.f, part + blocks);
+    BQ_LAUNCH_CHECK("max_field");
+    BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipStreamSynchronize(st));
+    return host[0];
+}
+
 } // extern "C"

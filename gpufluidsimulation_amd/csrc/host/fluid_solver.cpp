@@ -151,6 +151,30 @@ void BimocqGPUSolver::diffuseField(float *field, float *t0, float *t1, int ni, i
 }
 
 // :406-467, the Jacobi branch (:409-410): alpha = -1, beta = 1/6
+// Distortion-driven re-initialisation (BQ_OPT_REINIT_POLICY = 1): the two map sets follow different
+// schedules, so the scalar advector needs its own; the scalar snapshot/delta buffers the every-frame
+// policy never needs are allocated here.
+bool BimocqGPUSolver::setReinitPolicy(int policy)
+{
+    if (policy == reinit_policy) return true;
+    if (steps_taken != 0) { fl_report_error(FL_ERR_BAD_ARGUMENT, "BQ_OPT_REINIT_POLICY must be set before the first advance()"); return false; }
+    if (policy != 0 && policy != 1) { fl_report_error(FL_ERR_BAD_ARGUMENT, "BQ_OPT_REINIT_POLICY: 0 or 1"); return false; }
+    if (policy == 1) {
+        if (GpuSolver->slab.on && GpuSolver->slab.nranks > 1) {
+            fl_report_error(FL_ERR_UNSUPPORTED, "distortion-driven re-initialisation is single-GPU (maps that live for many steps outgrow the ghost zone)");
+            return false;
+        }
+        if (!ScalarAdvector.unshareMaps()) return false;
+        DeviceField *sb[] = { &DensityTemp, &TemperatureTemp, &DensityExtern, &TemperatureExtern };
+        for (DeviceField *f : sb)
+            if (!f->get() && !GpuSolver->allocField(*f, FIELD_S)) return false;
+    } else {
+        ScalarAdvector.shareMapsOf(VelocityAdvector);
+    }
+    reinit_policy = policy;
+    return true;
+}
+
 // BimocqGPUSolver.cpp:60-90: p, dir, residual, div, temp0, temp1 (N doubles each), tempResult (4096), and
 // LEVEL_COUNT levels of b/x/r with dims n -> (n - 1) / 2.  Levels without a single cell are left out (the
 // reference launches empty grids for them).
@@ -295,10 +319,13 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
                                     VelocityUPrev, VelocityVPrev, VelocityWPrev);
     // density and temperature live on the same nodes and use the same maps: batched (one map look-up)
     ScalarAdvector.advectFields2(Density, DensityInit, DensityPrev, Temperature, TemperatureInit, TemperaturePrev);
+    const bool policy1 = reinit_policy == 1;
     trace_stage(*this, "advect", framenum);
 
     // :157-159
     VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
+    // policy 1 follows the CPU solver (BimocqSolver.cpp:129-133): scalar snapshots BEFORE the sources act
+    if (policy1) { DensityTemp.copy_from(Density); TemperatureTemp.copy_from(Temperature); }
 
     emitSmoke(framenum, dt);                             // :164
     addBuoyancy(dt);                                     // :165
@@ -338,28 +365,51 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     // :185-186,195-198: DensityExtern = Density - DensityTemp right after DensityTemp <- Density is
     // identically zero, and accumulating a zero field (:215-216) adds 0: not executed.
 
-    if (framenum - vel_lastReinit > 10) {                // :200-205
-        vel_lastReinit = framenum;
-        proj_coeff = 1.f;
-    }
-    if (framenum - scalar_lastReinit > 30) {             // :207-211
-        scalar_lastReinit = framenum;
+    bool velReinit = true, scalarReinit = true;
+    if (policy1) {
+        // BimocqSolver.cpp:160-185: what the sources added to the scalars, the distortion of each map set in
+        // units of the step's travel, and the CPU solver's thresholds
+        gs.addFields(DensityExtern, Density, DensityTemp, -1.f, g.n());
+        gs.addFields(TemperatureExtern, Temperature, TemperatureTemp, -1.f, g.n());
+        last_vel_distortion = VelocityAdvector.estimateDistortion() / (MaxVelocity * dt);
+        last_scalar_distortion = ScalarAdvector.estimateDistortion() / (MaxVelocity * dt);
+        velReinit = scalarReinit = false;
+        if (last_vel_distortion > 1.f || framenum - vel_lastReinit > 10) { velReinit = true; vel_lastReinit = framenum; proj_coeff = 1.f; }
+        if (last_scalar_distortion > 5.f || framenum - scalar_lastReinit > 30) { scalarReinit = true; scalar_lastReinit = framenum; }
+    } else {
+        if (framenum - vel_lastReinit > 10) {                // :200-205
+            vel_lastReinit = framenum;
+            proj_coeff = 1.f;
+        }
+        if (framenum - scalar_lastReinit > 30) {             // :207-211
+            scalar_lastReinit = framenum;
+        }
     }
 
     // :213-214
     VelocityAdvector.accumulateVelocity2(VelocityUInit, VelocityVInit, VelocityWInit,
                                          duExtern, dvExtern, dwExtern, 1.f, duProj, dvProj, dwProj, proj_coeff);
+    if (policy1) {                                       // BimocqSolver.cpp:191-192 (:215-216 here adds zeros)
+        ScalarAdvector.accumulateField(DensityInit, DensityExtern);
+        ScalarAdvector.accumulateField(TemperatureInit, TemperatureExtern);
+    }
     trace_stage(*this, "accumulate", framenum);
 
-    // :218-223 `if (1)`: re-initialise every frame
-    VelocityAdvector.reinitializeMapping();
-    velocityReinitialize();
-    VelocityAdvector.accumulateVelocity(VelocityUInit, VelocityVInit, VelocityWInit, duProj, dvProj, dwProj, 1.f);
-
+    // :218-223 `if (1)`: re-initialise every frame; policy 1: when the rules above say so
+    if (velReinit) {
+        vel_reinits++;
+        VelocityAdvector.reinitializeMapping();
+        velocityReinitialize();
+        VelocityAdvector.accumulateVelocity(VelocityUInit, VelocityVInit, VelocityWInit, duProj, dvProj, dwProj, 1.f);
+    }
     // :225-229
-    if (ScalarAdvector.sharesMaps()) ScalarAdvector.noteSharedReinit();
-    else ScalarAdvector.reinitializeMapping();
-    scalarReinitialize();
+    if (scalarReinit) {
+        scalar_reinits++;
+        if (ScalarAdvector.sharesMaps()) ScalarAdvector.noteSharedReinit();
+        else ScalarAdvector.reinitializeMapping();
+        scalarReinitialize();
+    }
+    steps_taken++;
     trace_stage(*this, "reinit", framenum);
 }
 

@@ -48,6 +48,12 @@ public:
     long dump(unsigned frame, const std::string &filepath) { return outputResult(frame, filepath); }
 
     // projection variant (compile-time `#if` in the reference, BimocqGPUSolver.cpp:408-466)
+    int   reinit_policy = 0;            // BQ_OPT_REINIT_POLICY
+    bool  setReinitPolicy(int policy);
+    int   vel_reinits = 0, scalar_reinits = 0;
+    float last_vel_distortion = 0.f, last_scalar_distortion = 0.f;
+    int   steps_taken = 0;
+    DeviceField DensityTemp, TemperatureTemp, DensityExtern, TemperatureExtern;   // policy 1 only (:53-58)
     int   projection_kind = 0;          // BQ_PROJECTION_JACOBI / BQ_PROJECTION_MGCG
     int   mg_iters = 50;                // :444
     int   jacobi_iters = 100;           // :409

@@ -2,6 +2,7 @@
 #include "mapping.hpp"
 
 #include <algorithm>
+#include <cmath>
 
 namespace bqhost {
 
@@ -321,6 +322,26 @@ void MapperBaseGPU::reinitializeMapping()
     m.Dback = 0;
     m.Dfwd = 0;
     m.fwdIdentity = true;
+}
+
+// The reference scans gpuSolver->du on the host (Mapping.cpp:497-516); that scratch still holds older data
+// outside the window estimate_kernel writes, so it is cleared here: the distortion is the maximum over the
+// cells the kernel evaluates.
+float MapperBaseGPU::estimateDistortion()
+{
+    MapSet &m = *maps;
+    gpuMapper &gs = *gpuSolver;
+    fl_memset(gs.u_src, 0, g.n() * sizeof(float));
+    gpu_estimate_distortion(gs.u_src, m.BackwardX, m.BackwardY, m.BackwardZ, m.ForwardX, m.ForwardY, m.ForwardZ,
+                            g.h, g.ni, g.nj, g.nk);
+    return std::sqrt(gpu_max_field(gs.u_src, g.n()));
+}
+
+bool MapperBaseGPU::unshareMaps()
+{
+    if (!shared_) return true;
+    shared_ = false;
+    return init(g.ni, g.nj, g.nk, g.h, BlendCoeff, gpuSolver);
 }
 
 } // namespace bqhost

@@ -58,6 +58,10 @@ public:
                              DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2);
     void accumulateField(DeviceField &dfInit, DeviceField &fChange);
     void reinitializeMapping();
+    // Mapping.cpp:495-519: sqrt of the largest round-trip error |x - fwd(back(x))|, |x - back(fwd(x))|
+    float estimateDistortion();
+    // stop sharing the owner's maps: this mapper gets its own identity set (only before the first update)
+    bool unshareMaps();
 
     GridDims g;
     float BlendCoeff = 1.f;

@@ -88,7 +88,22 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
     if (option == BQ_OPT_KEEP_DMC_BORDER) {
         s->solver->VelocityAdvector.keepDmcBorder = value != 0;
         s->solver->ScalarAdvector.keepDmcBorder = value != 0;
+    } else if (option == BQ_OPT_REINIT_POLICY) {
+        s->solver->setReinitPolicy(value);
+        s->solver->ScalarAdvector.keepDmcBorder = s->solver->VelocityAdvector.keepDmcBorder;
     }
+}
+
+int bq_solver_reinit_counts(const bq_solver *s, int which)
+{
+    if (!s) return 0;
+    return which ? s->solver->scalar_reinits : s->solver->vel_reinits;
+}
+
+float bq_solver_last_distortion(const bq_solver *s, int which)
+{
+    if (!s) return 0.f;
+    return which ? s->solver->last_scalar_distortion : s->solver->last_vel_distortion;
 }
 
 void bq_solver_advance(bq_solver *s, int framenum, float dt)

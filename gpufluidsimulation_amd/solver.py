@@ -32,6 +32,8 @@ HOST_SIGS = {
     "bq_solver_advance": (None, [C.c_void_p, C.c_int, C.c_float]),
     "bq_solver_output_result": (C.c_long, [C.c_void_p, C.c_uint, C.c_char_p]),
     "bq_solver_download": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
+    "bq_solver_reinit_counts": (C.c_int, [C.c_void_p, C.c_int]),
+    "bq_solver_last_distortion": (C.c_float, [C.c_void_p, C.c_int]),
     "bq_solver_mg_history": (C.c_long, [C.c_void_p, C.POINTER(C.c_double), C.c_long]),
     "bq_solver_last_cfldt": (C.c_float, [C.c_void_p]),
     "bq_solver_last_ms": (C.c_float, [C.c_void_p]),
@@ -110,8 +112,16 @@ class BimocqGPUSolver:
         return out
 
     def setOption(self, option, value):
-        """option 1 = BQ_OPT_KEEP_DMC_BORDER"""
+        """option 1 = BQ_OPT_KEEP_DMC_BORDER, 2 = BQ_OPT_REINIT_POLICY (0 every frame, 1 distortion-driven)"""
         self.lib.bq_solver_set_option(self.s, option, value)
+        self._check()
+
+    def reinitCounts(self):
+        """(velocity map re-initialisations, scalar map re-initialisations) so far"""
+        return self.lib.bq_solver_reinit_counts(self.s, 0), self.lib.bq_solver_reinit_counts(self.s, 1)
+
+    def lastDistortion(self):
+        return self.lib.bq_solver_last_distortion(self.s, 0), self.lib.bq_solver_last_distortion(self.s, 1)
 
     def advance(self, framenum, dt):
         self.lib.bq_solver_advance(self.s, framenum, dt)

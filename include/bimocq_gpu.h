@@ -315,6 +315,10 @@ void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w
  * x and temp must carry the same boundary layer (V_Cycle clears both): sweeps are fused pairwise. */
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta,
                           int ni, int nj, int nk, int iter);
+/* max(0, max of field[0..count)) with NaNs skipped -- the host scan of MapperBaseGPU::estimateDistortion
+ * (Mapping.cpp:500-516) over the buffer gpu_estimate_distortion filled, as a device reduction; blocking.
+ * Intended for non-negative data (it reduces |x|).  Not slab-aware. */
+float gpu_max_field(const float *field, size_t count);
 /* clamp_extrema_box for a staggered buffer: dz = 1 for the w component (nk+1 planes) */
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
 /* clampExtrema_kernel (GPU_kernel.cu:146-167) on its own: after = clamp(after, min/max27(before)) */

@@ -53,7 +53,20 @@ void  bq_solver_set_smoke(bq_solver *s, float drop, float rise, const bq_emitter
 void  bq_solver_set_projection(bq_solver *s, int kind, int iters, float halfrdx);
 /* solver options: BQ_OPT_KEEP_DMC_BORDER (default 0 = reference behaviour: the backward map's border
  * nodes are zeroed by the DMC update; 1 = they keep their values, see csrc/host/mapping.hpp) */
-enum { BQ_OPT_KEEP_DMC_BORDER = 1 };
+enum {
+    BQ_OPT_KEEP_DMC_BORDER = 1,
+    /* 0 (default): both map sets are re-initialised every frame, as the reference's GPU solver does (`if (1)`,
+     * BimocqGPUSolver.cpp:218-229).  1: distortion-driven re-initialisation with the CPU solver's rules
+     * (BimocqSolver.cpp:165-229): velocity maps when their round-trip error exceeds 1 step-travel or after 10
+     * frames, scalar maps above 5 or after 30 frames; the scalar snapshots are taken before the sources act
+     * so that emission reaches DensityInit through the accumulation.  Set before the first advance().
+     * Single GPU only. */
+    BQ_OPT_REINIT_POLICY = 2
+};
+/* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
+ * last step measured (policy 1; 0 otherwise) */
+int   bq_solver_reinit_counts(const bq_solver *s, int which);
+float bq_solver_last_distortion(const bq_solver *s, int which);
 void  bq_solver_set_option(bq_solver *s, int option, int value);
 /* advance (BimocqGPUSolver.cpp:108-127) */
 void  bq_solver_advance(bq_solver *s, int framenum, float dt);

@@ -831,6 +831,11 @@ struct orc_solver {
     int jacobi_iters; float halfrdx;
     /* projection(): 0 = Jacobi (`#if 0` branch), 1 = fp64 multigrid-CG (the `#else` branch, :443-446) */
     int projection_kind, mg_iters, mg_levels;
+    /* 0: re-initialise both map sets every frame (the GPU solver's `if (1)`, BimocqGPUSolver.cpp:218-229);
+     * 1: distortion-driven, the CPU solver's thresholds (BimocqSolver.cpp:165-185) */
+    int reinit_policy;
+    float max_v, last_vel_distortion, last_scalar_distortion;
+    int vel_reinits, scalar_reinits;
     double *mg_div, *mg_p, *mg_dir, *mg_res, *mg_t0, *mg_t1, *mg_result;
     OrcCoarseLevel mg_level[6];
     /* BimocqGPUSolver.h:74-87 buffer roles */
@@ -925,7 +930,11 @@ void orc_solver_set_smoke(orc_solver *s, float drop_alpha, float rise_beta,
 void orc_solver_set_option(orc_solver *s, int option, int value)
 {
     if (option == 1) s->keep_dmc_border = value != 0;
+    if (option == 2) s->reinit_policy = value;
 }
+
+int orc_solver_reinit_counts(const orc_solver *s, int which) { return which ? s->scalar_reinits : s->vel_reinits; }
+float orc_solver_last_distortion(const orc_solver *s, int which) { return which ? s->last_scalar_distortion : s->last_vel_distortion; }
 
 /* BimocqGPUSolver.cpp:60-90: the fp64 work arrays and the level pyramid n -> (n - 1) / 2.  Levels that
  * would have no cell at all are left out (the reference launches empty grids for them). */
@@ -997,6 +1006,18 @@ static void mapper_reinit(orc_solver *s, mapper_t *m)
     memcpy(m->fx, m->ix, b);  memcpy(m->fy, m->iy, b);  memcpy(m->fz, m->iz, b);
 }
 
+/* MapperBaseGPU::estimateDistortion (Mapping.cpp:495-519): sqrt of the largest round-trip error of the
+ * map pair, over the cells estimate_kernel writes (the scratch is cleared first; the reference scans a
+ * scratch buffer that still holds older data outside that window) */
+static float mapper_distortion(orc_solver *s, mapper_t *m)
+{
+    memset(s->u_src, 0, s->n * sizeof(float));
+    orc_estimate_distortion(s->u_src, m->bx, m->by, m->bz, m->fx, m->fy, m->fz, s->h, s->ni, s->nj, s->nk);
+    float mx = 0.f;
+    for (size_t q = 0; q < s->n; q++) if (s->u_src[q] > mx) mx = s->u_src[q];
+    return sqrtf(mx);
+}
+
 /* Mapping.cpp:393-407 + GPU_Advection.h:505-528 */
 static void advect_scalar(orc_solver *s, float *f, float *finit, const float *fprev)
 {
@@ -1023,8 +1044,10 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
 
     /* getCFL(): BimocqGPUSolver.cpp:348-373 (evaluated on the current device fields: equal
      * to the reference's host copies when outputResult follows every advance) */
-    float cfldt = h / orc_max_abs3(s->U, s->V, s->W, ni, nj, nk);
+    s->max_v = orc_max_abs3(s->U, s->V, s->W, ni, nj, nk);
+    float cfldt = h / s->max_v;
     s->last_cfldt = cfldt;
+    const int policy = s->reinit_policy;
 
     mapper_update(s, &s->vel, cfldt, dt);                               /* :138 */
     mapper_update(s, &s->scal, cfldt, dt);                              /* :139 */
@@ -1045,6 +1068,9 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
     advect_scalar(s, s->T, s->Ti, s->Tp);                               /* :145 */
 
     memcpy(s->Ut, s->U, bu); memcpy(s->Vt, s->V, bv); memcpy(s->Wt, s->W, bw);   /* :157-159 */
+    /* policy 1 follows the CPU solver here (BimocqSolver.cpp:129-133): the scalar snapshots are taken BEFORE the
+     * sources act, so that rho - rhoTemp is what emission added (the GPU solver takes them after) */
+    if (policy == 1) { memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs); }
 
     for (int e = 0; e < s->n_em; e++)                                    /* :376-392 */
         if (framenum < s->em[e].emit_frames)
@@ -1076,7 +1102,7 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
                               s->jacobi_iters, s->halfrdx, -1.f, (float)(1.0 / 6.0));
     }
 
-    memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs);               /* :185-186 */
+    if (policy == 0) { memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs); }   /* :185-186 */
     memcpy(s->dUp, s->U, bu); memcpy(s->dVp, s->V, bv); memcpy(s->dWp, s->W, bw);  /* :188-190 */
     orc_add(s->dUp, s->Ut, -1.f, (int)s->nu);                           /* :191-193 */
     orc_add(s->dVp, s->Vt, -1.f, (int)s->nv);
@@ -1085,8 +1111,18 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
     orc_add(s->rhoe, s->rhot, -1.f, (int)s->n);
     orc_add(s->Te, s->Tt, -1.f, (int)s->n);
 
-    if (framenum - s->vel_last > 10) { s->vel_last = framenum; proj_coeff = 1.f; }   /* :200-205 */
-    if (framenum - s->scal_last > 30) { s->scal_last = framenum; }                    /* :207-211 */
+    int vel_reinit = 1, scalar_reinit = 1;
+    if (policy == 1) {
+        /* BimocqSolver.cpp:165-185: distortion of each map set in units of the step's travel */
+        s->last_vel_distortion = mapper_distortion(s, &s->vel) / (s->max_v * dt);
+        s->last_scalar_distortion = mapper_distortion(s, &s->scal) / (s->max_v * dt);
+        vel_reinit = scalar_reinit = 0;
+        if (s->last_vel_distortion > 1.f || framenum - s->vel_last > 10) { vel_reinit = 1; s->vel_last = framenum; proj_coeff = 1.f; }
+        if (s->last_scalar_distortion > 5.f || framenum - s->scal_last > 30) { scalar_reinit = 1; s->scal_last = framenum; }
+    } else {
+        if (framenum - s->vel_last > 10) { s->vel_last = framenum; proj_coeff = 1.f; }   /* :200-205 */
+        if (framenum - s->scal_last > 30) { s->scal_last = framenum; }                    /* :207-211 */
+    }
 
     {   /* :213-216 */
         mapper_t *m = &s->vel;
@@ -1097,14 +1133,16 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
         orc_accumulate_field(s->Te, s->Ti, q->fx, q->fy, q->fz, h, ni, nj, nk, 0, 1.f);
     }
 
-    {   /* :218-223 `if (1)`: reinitialise every frame (Q5) */
+    if (vel_reinit) {   /* :218-223 `if (1)`: reinitialise every frame (Q5); policy 1: BimocqSolver.cpp:203-215 */
         mapper_t *m = &s->vel;
+        s->vel_reinits++;
         mapper_reinit(s, m);
         memcpy(s->Up, s->Ui, bu); memcpy(s->Vp, s->Vi, bv); memcpy(s->Wp, s->Wi, bw);  /* :509-511 */
         memcpy(s->Ui, s->U, bu);  memcpy(s->Vi, s->V, bv);  memcpy(s->Wi, s->W, bw);   /* :513-515 */
         orc_accumulate_velocity(s->dUp, s->dVp, s->dWp, s->Ui, s->Vi, s->Wi, m->fx, m->fy, m->fz, h, ni, nj, nk, 0, 1.f);
     }
-    {   /* :225-229 */
+    if (scalar_reinit) {   /* :225-229; policy 1: BimocqSolver.cpp:216-227 */
+        s->scalar_reinits++;
         mapper_reinit(s, &s->scal);
         memcpy(s->rhop, s->rhoi, bs); memcpy(s->Tp, s->Ti, bs);         /* :522-523 */
         memcpy(s->rhoi, s->rho, bs);  memcpy(s->Ti, s->T, bs);          /* :525-526 */

@@ -172,6 +172,10 @@ void  orc_solver_set_projection(orc_solver *s, int jacobi_iters, float halfrdx);
 void  orc_solver_set_projection_kind(orc_solver *s, int kind, int iters);
 int   orc_solver_mg_levels(const orc_solver *s);
 const double *orc_solver_mg_history(const orc_solver *s);
+/* after a step: how often each map set was re-initialised so far (which: 0 velocity, 1 scalar) and the
+ * distortions the last step measured (policy 1 only) */
+int   orc_solver_reinit_counts(const orc_solver *s, int which);
+float orc_solver_last_distortion(const orc_solver *s, int which);
 void  orc_solver_set_option(orc_solver *s, int option, int value);
 void  orc_solver_advance(orc_solver *s, int framenum, float dt);
 /* which: 0 rho, 1 T, 2 u, 3 v, 4 w, 5 uinit, 6 vinit, 7 winit, 8 rhoinit, 9 Tinit,

@@ -13,6 +13,7 @@
 
 #include "../../include/bimocq_gpu.h"
 #include "../../oracle/bimocq_oracle.h"
+#include <math.h>
 
 static int g_err = FL_OK;
 static char g_text[256];
@@ -190,6 +191,12 @@ void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
 { orc_mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter); }
+float gpu_max_field(const float *field, size_t count)
+{
+    float m = 0.f;
+    for (size_t q = 0; q < count; q++) if (fabsf(field[q]) > m) m = fabsf(field[q]);
+    return m;
+}
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
 { orc_clamp_extrema_box_w(before, after, ni, nj, nk); }
 void gpu_divergence(const float *u, const float *v, const float *w, float *div, int ni, int nj, int nk, float hr)

@@ -99,6 +99,8 @@ _SIGS = {
     "orc_solver_destroy": (None, [C.c_void_p]),
     "orc_solver_set_smoke": (None, [C.c_void_p, c_f, c_f, C.POINTER(Emitter), c_i]),
     "orc_solver_set_projection": (None, [C.c_void_p, c_i, c_f]),
+    "orc_solver_reinit_counts": (c_i, [C.c_void_p, c_i]),
+    "orc_solver_last_distortion": (c_f, [C.c_void_p, c_i]),
     "orc_solver_set_projection_kind": (None, [C.c_void_p, c_i, c_i]),
     "orc_solver_mg_levels": (c_i, [C.c_void_p]),
     "orc_solver_mg_history": (DP, [C.c_void_p]),
@@ -158,6 +160,12 @@ class OracleSolver:
 
     def set_option(self, option, value):
         self.l.orc_solver_set_option(self.s, option, value)
+
+    def reinit_counts(self):
+        return self.l.orc_solver_reinit_counts(self.s, 0), self.l.orc_solver_reinit_counts(self.s, 1)
+
+    def last_distortion(self):
+        return self.l.orc_solver_last_distortion(self.s, 0), self.l.orc_solver_last_distortion(self.s, 1)
 
     def advance(self, frame, dt):
         self.l.orc_solver_advance(self.s, frame, dt)

@@ -17,7 +17,7 @@ FIELDS = ["rho", "T", "u", "v", "w", "uinit", "vinit", "winit", "rhoinit", "Tini
           "fx", "fy", "fz", "bx", "by", "bz", "p"]
 
 
-def run_pair(dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps, kind=0):
+def run_pair(dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps, kind=0, policy=0):
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     ni, nj, nk = dims
     o = OracleSolver(ni, nj, nk, L, visc, blend)
@@ -26,6 +26,9 @@ def run_pair(dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, st
     s = BimocqGPUSolver(ni, nj, nk, L, visc, blend)
     s.setSmoke(drop, rise, emitters)
     s.setProjection(iters, hr, kind)
+    if policy:
+        o.set_option(2, policy)
+        s.setOption(2, policy)
     dt = dt_cells * float(np.float32(L) / np.float32(ni))
     rms = {}
     for f in range(steps):
@@ -41,6 +44,9 @@ def run_pair(dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, st
     assert max(rms.values()) <= 1e-5            # the north star's stated tolerance (here: exactly 0)
     if kind == 1:
         assert F.same(o.mg_history(), s.mgHistory())
+    if policy:
+        assert s.reinitCounts() == o.reinit_counts() and s.lastDistortion() == o.last_distortion()
+        rms["reinits"] = s.reinitCounts()
     o.close(); s.close()
     return rms
 
@@ -187,3 +193,19 @@ def test_multigrid_cg_noncubic_blend():
     run_pair((24, 20, 16), 0.6, 0.0, 0.7,
              [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 0.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, 0.0, 3)],
              0.1, 1.0, 3, 1.0, 3.0, 4, kind=1)
+
+
+def test_distortion_driven_reinitialisation_policy():
+    """BQ_OPT_REINIT_POLICY = 1 -- maps live for several steps, separate velocity/scalar schedules
+    (BimocqSolver.cpp:165-229), blend < 1, 3-frame source; 16 steps bit-identical to the oracle including the
+    measured distortions and the re-initialisation counts"""
+    r = run_pair((32, 32, 32), 1.0, 0.0, 0.8, [(0.5, 0.2, 0.5, 0.12, 1.0, 1.0, 0.0, 3)], 0.0, 1.0, 30, 1.0, 1.5, 16, policy=1)
+    vel, scal = r["reinits"]
+    assert 2 <= vel < 16 and 1 <= scal <= vel
+
+
+def test_distortion_policy_non_pow2_spacing():
+    r = run_pair((24, 20, 16), 0.6, 0.0, 0.7,
+                 [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 0.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, 0.0, 3)],
+                 0.1, 1.0, 20, 1.0, 2.0, 8, policy=1)
+    assert 1 <= r["reinits"][1] <= r["reinits"][0] <= 8       # (this violent little scene re-initialises often)

@@ -27,7 +27,7 @@ def cpu_host():
     return lib
 
 
-def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps, kind=0):
+def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps, kind=0, policy=0):
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     ni, nj, nk = dims
     o = OracleSolver(ni, nj, nk, L, visc, blend)
@@ -36,6 +36,9 @@ def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt
     s = BimocqGPUSolver(ni, nj, nk, L, visc, blend, lib=cpu_host, errlib=cpu_host)
     s.setSmoke(drop, rise, emitters)
     s.setProjection(iters, hr, kind)
+    if policy:
+        o.set_option(2, policy)
+        s.setOption(2, policy)
     dt = dt_cells * float(np.float32(L) / np.float32(ni))
     for f in range(steps):
         o.advance(f, dt)
@@ -44,7 +47,11 @@ def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt
         for name in FIELDS:
             a, b = o.field(name), s.field(name)
             assert F.same(a, b), (f, name, F.maxdiff(a, b))
-    assert s.reinit_count == steps
+    if policy == 0:
+        assert s.reinit_count == steps
+    else:
+        assert s.reinitCounts() == o.reinit_counts()
+        assert s.lastDistortion() == o.last_distortion()
     return o, s
 
 
@@ -62,6 +69,17 @@ def test_multigrid_cg_projection_mode(cpu_host):
     ho, hs = o.mg_history(), s.mgHistory()
     assert ho is not None and hs is not None and F.same(ho, hs)
     assert hs[2004] < 1e-2 * hs[2000]               # four outer iterations cut the residual peak 100x
+
+
+def test_distortion_driven_reinitialisation(cpu_host):
+    """BQ_OPT_REINIT_POLICY = 1: maps live for several steps, the velocity and scalar sets follow
+    their own schedules (BimocqSolver.cpp:165-229), blend < 1 makes the two-level advection real; 16 steps with
+    a 3-frame source so that emission has to reach DensityInit through the accumulation"""
+    o, s = run_pair(cpu_host, (24, 24, 24), 1.0, 0.0, 0.8, [(0.5, 0.2, 0.5, 0.12, 1.0, 1.0, 0.0, 3)],
+                    0.0, 1.0, 30, 1.0, 1.5, 16, policy=1)
+    vel, scal = s.reinitCounts()
+    assert 2 <= vel < 16 and 1 <= scal < 16 and scal <= vel, (vel, scal)
+    assert np.isfinite(o.field("rho")).all() and o.field("rho").sum() > 10.0
 
 
 def test_noncubic_two_emitters_blend_substeps(cpu_host):
