@@ -381,6 +381,42 @@ __global__ __launch_bounds__(256) void semilag_kernel(float *field, const float 
     field[(size_t)i + (size_t)bi * j + (size_t)bi * bj * k] = sample<P2>(src, sp, org, pn);
 }
 
+// ---- N3: clamp_extrema_kernel (GPU_kernel.cu:892-942), corrected -------------------------------
+// MacCormack limiter of the reflection scheme.  The reference kernel adds the stagger offset with the wrong
+// sign, uses the departure point's world coordinates as grid indices and tests/overwrites fieldTemp at that
+// index from every thread: undefined output.  Built as it evidently means (oracle: orc_clamp_extrema):
+// node x = (i - o) h, x_d = x - dt u(x - dt/2 u(x)) clamped to [h, (n-1)h]; min/max of the 8 values of
+// `field` around x_d; fieldTemp at THIS node outside that range -> trilinear value of `field` at x_d.
+template <bool P2>
+__global__ __launch_bounds__(256) void clamp_extrema_kernel(const float *field, float *field_temp,
+                                                            const float *u, const float *v, const float *w,
+                                                            Spacing sp, int ni, int nj, int nk, int dx, int dy, int dz,
+                                                            float ox, float oy, float oz, float dt)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= ni || j >= nj || k >= nk) return;
+    const float h = sp.h;
+    const int ci = ni - dx, cj = nj - dy, ck = nk - dz;
+    Vel3 vel{make_field(u, ci + 1, cj, ck, 0), make_field(v, ci, cj + 1, ck, 0), make_field(w, ci, cj, ck + 1, 0)};
+    Field src = make_field(field, ni, nj, nk, 0);
+    const f3 org = mk3(-ox * h, -oy * h, -oz * h);
+    const f3 lo = mk3(h, h, h), hi = mk3((float)ci * h - h, (float)cj * h - h, (float)ck * h - h);
+    const float halfdt = 0.5f * dt;
+    const f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+    f3 vl = get_velocity<P2>(vel, sp, pt);
+    f3 px = mk3(pt.x - vl.x * halfdt, pt.y - vl.y * halfdt, pt.z - vl.z * halfdt);
+    vl = get_velocity<P2>(vel, sp, px);
+    px = clamp3(mk3(pt.x - vl.x * dt, pt.y - vl.y * dt, pt.z - vl.z * dt), lo, hi);
+    const Cell c = locate<P2>(src, sp, org, px);
+    float cv[8];
+    corners(src, c, cv);
+    const float mn = fminf(cv[0], fminf(cv[1], fminf(cv[2], fminf(cv[3], fminf(cv[4], fminf(cv[5], fminf(cv[6], cv[7])))))));
+    const float mx = fmaxf(cv[0], fmaxf(cv[1], fmaxf(cv[2], fmaxf(cv[3], fmaxf(cv[4], fmaxf(cv[5], fmaxf(cv[6], cv[7])))))));
+    const size_t id = (size_t)i + (size_t)ni * j + (size_t)ni * nj * k;
+    const float t = field_temp[id];
+    if (t < mn || t > mx) field_temp[id] = gather(src, c);
+}
+
 // ---- host-side dispatch helpers -----------------------------------------------------------
 // local dims + the library's slab context (fl_set_slab); single GPU: koff = 0, nkg = nk
 static inline Grid mk_grid(int ni, int nj, int nk)
@@ -393,9 +429,9 @@ static inline Grid mk_grid(int ni, int nj, int nk)
 static bool dims_ok(int ni, int nj, int nk, const char *op)
 {
     if (ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, op, "non-positive grid dims"); return false; }
-    // byte offsets are 32-bit in the buffer descriptors: (ni+1)*(nj+1)*(nk+1)*4 must fit
+    // byte offsets are 32-bit in the buffer descriptors and 2 GiB is the parking offset of out-of-range cells (bq_device.hip.h: corners()): (ni+1)*(nj+1)*(nk+1)*4 must stay below it
     double bytes = 4.0 * (double)(ni + 1) * (double)(nj + 1) * (double)(nk + 1);
-    if (bytes >= 4294967296.0) { latch(FL_ERR_BAD_ARGUMENT, op, "field larger than 4 GiB"); return false; }
+    if (bytes >= 2147483648.0) { latch(FL_ERR_BAD_ARGUMENT, op, "field larger than 2 GiB"); return false; }
     if (nk + 1 > 65535) { latch(FL_ERR_BAD_ARGUMENT, op, "nk too large for grid.z"); return false; }
     return true;
 }
@@ -737,6 +773,19 @@ void gpu_semilag(float *field, float *field_src, float *u, float *v, float *w,
     BQ_REQUIRE((dim_x | dim_y | dim_z) == 0 || (dim_x + dim_y + dim_z) == 1, "gpu_semilag");
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     BQ_DISPATCH1(semilag_kernel, sp.pow2, grid_for(ni + dim_x, nj + dim_y, nk + dim_z), field, field_src, u, v, w, sp, g, dim_x, dim_y, dim_z, cfldt, dt);
+}
+
+void gpu_clamp_extrema(float *field, float *fieldTemp, float *u, float *v, float *w,
+                       int ni, int nj, int nk, int dimx, int dimy, int dimz,
+                       float ox, float oy, float oz, float h, float dt)
+{
+    BQ_ENTER("gpu_clamp_extrema", field, fieldTemp, u, v, w)
+    BQ_REQUIRE(field != fieldTemp && ((dimx | dimy | dimz) == 0 || (dimx + dimy + dimz) == 1) &&
+               ni - dimx >= 1 && nj - dimy >= 1 && nk - dimz >= 1, "gpu_clamp_extrema");
+    if (rt().slab_on) { latch(FL_ERR_UNSUPPORTED, "gpu_clamp_extrema", "the reflection scheme is single-GPU"); return; }
+    Spacing sp = make_spacing(h);
+    BQ_DISPATCH1(clamp_extrema_kernel, sp.pow2, grid_for(ni, nj, nk), field, fieldTemp, u, v, w, sp, ni, nj, nk,
+                 dimx, dimy, dimz, ox, oy, oz, dt);
 }
 
 void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)

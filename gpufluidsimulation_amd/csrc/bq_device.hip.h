@@ -90,7 +90,7 @@ __device__ __forceinline__ float lerp_const(float a, float b, float c, double om
 
 // Cell + weights of one sample position (GPU_kernel.cu:45-51)
 struct Cell {
-    unsigned base;          // byte offset of corner 000 (wraps for negative indices -> out of range)
+    unsigned base;          // byte offset of corner 000; 2 GiB (out of range) when its flat index is negative
     float fx, fy, fz;
 };
 
@@ -105,23 +105,36 @@ __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off
     Cell c;
     c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k;
     int idx = i + f.nx * j + f.nx * f.ny * (k - f.koff);
-    c.base = (unsigned)idx * 4u;
+    c.base = idx < 0 ? 0x80000000u : (unsigned)idx * 4u;    // negative base: every corner out of range (see corners())
     return c;
+}
+
+// The 8 corner values of a cell.  Contract (oracle: sample()): a cell whose base corner has a NEGATIVE flat
+// index reads all zeros; otherwise a corner whose flat index lies in [0, count) is read and anything else is
+// 0 (a corner one past a row/plane wraps into the next one, as the reference's flat indexing does).
+// locate() parks a negative base at 2 GiB, beyond every field (dims_ok caps them at 2 GiB), so the range
+// check of the buffer descriptor delivers exactly that -- no compare or branch per corner.  (Without the
+// parking a base of index -1 would wrap through 2^32: the address unit adds the instruction's immediate
+// +4 beyond 32 bits and reports out-of-range where the wrapped offset 0 is valid.)
+__device__ __forceinline__ void corners(const Field &f, const Cell &c, float (&v)[8])
+{
+    const unsigned sj = (unsigned)f.nx * 4u, sk = (unsigned)f.nx * (unsigned)f.ny * 4u;
+    v[0] = ldf(f, c.base);           v[1] = ldf(f, c.base + 4u);
+    v[2] = ldf(f, c.base + sj);      v[3] = ldf(f, c.base + sj + 4u);
+    v[4] = ldf(f, c.base + sk);      v[5] = ldf(f, c.base + sk + 4u);
+    v[6] = ldf(f, c.base + sk + sj); v[7] = ldf(f, c.base + sk + sj + 4u);
 }
 
 // GPU_kernel.cu:27-41 + :53-61
 __device__ __forceinline__ float gather(const Field &f, const Cell &c)
 {
-    unsigned sj = (unsigned)f.nx * 4u, sk = (unsigned)f.nx * (unsigned)f.ny * 4u;
-    float v000 = ldf(f, c.base),           v001 = ldf(f, c.base + 4u);
-    float v010 = ldf(f, c.base + sj),      v011 = ldf(f, c.base + sj + 4u);
-    float v100 = ldf(f, c.base + sk),      v101 = ldf(f, c.base + sk + 4u);
-    float v110 = ldf(f, c.base + sk + sj), v111 = ldf(f, c.base + sk + sj + 4u);
+    float v[8];
+    corners(f, c, v);
     double ox = 1.0 - (double)c.fx, oy = 1.0 - (double)c.fy, oz = 1.0 - (double)c.fz;
-    float l00 = lerp_w(v000, v001, c.fx, ox);
-    float l01 = lerp_w(v010, v011, c.fx, ox);
-    float l10 = lerp_w(v100, v101, c.fx, ox);
-    float l11 = lerp_w(v110, v111, c.fx, ox);
+    float l00 = lerp_w(v[0], v[1], c.fx, ox);
+    float l01 = lerp_w(v[2], v[3], c.fx, ox);
+    float l10 = lerp_w(v[4], v[5], c.fx, ox);
+    float l11 = lerp_w(v[6], v[7], c.fx, ox);
     float m0 = lerp_w(l00, l01, c.fy, oy);
     float m1 = lerp_w(l10, l11, c.fy, oy);
     return lerp_w(m0, m1, c.fz, oz);

@@ -198,11 +198,6 @@ void gpu_mad(float *field, float *field1, float *field2, float coeff1, float coe
     BQ_LAUNCH_CHECK("mad_kernel");
 }
 
-void gpu_clamp_extrema(float *, float *, float *, float *, float *, int, int, int, int, int, int, float, float, float, float, float)
-{
-    latch(FL_ERR_UNSUPPORTED, "gpu_clamp_extrema", "out of scope: reflection-scheme limiter (buggy in the reference)");
-}
-
 void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk)
 {
     if (!ensure_ready("gpu_init_maps")) return;

@@ -110,12 +110,87 @@ void BimocqGPUSolver::advance(int framenum, float dt)
     GpuSolver->startEventRecord();
     switch (myscheme) {
     case BIMOCQ: advanceBimocq(framenum, dt); break;
-    default:
-        // the other schemes (advanceReflection, :232-337) are out of scope for this path
-        break;
+    case MAC_REFLECTION: advanceReflection(framenum, dt); break;
+    default: break;                                      // the reference's GPU solver has no other scheme (:112-122)
     }
     last_ms = GpuSolver->endEventRecord();
     if (verbose) printf("[Bimocq GPU Time: %gms ]\n", last_ms);
+}
+
+// :232-337 advanceReflection: MacCormack advection of rho, T and of the velocity (half step),
+// sources, projection, reflection 2 u_proj - u advected another half step, sources, projection.  The
+// limiter is the corrected gpu_clamp_extrema (include/bimocq_gpu.h).  Single GPU.
+void BimocqGPUSolver::advanceReflection(int framenum, float dt)
+{
+    gpuMapper &gs = *GpuSolver;
+    if (gs.slab.on && gs.slab.nranks > 1) { fl_report_error(FL_ERR_UNSUPPORTED, "the reflection scheme is single-GPU"); return; }
+    DeviceField *extra[] = { &DensityTemp, &TemperatureTemp };
+    for (DeviceField *f : extra)
+        if (!f->get() && !gs.allocField(*f, FIELD_S)) return;
+    const float cfldt = getCFL();                        // :234
+    last_cfldt = cfldt;
+    const float h = CellSize;
+    const int ni = g.ni, nj = g.nj, nk = g.nk;
+    const size_t n = g.n(), nu = g.nu(), nv = g.nv(), nw = g.nw();
+
+    // semilagAdvectField / semilagAdvectVelocity (GPU_Advection.h:530-551) clear their outputs first
+    auto semilagScalar = [&](DeviceField &dst, DeviceField &src, float t) {
+        fl_memset(dst, 0, n * sizeof(float));
+        gpu_semilag(dst, src, VelocityU, VelocityV, VelocityW, 0, 0, 0, h, ni, nj, nk, cfldt, t);
+    };
+    auto semilagVelocity = [&](DeviceField &uo, DeviceField &vo, DeviceField &wo, DeviceField &us, DeviceField &vs, DeviceField &ws, float t) {
+        uo.zero(); vo.zero(); wo.zero();
+        gpu_semilag(uo, us, VelocityU, VelocityV, VelocityW, 1, 0, 0, h, ni, nj, nk, cfldt, t);
+        gpu_semilag(vo, vs, VelocityU, VelocityV, VelocityW, 0, 1, 0, h, ni, nj, nk, cfldt, t);
+        gpu_semilag(wo, ws, VelocityU, VelocityV, VelocityW, 0, 0, 1, h, ni, nj, nk, cfldt, t);
+    };
+    auto clampVelocity = [&]() {                         // :283-285, :323-325: source field = VelocityU/V/W
+        gpu_clamp_extrema(VelocityU, VelocityUTemp, VelocityU, VelocityV, VelocityW, ni + 1, nj, nk, 1, 0, 0, 0.5f, 0.f, 0.f, h, 0.5f * dt);
+        gpu_clamp_extrema(VelocityV, VelocityVTemp, VelocityU, VelocityV, VelocityW, ni, nj + 1, nk, 0, 1, 0, 0.f, 0.5f, 0.f, h, 0.5f * dt);
+        gpu_clamp_extrema(VelocityW, VelocityWTemp, VelocityU, VelocityV, VelocityW, ni, nj, nk + 1, 0, 0, 1, 0.f, 0.f, 0.5f, h, 0.5f * dt);
+    };
+    auto sources = [&](bool emit) {                      // :289-297 / :330-337
+        if (emit) emitSmoke(framenum, dt);
+        addBuoyancy(0.5f * dt);
+        if (Viscosity) {
+            diffuseField(VelocityU, VelocityUTemp, TempSrcU, ni + 1, nj, nk, 20, Viscosity, 0.5f * dt);
+            diffuseField(VelocityV, VelocityVTemp, TempSrcV, ni, nj + 1, nk, 20, Viscosity, 0.5f * dt);
+            diffuseField(VelocityW, VelocityWTemp, TempSrcW, ni, nj, nk + 1, 20, Viscosity, 0.5f * dt);
+        }
+    };
+
+    DeviceField *scal[2] = { &Density, &Temperature }, *tmp[2] = { &DensityTemp, &TemperatureTemp };
+    for (int a = 0; a < 2; a++) {                        // :237-263
+        semilagScalar(*tmp[a], *scal[a], -dt);
+        semilagScalar(TempSrcU, *tmp[a], dt);
+        gs.add(*tmp[a], TempSrcU, -0.5f, n);
+        gs.add(*tmp[a], *scal[a], 0.5f, n);
+        gpu_clamp_extrema(*scal[a], *tmp[a], VelocityU, VelocityV, VelocityW, ni, nj, nk, 0, 0, 0, 0.f, 0.f, 0.f, h, dt);
+        fl_memcpy_d2d(*scal[a], *tmp[a], n * sizeof(float));
+    }
+    // :267-287
+    semilagVelocity(VelocityUTemp, VelocityVTemp, VelocityWTemp, VelocityU, VelocityV, VelocityW, -0.5f * dt);
+    semilagVelocity(TempSrcU, TempSrcV, TempSrcW, VelocityUTemp, VelocityVTemp, VelocityWTemp, 0.5f * dt);
+    gs.add(VelocityUTemp, TempSrcU, -0.5f, nu); gs.add(VelocityVTemp, TempSrcV, -0.5f, nv); gs.add(VelocityWTemp, TempSrcW, -0.5f, nw);
+    gs.add(VelocityUTemp, VelocityU, 0.5f, nu); gs.add(VelocityVTemp, VelocityV, 0.5f, nv); gs.add(VelocityWTemp, VelocityW, 0.5f, nw);
+    clampVelocity();
+    VelocityU.copy_from(VelocityUTemp); VelocityV.copy_from(VelocityVTemp); VelocityW.copy_from(VelocityWTemp);
+
+    sources(true);
+    VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);   // :299-303
+    projection();                                        // :305
+    gpu_mad(duProj, VelocityU, VelocityUTemp, 2.f, -1.f, (int)nu);      // :307-309
+    gpu_mad(dvProj, VelocityV, VelocityVTemp, 2.f, -1.f, (int)nv);
+    gpu_mad(dwProj, VelocityW, VelocityWTemp, 2.f, -1.f, (int)nw);
+    semilagVelocity(VelocityUTemp, VelocityVTemp, VelocityWTemp, duProj, dvProj, dwProj, -0.5f * dt);             // :311
+    semilagVelocity(TempSrcU, TempSrcV, TempSrcW, VelocityUTemp, VelocityVTemp, VelocityWTemp, 0.5f * dt);        // :313
+    gs.add(VelocityUTemp, TempSrcU, -0.5f, nu); gs.add(VelocityVTemp, TempSrcV, -0.5f, nv); gs.add(VelocityWTemp, TempSrcW, -0.5f, nw);
+    gs.add(VelocityUTemp, duProj, 0.5f, nu); gs.add(VelocityVTemp, dvProj, 0.5f, nv); gs.add(VelocityWTemp, dwProj, 0.5f, nw);
+    clampVelocity();
+    VelocityU.copy_from(VelocityUTemp); VelocityV.copy_from(VelocityVTemp); VelocityW.copy_from(VelocityWTemp);
+    sources(false);
+    projection();
+    steps_taken++;
 }
 
 // :348-373.  The reference scans host copies that outputResult() refreshed after the previous

@@ -33,6 +33,7 @@ public:
 
     void advance(int framenum, float dt);
     void advanceBimocq(int framenum, float dt);
+    void advanceReflection(int framenum, float dt);
     float getCFL();
     void emitSmoke(int framenum, float dt);
     void addBuoyancy(float dt);

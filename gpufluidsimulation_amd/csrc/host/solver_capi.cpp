@@ -21,7 +21,7 @@ bq_solver *bq_solver_create(int device, int nx, int ny, int nz, float L, float v
 bq_solver *bq_solver_create_slab(int device, int nx, int ny, int nz, float L, float viscosity, float blend, int scheme,
                                  int rank, int nranks, int ghost)
 {
-    if (nx < 8 || ny < 8 || nz < 8 || scheme != BQ_SCHEME_BIMOCQ) return nullptr;
+    if (nx < 8 || ny < 8 || nz < 8 || (scheme != BQ_SCHEME_BIMOCQ && scheme != BQ_SCHEME_MAC_REFLECTION)) return nullptr;
     SlabCtx sl;
     if (nranks > 1 || ghost > 0) {
         // even z-slabs: rank r owns planes [r*nz/nranks, (r+1)*nz/nranks); each must be deeper than the ghost zone
@@ -35,7 +35,7 @@ bq_solver *bq_solver_create_slab(int device, int nx, int ny, int nz, float L, fl
     auto s = std::make_unique<bq_solver>();
     s->mapper = std::make_unique<gpuMapper>(device, nx, ny, nz, L / nx, sl);   // main.cpp:151 / :37 (h = L/ni)
     if (!s->mapper->ok()) return nullptr;
-    s->solver = std::make_unique<BimocqGPUSolver>(nx, ny, nz, L, viscosity, blend, BIMOCQ, s->mapper.get());
+    s->solver = std::make_unique<BimocqGPUSolver>(nx, ny, nz, L, viscosity, blend, scheme == BQ_SCHEME_MAC_REFLECTION ? MAC_REFLECTION : BIMOCQ, s->mapper.get());
     if (!s->solver->ok()) return nullptr;
     return s.release();
 }

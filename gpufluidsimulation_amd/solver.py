@@ -66,14 +66,14 @@ class BimocqGPUSolver:
     can drive the very same host code linked against a CPU stand-in of the C-ABI."""
 
     def __init__(self, nx, ny, nz, L=1.0, viscosity=0.0, blend=1.0, device=0, lib=None, errlib=None,
-                 rank=0, nranks=1, ghost=0):
+                 rank=0, nranks=1, ghost=0, scheme=0):
         """nz is the GLOBAL plane count; with nranks > 1 (or ghost > 0) this object is one z-slab rank
         (set the communicator up first: gpufluidsimulation_amd.transport)."""
         self.lib = lib or host_lib()
         self.errlib = errlib or (_lib.hip_lib() if lib is None else lib)
         self.nx, self.ny, self.nz = nx, ny, nz
         self.h = float(np.float32(L) / np.float32(nx))
-        self.s = self.lib.bq_solver_create_slab(device, nx, ny, nz, L, viscosity, blend, 0, rank, nranks, ghost)
+        self.s = self.lib.bq_solver_create_slab(device, nx, ny, nz, L, viscosity, blend, scheme, rank, nranks, ghost)
         if not self.s:
             self._check()
             raise _lib.BimocqError("bq_solver_create failed")

@@ -162,9 +162,14 @@ void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
                            float *debugParam, int ni, int nj, int nk, int iter,
                            float halfrdx, float alpha, float beta);
 
-/* GPU_Advection.h:101 -- OUT OF SCOPE (MacCormack limiter of the reflection scheme; the
- * reference kernel uses world coordinates as grid indices, GPU_kernel.cu:913-915).
- * Latches FL_ERR_UNSUPPORTED. */
+/* GPU_Advection.h:101 / GPU_kernel.cu:892-950 -- MacCormack limiter of the reflection scheme, CORRECTED
+ * (SURVEY 8f N3).  The reference kernel adds the stagger offset with the wrong sign, uses the departure
+ * point's world coordinates as grid indices (:913-915) and tests/overwrites fieldTemp there from every
+ * thread, so its output is undefined; this entry does what it evidently means:
+ *   node x = (i - o) h, o = (ox, oy, oz) (0.5 along the staggered axis); x_d = x - dt u(x - dt/2 u(x)),
+ *   clamped to [h, (n-1)h]; if fieldTemp at this node lies outside the min/max of the 8 values of `field`
+ *   around x_d, it becomes the trilinear value of `field` at x_d.
+ * ni, nj, nk: BUFFER dims (cells + dim).  field is read only; fieldTemp must not alias it. */
 void gpu_clamp_extrema(float *field, float *fieldTemp, float *u, float *v, float *w,
                        int ni, int nj, int nk, int dimx, int dimy, int dimz,
                        float ox, float oy, float oz, float h, float dt);

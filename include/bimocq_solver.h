@@ -23,7 +23,9 @@ typedef struct bq_emitter {
     int   emit_frames;                  /* active while framenum < emit_frames */
 } bq_emitter;
 
-enum { BQ_SCHEME_BIMOCQ = 0 };          /* enum Scheme, BimocqSolver.h:29 (others: out of scope) */
+/* enum Scheme, BimocqSolver.h:29.  The reference's GPU solver implements BIMOCQ and MAC_REFLECTION
+ * (BimocqGPUSolver.cpp:112-122); the reflection scheme runs with the corrected limiter (gpu_clamp_extrema). */
+enum { BQ_SCHEME_BIMOCQ = 0, BQ_SCHEME_MAC_REFLECTION = 3 };
 enum {
     BQ_PROJECTION_JACOBI = 0,           /* the `#if 0` branch of BimocqGPUSolver::projection (:408-417); iters = sweeps      */
     BQ_PROJECTION_MGCG = 1              /* the `#else` branch (:443-446): fp64 multigrid-CG; iters = outer iterations (50)  */

@@ -72,8 +72,10 @@ static inline float ld(const float *b, long idx, long count)
     return (idx >= 0 && idx < count) ? b[idx] : 0.0f;
 }
 
-/* GPU_kernel.cu:43-62 sample_buffer: no index clamping, flat index arithmetic kept;
- * reads outside the allocation return 0 (header, arithmetic contract). */
+/* GPU_kernel.cu:43-62 sample_buffer: no index clamping, flat index arithmetic kept (a corner one past a
+ * row/plane wraps into the next one); reads outside the allocation return 0 and a cell whose base corner
+ * has a negative flat index -- memory before the array in the reference: undefined -- reads all zeros
+ * (header, arithmetic contract). */
 static inline float sample(const float *b, int nx, int ny, int nz, float h, f3 off, f3 pos)
 {
     float sx = pos.x - off.x, sy = pos.y - off.y, sz = pos.z - off.z;
@@ -82,6 +84,7 @@ static inline float sample(const float *b, int nx, int ny, int nz, float h, f3 o
     float fx = qx - (float)i, fy = qy - (float)j, fz = qz - (float)k;
     long sj = nx, sk = (long)nx * ny, count = (long)nx * ny * nz;
     long base = (long)i + sj * j + sk * (k - KOFF);
+    if (base < 0) base = count;                 /* every corner out of range */
     return trilerp(ld(b, base, count),           ld(b, base + 1, count),
                    ld(b, base + sj, count),      ld(b, base + sj + 1, count),
                    ld(b, base + sk, count),      ld(b, base + sk + 1, count),
@@ -570,6 +573,51 @@ void orc_semilag(float *field, const float *field_src,
             }
 }
 
+/* gpu_clamp_extrema / clamp_extrema_kernel (GPU_kernel.cu:892-950), the MacCormack limiter of the
+ * reflection scheme, CORRECTED.  As written the reference kernel (a) adds the stagger offset
+ * with the wrong sign, (b) uses the departure point's WORLD coordinates as grid indices (:913-915) and
+ * (c) tests and overwrites fieldTemp at that bogus index from every thread at once -- its output is
+ * undefined.  What the code evidently means, and what is built here:
+ *   node x = (i - o) h; departure point by the kernel's own midpoint rule, x_d = x - dt u(x - dt/2 u(x)),
+ *   clamped to [h, (n-1)h] like every other trace; the 8 values of `field` around x_d give min/max; if
+ *   fieldTemp at THIS node lies outside, it is replaced by the trilinear value of `field` at x_d.
+ * ni, nj, nk are BUFFER dims (cells + dim), o = (ox, oy, oz) = 0.5 along the staggered axis. */
+void orc_clamp_extrema(const float *field, float *field_temp, const float *u, const float *v, const float *w,
+                       int ni, int nj, int nk, int dimx, int dimy, int dimz, float ox, float oy, float oz,
+                       float h, float dt)
+{
+    const int ci = ni - dimx, cj = nj - dimy, ck = nk - dimz;
+    const f3 org = mk3(-ox * h, -oy * h, -oz * h);
+    const f3 lo = mk3(h, h, h), hi = mk3((float)ci * h - h, (float)cj * h - h, (float)ck * h - h);
+    const float halfdt = 0.5f * dt;
+    const long sj = ni, sk = (long)ni * nj, count = (long)ni * nj * nk;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nk; k++)
+        for (int j = 0; j < nj; j++)
+            for (int i = 0; i < ni; i++) {
+                f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+                f3 vel = get_velocity(u, v, w, h, ci, cj, ck, pt);
+                f3 px = mk3(pt.x - vel.x * halfdt, pt.y - vel.y * halfdt, pt.z - vel.z * halfdt);
+                vel = get_velocity(u, v, w, h, ci, cj, ck, px);
+                px = clamp3(mk3(pt.x - vel.x * dt, pt.y - vel.y * dt, pt.z - vel.z * dt), lo, hi);
+                float qx = (px.x - org.x) / h, qy = (px.y - org.y) / h, qz = (px.z - org.z) / h;
+                int gi = (int)floorf(qx), gj = (int)floorf(qy), gk = (int)floorf(qz);
+                float cx = qx - (float)gi, cy = qy - (float)gj, cz = qz - (float)gk;
+                long base = (long)gi + sj * gj + sk * gk;
+                if (base < 0) base = count;
+                float v0 = ld(field, base, count),           v1 = ld(field, base + 1, count);
+                float v2 = ld(field, base + sj, count),      v3 = ld(field, base + sj + 1, count);
+                float v4 = ld(field, base + sk, count),      v5 = ld(field, base + sk + 1, count);
+                float v6 = ld(field, base + sk + sj, count), v7 = ld(field, base + sk + sj + 1, count);
+                float mn = fminf(v0, fminf(v1, fminf(v2, fminf(v3, fminf(v4, fminf(v5, fminf(v6, v7)))))));
+                float mx = fmaxf(v0, fmaxf(v1, fmaxf(v2, fmaxf(v3, fmaxf(v4, fmaxf(v5, fmaxf(v6, v7)))))));
+                long id = (long)i + sj * j + sk * k;
+                float t = field_temp[id];
+                if (t < mn || t > mx)
+                    field_temp[id] = trilerp(v0, v1, v2, v3, v4, v5, v6, v7, cx, cy, cz);
+            }
+}
+
 /* GPU_kernel.cu:560-565 + :729-734 (exactly `number` elements; the reference's
  * rounded-up grid overrun is not replicated) */
 void orc_add(float *f1, const float *f2, float coeff, int number)
@@ -834,6 +882,7 @@ struct orc_solver {
     /* 0: re-initialise both map sets every frame (the GPU solver's `if (1)`, BimocqGPUSolver.cpp:218-229);
      * 1: distortion-driven, the CPU solver's thresholds (BimocqSolver.cpp:165-185) */
     int reinit_policy;
+    int scheme;                 /* enum Scheme (BimocqSolver.h:29): 0 BIMOCQ, 3 MAC_REFLECTION */
     float max_v, last_vel_distortion, last_scalar_distortion;
     int vel_reinits, scalar_reinits;
     double *mg_div, *mg_p, *mg_dir, *mg_res, *mg_t0, *mg_t1, *mg_result;
@@ -931,6 +980,7 @@ void orc_solver_set_option(orc_solver *s, int option, int value)
 {
     if (option == 1) s->keep_dmc_border = value != 0;
     if (option == 2) s->reinit_policy = value;
+    if (option == 3) s->scheme = value;
 }
 
 int orc_solver_reinit_counts(const orc_solver *s, int which) { return which ? s->scalar_reinits : s->vel_reinits; }
@@ -1032,11 +1082,112 @@ static void advect_scalar(orc_solver *s, float *f, float *finit, const float *fp
                             s->h, s->ni, s->nj, s->nk, 0, b);
 }
 
+/* BimocqGPUSolver::projection (:406-467) */
+static void solver_project(orc_solver *s)
+{
+    const int ni = s->ni, nj = s->nj, nk = s->nk;
+    const size_t bs = s->n * sizeof(float);
+    if (s->projection_kind == 1) {
+        /* :443-446 projectionMultiGrid(U, V, W, div, p, dir, residual, temp0, temp1, tempResult, levels, ...) */
+        orc_multi_grid_conjugate_gradient(s->U, s->V, s->W, s->mg_div, s->mg_p, s->mg_dir, s->mg_res, s->mg_t0, s->mg_t1,
+                                          s->mg_result, s->mg_level, s->mg_levels, s->mg_iters, (double)s->halfrdx);
+    } else {
+        /* GPU_Advection.h:602-608 zeroes div, p, p_temp first */
+        memset(s->div, 0, bs); memset(s->p, 0, bs); memset(s->pt, 0, bs);
+        orc_projection_jacobi(s->U, s->V, s->W, s->div, s->p, s->pt, NULL, ni, nj, nk,
+                              s->jacobi_iters, s->halfrdx, -1.f, (float)(1.0 / 6.0));
+    }
+}
+
+static void solver_sources(orc_solver *s, int framenum, float dt_buoyancy, float dt_diffuse, int emit)
+{
+    const int ni = s->ni, nj = s->nj, nk = s->nk;
+    const float h = s->h;
+    if (emit)
+        for (int e = 0; e < s->n_em; e++)                                /* :376-392 */
+            if (framenum < s->em[e].emit_frames)
+                orc_emit_smoke(s->U, s->V, s->W, s->rho, s->T, h, ni, nj, nk,
+                               s->em[e].cx, s->em[e].cy, s->em[e].cz, s->em[e].radius,
+                               s->em[e].density, s->em[e].temperature, s->em[e].emiter);
+    orc_add_buoyancy(s->V, s->rho, s->T, ni, nj, nk, s->alpha, s->beta, dt_buoyancy);  /* :394-397 */
+    if (s->viscosity != 0.f) {                                          /* :167-172 / :286-291 incl. the aliasing of Q7 */
+        float coef = s->viscosity * (dt_diffuse / (h * h));             /* :401 */
+        orc_diffuse_field(s->U, s->Ut, s->Su, ni + 1, nj, nk, 20, coef);
+        orc_diffuse_field(s->V, s->Vt, s->Sv, ni, nj + 1, nk, 20, coef);
+        orc_diffuse_field(s->W, s->Wt, s->Sw, ni, nj, nk + 1, 20, coef);
+    }
+}
+
+/* gpuMapper::semilagAdvectField / semilagAdvectVelocity (GPU_Advection.h:530-551): output cleared first */
+static void semilag_scalar(orc_solver *s, float *dst, const float *src, float cfldt, float dt)
+{
+    memset(dst, 0, s->n * sizeof(float));
+    orc_semilag(dst, src, s->U, s->V, s->W, 0, 0, 0, s->h, s->ni, s->nj, s->nk, cfldt, dt);
+}
+static void semilag_velocity(orc_solver *s, float *uo, float *vo, float *wo, const float *us, const float *vs, const float *ws,
+                             float cfldt, float dt)
+{
+    memset(uo, 0, s->nu * sizeof(float)); memset(vo, 0, s->nv * sizeof(float)); memset(wo, 0, s->nw * sizeof(float));
+    orc_semilag(uo, us, s->U, s->V, s->W, 1, 0, 0, s->h, s->ni, s->nj, s->nk, cfldt, dt);
+    orc_semilag(vo, vs, s->U, s->V, s->W, 0, 1, 0, s->h, s->ni, s->nj, s->nk, cfldt, dt);
+    orc_semilag(wo, ws, s->U, s->V, s->W, 0, 0, 1, s->h, s->ni, s->nj, s->nk, cfldt, dt);
+}
+
+/* BimocqGPUSolver::advanceReflection (:232-337) with the corrected limiter (orc_clamp_extrema).  Buffer
+ * roles as in the reference: DensityTemp/TemperatureTemp = rhot/Tt, TempSrc* = Su/Sv/Sw, d*Proj = dUp.. */
+static void advance_reflection(orc_solver *s, int framenum, float dt)
+{
+    const int ni = s->ni, nj = s->nj, nk = s->nk;
+    const float h = s->h;
+    const size_t bu = s->nu * sizeof(float), bv = s->nv * sizeof(float), bw = s->nw * sizeof(float), bs = s->n * sizeof(float);
+    s->max_v = orc_max_abs3(s->U, s->V, s->W, ni, nj, nk);
+    const float cfldt = h / s->max_v;
+    s->last_cfldt = cfldt;
+
+    float *scal[2] = { s->rho, s->T }, *tmp[2] = { s->rhot, s->Tt };
+    for (int a = 0; a < 2; a++) {                                       /* :237-263 MacCormack on rho, T */
+        semilag_scalar(s, tmp[a], scal[a], cfldt, -dt);
+        semilag_scalar(s, s->Su, tmp[a], cfldt, dt);
+        orc_add(tmp[a], s->Su, -0.5f, (int)s->n);
+        orc_add(tmp[a], scal[a], 0.5f, (int)s->n);
+        orc_clamp_extrema(scal[a], tmp[a], s->U, s->V, s->W, ni, nj, nk, 0, 0, 0, 0.f, 0.f, 0.f, h, dt);
+        memcpy(scal[a], tmp[a], bs);
+    }
+    {                                                                   /* :267-287 velocity, half a step */
+        semilag_velocity(s, s->Ut, s->Vt, s->Wt, s->U, s->V, s->W, cfldt, -0.5f * dt);
+        semilag_velocity(s, s->Su, s->Sv, s->Sw, s->Ut, s->Vt, s->Wt, cfldt, 0.5f * dt);
+        orc_add(s->Ut, s->Su, -0.5f, (int)s->nu); orc_add(s->Vt, s->Sv, -0.5f, (int)s->nv); orc_add(s->Wt, s->Sw, -0.5f, (int)s->nw);
+        orc_add(s->Ut, s->U, 0.5f, (int)s->nu);   orc_add(s->Vt, s->V, 0.5f, (int)s->nv);   orc_add(s->Wt, s->W, 0.5f, (int)s->nw);
+        orc_clamp_extrema(s->U, s->Ut, s->U, s->V, s->W, ni + 1, nj, nk, 1, 0, 0, 0.5f, 0.f, 0.f, h, 0.5f * dt);
+        orc_clamp_extrema(s->V, s->Vt, s->U, s->V, s->W, ni, nj + 1, nk, 0, 1, 0, 0.f, 0.5f, 0.f, h, 0.5f * dt);
+        orc_clamp_extrema(s->W, s->Wt, s->U, s->V, s->W, ni, nj, nk + 1, 0, 0, 1, 0.f, 0.f, 0.5f, h, 0.5f * dt);
+        memcpy(s->U, s->Ut, bu); memcpy(s->V, s->Vt, bv); memcpy(s->W, s->Wt, bw);
+    }
+    solver_sources(s, framenum, 0.5f * dt, 0.5f * dt, 1);               /* :289-297 */
+    memcpy(s->Ut, s->U, bu); memcpy(s->Vt, s->V, bv); memcpy(s->Wt, s->W, bw);     /* :299-303 */
+    solver_project(s);                                                  /* :305 */
+    orc_mad(s->dUp, s->U, s->Ut, 2.f, -1.f, (int)s->nu);                /* :307-309 reflection: 2 u_proj - u */
+    orc_mad(s->dVp, s->V, s->Vt, 2.f, -1.f, (int)s->nv);
+    orc_mad(s->dWp, s->W, s->Wt, 2.f, -1.f, (int)s->nw);
+    semilag_velocity(s, s->Ut, s->Vt, s->Wt, s->dUp, s->dVp, s->dWp, cfldt, -0.5f * dt);      /* :311 */
+    semilag_velocity(s, s->Su, s->Sv, s->Sw, s->Ut, s->Vt, s->Wt, cfldt, 0.5f * dt);          /* :313 */
+    orc_add(s->Ut, s->Su, -0.5f, (int)s->nu); orc_add(s->Vt, s->Sv, -0.5f, (int)s->nv); orc_add(s->Wt, s->Sw, -0.5f, (int)s->nw);
+    orc_add(s->Ut, s->dUp, 0.5f, (int)s->nu); orc_add(s->Vt, s->dVp, 0.5f, (int)s->nv); orc_add(s->Wt, s->dWp, 0.5f, (int)s->nw);
+    /* :323-325: the limiter is given VelocityU/V/W as the source field (not d*Proj, which was advected) */
+    orc_clamp_extrema(s->U, s->Ut, s->U, s->V, s->W, ni + 1, nj, nk, 1, 0, 0, 0.5f, 0.f, 0.f, h, 0.5f * dt);
+    orc_clamp_extrema(s->V, s->Vt, s->U, s->V, s->W, ni, nj + 1, nk, 0, 1, 0, 0.f, 0.5f, 0.f, h, 0.5f * dt);
+    orc_clamp_extrema(s->W, s->Wt, s->U, s->V, s->W, ni, nj, nk + 1, 0, 0, 1, 0.f, 0.f, 0.5f, h, 0.5f * dt);
+    memcpy(s->U, s->Ut, bu); memcpy(s->V, s->Vt, bv); memcpy(s->W, s->Wt, bw);
+    solver_sources(s, framenum, 0.5f * dt, 0.5f * dt, 0);               /* :330-337 (no emission the second time) */
+    solver_project(s);
+}
+
 /* BimocqGPUSolver.cpp:129-230 advanceBimocq with the Jacobi projection branch
  * (:408-410; div/p/p_temp get dedicated buffers -- the reference lends it DensityTemp,
  * TemperatureTemp and TempSrcV, all dead at that point). */
 void orc_solver_advance(orc_solver *s, int framenum, float dt)
 {
+    if (s->scheme == 3) { advance_reflection(s, framenum, dt); return; }        /* enum Scheme: MAC_REFLECTION */
     const int ni = s->ni, nj = s->nj, nk = s->nk;
     const float h = s->h;
     size_t bu = s->nu * sizeof(float), bv = s->nv * sizeof(float), bw = s->nw * sizeof(float), bs = s->n * sizeof(float);
@@ -1072,35 +1223,14 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
      * sources act, so that rho - rhoTemp is what emission added (the GPU solver takes them after) */
     if (policy == 1) { memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs); }
 
-    for (int e = 0; e < s->n_em; e++)                                    /* :376-392 */
-        if (framenum < s->em[e].emit_frames)
-            orc_emit_smoke(s->U, s->V, s->W, s->rho, s->T, h, ni, nj, nk,
-                           s->em[e].cx, s->em[e].cy, s->em[e].cz, s->em[e].radius,
-                           s->em[e].density, s->em[e].temperature, s->em[e].emiter);
-    orc_add_buoyancy(s->V, s->rho, s->T, ni, nj, nk, s->alpha, s->beta, dt);  /* :394-397 */
-
-    if (s->viscosity != 0.f) {                                          /* :167-172 incl. the aliasing of Q7 */
-        float coef = s->viscosity * (dt / (h * h));                     /* :401 */
-        orc_diffuse_field(s->U, s->Ut, s->Su, ni + 1, nj, nk, 20, coef);
-        orc_diffuse_field(s->V, s->Vt, s->Sv, ni, nj + 1, nk, 20, coef);
-        orc_diffuse_field(s->W, s->Wt, s->Sw, ni, nj, nk + 1, 20, coef);
-    }
+    solver_sources(s, framenum, dt, dt, 1);                            /* :164-172 */
 
     orc_add_field(s->dUe, s->U, s->Ut, -1.f, (int)s->nu);               /* :175-177 */
     orc_add_field(s->dVe, s->V, s->Vt, -1.f, (int)s->nv);
     orc_add_field(s->dWe, s->W, s->Wt, -1.f, (int)s->nw);
     memcpy(s->Ut, s->U, bu); memcpy(s->Vt, s->V, bv); memcpy(s->Wt, s->W, bw);   /* :179-181 */
 
-    /* projection(): GPU_Advection.h:602-608 zeroes div, p, p_temp first */
-    if (s->projection_kind == 1) {
-        /* :443-446 projectionMultiGrid(U, V, W, div, p, dir, residual, temp0, temp1, tempResult, levels, ...) */
-        orc_multi_grid_conjugate_gradient(s->U, s->V, s->W, s->mg_div, s->mg_p, s->mg_dir, s->mg_res, s->mg_t0, s->mg_t1,
-                                          s->mg_result, s->mg_level, s->mg_levels, s->mg_iters, (double)s->halfrdx);
-    } else {
-        memset(s->div, 0, bs); memset(s->p, 0, bs); memset(s->pt, 0, bs);
-        orc_projection_jacobi(s->U, s->V, s->W, s->div, s->p, s->pt, NULL, ni, nj, nk,
-                              s->jacobi_iters, s->halfrdx, -1.f, (float)(1.0 / 6.0));
-    }
+    solver_project(s);
 
     if (policy == 0) { memcpy(s->rhot, s->rho, bs); memcpy(s->Tt, s->T, bs); }   /* :185-186 */
     memcpy(s->dUp, s->U, bu); memcpy(s->dVp, s->V, bv); memcpy(s->dWp, s->W, bw);  /* :188-190 */

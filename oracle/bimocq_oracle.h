@@ -97,6 +97,9 @@ void orc_compensate_error_field(const float *u, const float *du, float *u_src,
                                 const float *fx, const float *fy, const float *fz,
                                 float h, int ni, int nj, int nk, int is_point);
 void orc_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
+void orc_clamp_extrema(const float *field, float *field_temp, const float *u, const float *v, const float *w,
+                       int ni, int nj, int nk, int dimx, int dimy, int dimz, float ox, float oy, float oz,
+                       float h, float dt);
 void orc_semilag(float *field, const float *field_src,
                  const float *u, const float *v, const float *w,
                  int dim_x, int dim_y, int dim_z,

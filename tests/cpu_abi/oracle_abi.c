@@ -102,10 +102,6 @@ void gpu_add_field(float *out, float *f1, float *f2, float coeff, int number) { 
 void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *pt, float *dbg,
                            int ni, int nj, int nk, int iter, float halfrdx, float alpha, float beta)
 { orc_projection_jacobi(u, v, w, div, p, pt, g_opt[FL_OPT_RESIDUAL_STRIDE] > 0 ? dbg : NULL, ni, nj, nk, iter, halfrdx, alpha, beta); }
-void gpu_clamp_extrema(float *a, float *b, float *c, float *d, float *e, int f, int g, int h, int i, int j, int k,
-                       float l, float m, float n, float o, float p)
-{ (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m; (void)n; (void)o; (void)p;
-  latch(FL_ERR_UNSUPPORTED, "gpu_clamp_extrema"); }
 void gpu_mad(float *out, float *f1, float *f2, float c1, float c2, int number) { orc_mad(out, f1, f2, c1, c2, number); }
 void gpu_conjugate_gradient(float *a, float *b, float *c, float *d, float *e, float *f, float *g, float *h,
                             int i, int j, int k, int l, float m)
@@ -191,6 +187,9 @@ void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
 { orc_mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter); }
+void gpu_clamp_extrema(float *field, float *ft, float *u, float *v, float *w, int ni, int nj, int nk,
+                       int dx, int dy, int dz, float ox, float oy, float oz, float h, float dt)
+{ orc_clamp_extrema(field, ft, u, v, w, ni, nj, nk, dx, dy, dz, ox, oy, oz, h, dt); }
 float gpu_max_field(const float *field, size_t count)
 {
     float m = 0.f;

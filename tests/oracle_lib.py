@@ -82,6 +82,7 @@ _SIGS = {
     "orc_mg_smooth": (None, [DP, DP, DP, C.c_double, C.c_double, c_i, c_i, c_i, c_i]),
     "orc_mg_restrict": (None, [DP, DP] + [c_i] * 6),
     "orc_mg_prolong": (None, [DP, DP] + [c_i] * 6),
+    "orc_clamp_extrema": (None, [FP] * 5 + [c_i] * 6 + [c_f] * 5),
     "orc_semilag": (None, [FP] * 5 + [c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_f]),
     "orc_emit_smoke": (None, [FP] * 5 + [c_f, c_i, c_i, c_i] + [c_f] * 7),
     "orc_add_buoyancy": (None, [FP] * 3 + [c_i, c_i, c_i, c_f, c_f, c_f]),

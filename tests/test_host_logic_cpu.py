@@ -27,13 +27,15 @@ def cpu_host():
     return lib
 
 
-def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps, kind=0, policy=0):
+def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt_cells, steps, kind=0, policy=0, scheme=0):
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     ni, nj, nk = dims
     o = OracleSolver(ni, nj, nk, L, visc, blend)
     o.set_smoke(drop, rise, emitters)
     o.set_projection(iters, hr, kind)
-    s = BimocqGPUSolver(ni, nj, nk, L, visc, blend, lib=cpu_host, errlib=cpu_host)
+    if scheme:
+        o.set_option(3, scheme)
+    s = BimocqGPUSolver(ni, nj, nk, L, visc, blend, lib=cpu_host, errlib=cpu_host, scheme=scheme)
     s.setSmoke(drop, rise, emitters)
     s.setProjection(iters, hr, kind)
     if policy:
@@ -47,7 +49,9 @@ def run_pair(cpu_host, dims, L, visc, blend, emitters, drop, rise, iters, hr, dt
         for name in FIELDS:
             a, b = o.field(name), s.field(name)
             assert F.same(a, b), (f, name, F.maxdiff(a, b))
-    if policy == 0:
+    if scheme:
+        pass
+    elif policy == 0:
         assert s.reinit_count == steps
     else:
         assert s.reinitCounts() == o.reinit_counts()
@@ -69,6 +73,15 @@ def test_multigrid_cg_projection_mode(cpu_host):
     ho, hs = o.mg_history(), s.mgHistory()
     assert ho is not None and hs is not None and F.same(ho, hs)
     assert hs[2004] < 1e-2 * hs[2000]               # four outer iterations cut the residual peak 100x
+
+
+def test_reflection_scheme(cpu_host):
+    """MAC_REFLECTION (BimocqGPUSolver.cpp:232-337, the shipped default scheme) with the corrected limiter:
+    host state machine vs the oracle's over 6 steps, viscous so that both diffusion half-steps run"""
+    o, s = run_pair(cpu_host, (24, 20, 16), 0.6, 1e-3, 1.0,
+                    [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 0.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, 0.0, 3)],
+                    0.1, 1.0, 16, 1.0, 1.5, 6, scheme=3)
+    assert np.isfinite(o.field("v")).all() and np.abs(o.field("v")).max() > 1e-2 and o.field("rho").max() > 0.5
 
 
 def test_distortion_driven_reinitialisation(cpu_host):
@@ -124,4 +137,4 @@ def test_output_result_dump(cpu_host, tmp_path):
 
 def test_create_rejects_bad_arguments(cpu_host):
     assert not cpu_host.bq_solver_create(0, 4, 16, 16, 1.0, 0.0, 1.0, 0)       # too small
-    assert not cpu_host.bq_solver_create(0, 16, 16, 16, 1.0, 0.0, 1.0, 3)      # MAC_REFLECTION: out of scope
+    assert not cpu_host.bq_solver_create(0, 16, 16, 16, 1.0, 0.0, 1.0, 1)      # SEMILAG: the GPU solver has no such scheme
