@@ -11,6 +11,11 @@ CSRC     := $(PKG)/csrc
 OBJDIR   := build/obj
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
 RCCL_LIB ?= -ldl    # RCCL itself is dlopen'ed by bq_halo.hip on first multi-GPU use
+# make HAVE_OPENVDB=1: outputResult additionally writes real .vdb files (needs OpenVDB; absent in this image)
+ifeq ($(HAVE_OPENVDB),1)
+VDB_FLAGS := -DHAVE_OPENVDB
+VDB_LIBS  := -lopenvdb -ltbb
+endif
 
 KERNEL_SRCS := $(sort $(wildcard $(CSRC)/*.hip))
 KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(KERNEL_SRCS))
@@ -28,11 +33,11 @@ $(PKG)/libbimocq_hip.so: $(KERNEL_OBJS)
 
 $(OBJDIR)/host_%.o: $(CSRC)/host/%.cpp $(wildcard $(CSRC)/host/*.hpp) include/bimocq_gpu.h include/bimocq_solver.h
 	@mkdir -p $(OBJDIR)
-	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -c $< -o $@
+	g++ -O2 -std=c++17 -fPIC -pthread -Wall -Wextra -Iinclude $(VDB_FLAGS) -c $< -o $@
 
 # the host solver only speaks the C-ABI: it links against libbimocq_hip.so by name ($$ORIGIN rpath)
 $(PKG)/libbimocq_host.so: $(HOST_OBJS) $(PKG)/libbimocq_hip.so
-	g++ -shared -fPIC -o $@ $(HOST_OBJS) -L$(PKG) -lbimocq_hip -Wl,-rpath,'$$ORIGIN'
+	g++ -shared -fPIC -pthread -o $@ $(HOST_OBJS) -L$(PKG) -lbimocq_hip $(VDB_LIBS) -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -49,6 +49,10 @@ HIP_SIGS = {
     "fl_memcpy_d2h": (None, [VP, VP, C.c_size_t]),
     "fl_memcpy_d2d": (None, [VP, VP, C.c_size_t]),
     "fl_sync": (None, []),
+    "fl_malloc_host": (VP, [C.c_size_t]),
+    "fl_free_host": (None, [VP]),
+    "fl_download_begin": (VP, [VP, VP, C.c_size_t]),
+    "fl_download_wait": (c_i, [VP]),
     "fl_event_create": (VP, []),
     "fl_event_record": (None, [VP]),
     "fl_event_elapsed_ms": (c_f, [VP, VP]),

@@ -12,6 +12,7 @@ struct Runtime {
     int         device = -1;
     hipStream_t compute = nullptr;      // every operator launches here
     hipStream_t halo = nullptr;         // ghost-plane exchange (multi-GPU), overlapped with interior work
+    hipStream_t copy = nullptr;         // device -> host downloads of the dump path, overlapped with the next step
     int         err = FL_OK;
     char        err_text[256] = {0};
     int         opt_residual_stride = 0;

@@ -79,6 +79,7 @@ int fl_init(int device)
     }
     if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.compute, hipStreamNonBlocking))) return FL_ERR_HIP;
     if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.halo, hipStreamNonBlocking))) return FL_ERR_HIP;
+    if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.copy, hipStreamNonBlocking))) return FL_ERR_HIP;
     g_rt.device = device;
     g_rt.ready = true;
     return FL_OK;
@@ -89,10 +90,13 @@ void fl_shutdown(void)
     if (!g_rt.ready) return;
     (void)hipStreamSynchronize(g_rt.compute);
     (void)hipStreamSynchronize(g_rt.halo);
+    (void)hipStreamSynchronize(g_rt.copy);
     if (g_rt.scratch) (void)hipFree(g_rt.scratch);
     if (g_rt.pinned) (void)hipHostFree(g_rt.pinned);
     (void)hipStreamDestroy(g_rt.compute);
     (void)hipStreamDestroy(g_rt.halo);
+    (void)hipStreamDestroy(g_rt.copy);
+    g_rt.copy = nullptr;
     g_rt.scratch = nullptr; g_rt.scratch_bytes = 0;
     g_rt.pinned = nullptr; g_rt.pinned_bytes = 0;
     g_rt.compute = nullptr; g_rt.halo = nullptr;
@@ -152,6 +156,45 @@ void fl_sync(void)
     if (!g_rt.ready) return;
     BQ_HIP(hipStreamSynchronize(g_rt.compute));
     BQ_HIP(hipStreamSynchronize(g_rt.halo));
+}
+
+// ---- asynchronous downloads (the dump path) ---------------------------------------
+void *fl_malloc_host(size_t bytes)
+{
+    if (!bq::ensure_ready("fl_malloc_host")) return nullptr;
+    void *p = nullptr;
+    if (!BQ_HIP(hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault))) return nullptr;
+    return p;
+}
+
+void fl_free_host(void *p)
+{
+    if (p) BQ_HIP(hipHostFree(p));
+}
+
+// Copy `bytes` device -> pinned host on the copy stream, ordered after everything queued on the compute
+// stream so far; later compute work does not wait for it.  Returns a ticket for fl_download_wait().
+void *fl_download_begin(void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (!bq::ensure_ready("fl_download_begin")) return nullptr;
+    if (!host_dst || !dev_src) { bq::latch(FL_ERR_BAD_ARGUMENT, "fl_download_begin", "null pointer"); return nullptr; }
+    hipEvent_t ready = nullptr, done = nullptr;
+    if (!BQ_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming)) || !BQ_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming))) return nullptr;
+    bool ok = BQ_HIP(hipEventRecord(ready, g_rt.compute)) && BQ_HIP(hipStreamWaitEvent(g_rt.copy, ready, 0));
+    ok = ok && BQ_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, g_rt.copy));
+    ok = ok && BQ_HIP(hipEventRecord(done, g_rt.copy));
+    (void)hipEventDestroy(ready);
+    if (!ok) { (void)hipEventDestroy(done); return nullptr; }
+    return (void *)done;
+}
+
+// Block the calling host thread (any thread) until the download has landed; releases the ticket.
+int fl_download_wait(void *ticket)
+{
+    if (!ticket) return FL_ERR_BAD_ARGUMENT;
+    const bool ok = BQ_HIP(hipEventSynchronize((hipEvent_t)ticket));
+    (void)hipEventDestroy((hipEvent_t)ticket);
+    return ok ? FL_OK : FL_ERR_HIP;
 }
 
 void *fl_event_create(void)

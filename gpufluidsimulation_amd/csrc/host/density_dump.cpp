@@ -4,9 +4,11 @@
 // in k, j, i order; keep |value| where it exceeds 1e-4 (a float compared against the double literal);
 // one grid named "density", class fog volume, linear transform = voxel size; file
 // <path>/density_render_%04d.<ext> numbered frame (the caller passes frame + 1).
-// OpenVDB is not available in this image, so the container is a dependency-free sparse
-// format ("BQDENS01", little endian) that carries exactly the same information; a z-slab rank
+// OpenVDB is not available in this image, so the default container is a dependency-free
+// sparse format ("BQDENS01", little endian) that carries exactly the same information; a z-slab rank
 // writes its own planes with k_offset so that eight ranks' files concatenate to the global grid.
+// Built with -DHAVE_OPENVDB (make HAVE_OPENVDB=1; needs the OpenVDB headers and library, never compiled
+// in this image) the same voxels go into a real .vdb as well (write_density_vdb below).
 #include "fluid_solver.hpp"
 
 #include <cerrno>
@@ -15,6 +17,9 @@
 #include <cstdio>
 #include <cstring>
 #include <sys/stat.h>
+#ifdef HAVE_OPENVDB
+#include <openvdb/openvdb.h>
+#endif
 
 namespace bqhost {
 
@@ -85,7 +90,50 @@ long write_density_dump(unsigned frame, const std::string &filepath, float voxel
     hd.count = total;
     if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&hd, sizeof hd, 1, f) != 1) { fclose(f); return -1; }
     fclose(f);
+#ifdef HAVE_OPENVDB
+    if (write_density_vdb(frame, filepath, voxel_size, density, nx, ny, nz, k_offset, nz_global) < 0) return -1;
+#endif
     return (long)total;
 }
+
+#ifdef HAVE_OPENVDB
+// The real thing, for boxes that have OpenVDB: <path>/density_render_%04d.vdb (slab ranks:
+// .k%05d.vdb) holding one float grid "density" -- fog volume, linear transform of the voxel size, active
+// voxels = the cells whose |rho| exceeds 1e-4, stored value |rho|, global (i, j, k) coordinates.
+long write_density_vdb(unsigned frame, const std::string &filepath, float voxel_size,
+                       const float *density, int nx, int ny, int nz, int k_offset, int nz_global)
+{
+    static const bool initialised = (openvdb::initialize(), true);
+    (void)initialised;
+    auto grid = openvdb::FloatGrid::create();
+    grid->setName("density");
+    grid->setGridClass(openvdb::GRID_FOG_VOLUME);
+    grid->setTransform(openvdb::math::Transform::createLinearTransform(voxel_size));
+    auto acc = grid->getAccessor();
+    long total = 0;
+    const size_t plane = (size_t)nx * ny;
+    for (int k = 0; k < nz; k++)
+        for (int j = 0; j < ny; j++) {
+            const float *row = density + plane * k + (size_t)nx * j;
+            for (int i = 0; i < nx; i++) {
+                const float a = std::fabs(row[i]);
+                if ((double)a > 1e-4) { acc.setValue(openvdb::Coord(i, j, k + k_offset), a); total++; }
+            }
+        }
+    char name[512];
+    if (k_offset == 0 && nz == nz_global)
+        snprintf(name, sizeof name, "%s/density_render_%04u.vdb", filepath.c_str(), frame);
+    else
+        snprintf(name, sizeof name, "%s/density_render_%04u.k%05d.vdb", filepath.c_str(), frame, k_offset);
+    try {
+        openvdb::io::File out(name);
+        out.write({ grid });
+        out.close();
+    } catch (const std::exception &) {
+        return -1;
+    }
+    return total;
+}
+#endif
 
 } // namespace bqhost

@@ -488,6 +488,39 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     trace_stage(*this, "reinit", framenum);
 }
 
+bool BimocqGPUSolver::outputResultAsync(unsigned frame, const std::string &filepath)
+{
+    waitOutput();
+    if (!dump_host_) dump_host_ = static_cast<float *>(fl_malloc_host(g.n() * sizeof(float)));
+    if (!dump_host_) return false;
+    void *ticket = fl_download_begin(dump_host_, Density.get(), g.n() * sizeof(float));
+    if (!ticket) return false;
+    const SlabCtx sl = GpuSolver->slab;
+    const GridDims gd = g;
+    const float h = CellSize;
+    float *host = dump_host_;
+    dump_thread_ = std::thread([this, ticket, frame, filepath, sl, gd, h, host] {
+        if (fl_download_wait(ticket) != FL_OK) { dump_result_ = -1; return; }
+        if (filepath.empty()) { dump_result_ = 0; return; }
+        if (!sl.on) { dump_result_ = write_density_dump(frame + 1, filepath, h, host, gd.ni, gd.nj, gd.nk, 0, gd.nk); return; }
+        const size_t plane = (size_t)gd.ni * gd.nj;
+        dump_result_ = write_density_dump(frame + 1, filepath, h, host + plane * sl.G, gd.ni, gd.nj, sl.own1 - sl.own0, sl.own0, sl.nkg);
+    });
+    return true;
+}
+
+long BimocqGPUSolver::waitOutput()
+{
+    if (dump_thread_.joinable()) dump_thread_.join();
+    return dump_result_;
+}
+
+BimocqGPUSolver::~BimocqGPUSolver()
+{
+    waitOutput();
+    if (dump_host_) fl_free_host(dump_host_);
+}
+
 // :536-543.  A slab rank downloads its local planes and writes the planes it owns.
 long BimocqGPUSolver::outputResult(unsigned frame, const std::string &filepath)
 {

@@ -7,6 +7,7 @@
 // `FluidSolver` (the name BASELINE.json uses) is an alias with step()/dump() spellings.
 #pragma once
 #include <string>
+#include <thread>
 #include <vector>
 #include "bimocq_solver.h"
 #include "mapping.hpp"
@@ -43,6 +44,13 @@ public:
     void scalarReinitialize();
     void setSmoke(float drop, float raise, const std::vector<Emitter> &emitters);
     long outputResult(unsigned frame, const std::string &filepath);
+    // The same dump without stalling the simulation: the density is downloaded into pinned
+    // memory on the copy stream, ordered after the step that produced it, and a worker thread writes the file
+    // while the next advance() runs.  At most one dump is in flight: a second call first waits for the
+    // previous one.  waitOutput() returns that dump's voxel count (or -1) and leaves nothing in flight.
+    bool outputResultAsync(unsigned frame, const std::string &filepath);
+    long waitOutput();
+    ~BimocqGPUSolver();
 
     // FluidSolver spellings
     void step(int framenum, float dt) { advance(framenum, dt); }
@@ -97,6 +105,9 @@ public:
 
 private:
     bool ok_ = false;
+    float *dump_host_ = nullptr;        // pinned staging buffer of the asynchronous dump
+    std::thread dump_thread_;
+    long dump_result_ = 0;
 };
 
 using FluidSolver = BimocqGPUSolver;
@@ -105,5 +116,9 @@ using FluidSolver = BimocqGPUSolver;
 // number of voxels written or -1.  Defined in density_dump.cpp.
 long write_density_dump(unsigned frame, const std::string &filepath, float voxel_size,
                         const float *density, int nx, int ny, int nz, int k_offset, int nz_global);
+#ifdef HAVE_OPENVDB
+long write_density_vdb(unsigned frame, const std::string &filepath, float voxel_size,
+                       const float *density, int nx, int ny, int nz, int k_offset, int nz_global);
+#endif
 
 } // namespace bqhost

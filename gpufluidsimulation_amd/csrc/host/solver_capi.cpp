@@ -117,6 +117,17 @@ long bq_solver_output_result(bq_solver *s, unsigned frame, const char *path)
     return s->solver->outputResult(frame, path ? std::string(path) : std::string());
 }
 
+int bq_solver_output_result_async(bq_solver *s, unsigned frame, const char *path)
+{
+    if (!s) return 0;
+    return s->solver->outputResultAsync(frame, path ? std::string(path) : std::string()) ? 1 : 0;
+}
+
+long bq_solver_output_wait(bq_solver *s)
+{
+    return s ? s->solver->waitOutput() : -1;
+}
+
 long bq_solver_download(bq_solver *s, int which, float *host, long capacity)
 {
     if (!s) return 0;

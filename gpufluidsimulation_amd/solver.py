@@ -31,6 +31,8 @@ HOST_SIGS = {
     "bq_solver_set_option": (None, [C.c_void_p, C.c_int, C.c_int]),
     "bq_solver_advance": (None, [C.c_void_p, C.c_int, C.c_float]),
     "bq_solver_output_result": (C.c_long, [C.c_void_p, C.c_uint, C.c_char_p]),
+    "bq_solver_output_result_async": (C.c_int, [C.c_void_p, C.c_uint, C.c_char_p]),
+    "bq_solver_output_wait": (C.c_long, [C.c_void_p]),
     "bq_solver_download": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
     "bq_solver_reinit_counts": (C.c_int, [C.c_void_p, C.c_int]),
     "bq_solver_last_distortion": (C.c_float, [C.c_void_p, C.c_int]),
@@ -130,6 +132,15 @@ class BimocqGPUSolver:
         n = self.lib.bq_solver_output_result(self.s, frame, path.encode() if path else None)
         self._check()
         return n
+
+    def outputResultAsync(self, frame, path=None):
+        """start the dump of the current density without stalling the simulation; waitOutput() joins it"""
+        ok = self.lib.bq_solver_output_result_async(self.s, frame, path.encode() if path else None)
+        self._check()
+        return bool(ok)
+
+    def waitOutput(self):
+        return self.lib.bq_solver_output_wait(self.s)
 
     def field(self, name):
         which = FIELD_IDS[name]

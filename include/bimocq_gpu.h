@@ -219,6 +219,13 @@ void  fl_memcpy_h2d(void *dst, const void *src, size_t bytes);          /* block
 void  fl_memcpy_d2h(void *dst, const void *src, size_t bytes);          /* blocking, after queued work */
 void  fl_memcpy_d2d(void *dst, const void *src, size_t bytes);          /* async on the compute stream */
 void  fl_sync(void);
+/* Asynchronous download for the dump path (replaces the blocking cudaMemcpy of copyDeviceToHost,
+ * GPU_Advection.h:276-299): pinned host memory, a copy on the library's third stream ordered after the
+ * compute work queued so far, and a ticket any host thread can wait on while the next step runs. */
+void *fl_malloc_host(size_t bytes);
+void  fl_free_host(void *p);
+void *fl_download_begin(void *host_dst, const void *dev_src, size_t bytes);
+int   fl_download_wait(void *ticket);
 /* startEventRecord / endEventRecord (GPU_Advection.h:228-247) */
 void *fl_event_create(void);
 void  fl_event_record(void *ev);

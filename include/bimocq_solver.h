@@ -84,6 +84,11 @@ long  bq_solver_download(bq_solver *s, int which, float *host, long capacity);
  * residual per outer iteration at [2000..2000+iters] -- what the reference prints, BimocqGPUSolver.cpp:447-452).
  * Returns the count (0 before the first MGCG projection); copies min(count, capacity). */
 long  bq_solver_mg_history(const bq_solver *s, double *host, long capacity);
+/* The dump without stalling the simulation: asynchronous download on a third stream + a writer thread; the
+ * file is the one bq_solver_output_result would write.  At most one dump in flight (a second call waits for
+ * the first).  _wait returns the voxel count of the last asynchronous dump, or -1. */
+int   bq_solver_output_result_async(bq_solver *s, unsigned frame, const char *path);
+long  bq_solver_output_wait(bq_solver *s);
 float bq_solver_last_cfldt(const bq_solver *s);
 float bq_solver_last_ms(const bq_solver *s);          /* event time of the last advance()        */
 int   bq_solver_reinit_count(const bq_solver *s);

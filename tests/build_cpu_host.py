@@ -29,7 +29,7 @@ def build():
         obj = os.path.join(OUT, os.path.basename(src) + ".o")
         subprocess.check_call([cc, std, *cflags, "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
         objs.append(obj)
-    subprocess.check_call(["g++", "-shared", "-fopenmp", "-o", SO, *objs, "-lm"])
+    subprocess.check_call(["g++", "-shared", "-fopenmp", "-pthread", "-o", SO, *objs, "-lm"])
     return SO
 
 

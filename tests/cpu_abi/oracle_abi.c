@@ -187,6 +187,10 @@ void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
 { orc_mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter); }
+void *fl_malloc_host(size_t bytes) { return calloc(bytes ? bytes : 4, 1); }
+void fl_free_host(void *p) { free(p); }
+void *fl_download_begin(void *host_dst, const void *dev_src, size_t bytes) { memcpy(host_dst, dev_src, bytes); return (void *)1; }
+int fl_download_wait(void *ticket) { return ticket ? FL_OK : FL_ERR_BAD_ARGUMENT; }
 void gpu_clamp_extrema(float *field, float *ft, float *u, float *v, float *w, int ni, int nj, int nk,
                        int dx, int dy, int dz, float ox, float oy, float oz, float h, float dt)
 { orc_clamp_extrema(field, ft, u, v, w, ni, nj, nk, dx, dy, dz, ox, oy, oz, h, dt); }

@@ -220,3 +220,24 @@ def test_reflection_scheme_trajectory():
     run_pair((24, 20, 16), 0.6, 1e-3, 1.0,
              [(0.2, 0.26, 0.21, 0.09, 1.0, 2.0, 0.0, 3), (0.4, 0.27, 0.19, 0.09, 0.5, 1.5, 0.0, 3)],
              0.1, 1.0, 3, 1.0, 1.5, 4, kind=1, scheme=3)
+
+
+def test_async_dump_overlaps_next_step(tmp_path):
+    """the density dump through the copy stream + writer thread equals the blocking dump byte for
+    byte, although the next advance() is queued before the download is waited for"""
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    n = 48
+    s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0)
+    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)]); s.setProjection(30, 0.5)
+    dt = 2.0 / n
+    for f in range(3):
+        s.advance(f, dt)
+    a, b = str(tmp_path / "sync"), str(tmp_path / "async")
+    n_sync = s.outputResult(2, a)
+    assert s.outputResultAsync(2, b)
+    for f in range(3, 6):
+        s.advance(f, dt)                               # runs while the dump is downloaded and written
+    assert s.waitOutput() == n_sync and n_sync > 100
+    fa, fb = os.path.join(a, "density_render_0003.bqd"), os.path.join(b, "density_render_0003.bqd")
+    assert open(fa, "rb").read() == open(fb, "rb").read()
+    s.close()

@@ -135,6 +135,25 @@ def test_output_result_dump(cpu_host, tmp_path):
     assert s.outputResult(1, None) == 0               # path-less call only refreshes host copies
 
 
+def test_async_dump_equals_blocking_dump(cpu_host, tmp_path):
+    """outputResultAsync + waitOutput write the very file outputResult writes, also when the next step is
+    issued before the wait (the dump must show the density of the step it was requested after)"""
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    N = 20
+    s = BimocqGPUSolver(N, N, N, 1.0, 0.0, 1.0, lib=cpu_host, errlib=cpu_host)
+    s.setSmoke(0.0, 1.0, [(0.5, 0.3, 0.5, 0.2, 1.0, 1.0, 0.0, 1)]); s.setProjection(8, 0.5)
+    dt = 2.0 / N
+    s.advance(0, dt)
+    a, b = str(tmp_path / "sync"), str(tmp_path / "async")
+    n_sync = s.outputResult(0, a)
+    assert s.outputResultAsync(0, b)
+    s.advance(1, dt)                                   # overlaps the writer thread
+    assert s.waitOutput() == n_sync and n_sync > 0
+    fa, fb = os.path.join(a, "density_render_0001.bqd"), os.path.join(b, "density_render_0001.bqd")
+    assert open(fa, "rb").read() == open(fb, "rb").read()
+    assert s.outputResultAsync(1, None) and s.waitOutput() == 0        # path-less: download only
+
+
 def test_create_rejects_bad_arguments(cpu_host):
     assert not cpu_host.bq_solver_create(0, 4, 16, 16, 1.0, 0.0, 1.0, 0)       # too small
     assert not cpu_host.bq_solver_create(0, 16, 16, 16, 1.0, 0.0, 1.0, 1)      # SEMILAG: the GPU solver has no such scheme
