@@ -52,3 +52,5 @@ if __name__ == "__main__":
     for name, scene in SCENES.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **run_oracle(scene))
         print("wrote", name)
+    import op_vectors
+    op_vectors.generate()

@@ -42,3 +42,28 @@ def test_hip_reproduces_golden(name):
     for key in FIELDS:
         assert F.same(want[key], s.field(key)), (key, F.maxdiff(want[key], s.field(key)))
     s.close()
+
+
+# ---- per-operator vectors (tests/golden/op_vectors.py) ----------------------------------------------
+import op_vectors                                                           # noqa: E402
+
+
+def _op_params():
+    return [(g, name) for g, dims in op_vectors.GRIDS.items() for name in op_vectors.cases(*dims)]
+
+
+@pytest.mark.parametrize("grid,name", _op_params())
+def test_oracle_reproduces_op_vectors(grid, name):
+    want = np.load(op_vectors.path(grid))
+    got = op_vectors.run_oracle(op_vectors.cases(*op_vectors.GRIDS[grid])[name])
+    assert op_vectors.check(grid, name, got, want) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,name", _op_params())
+def test_hip_reproduces_op_vectors(grid, name):
+    import gpufluidsimulation_amd as bq
+    assert bq.hip_lib().fl_init(0) == 0
+    want = np.load(op_vectors.path(grid))
+    got = op_vectors.run_hip(op_vectors.cases(*op_vectors.GRIDS[grid])[name])
+    assert op_vectors.check(grid, name, got, want) == []
