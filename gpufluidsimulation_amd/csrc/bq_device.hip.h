@@ -40,6 +40,34 @@ __device__ __forceinline__ float ldf(const Field &f, unsigned byte_off)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(f.rsrc, byte_off, 0, 0));
 }
 
+// Neighbour-lane exchange across the whole wave64 as DPP moves (wave_shr:1 / wave_shl:1, GFX9 encodings
+// 0x138 / 0x130): a VALU instruction, where __shfl_up/__shfl_down compile to ds_bpermute_b32 on the LDS pipe.
+// lane_up(x): lane l receives lane l-1's x (lane 0 keeps its own); lane_down(x): lane l receives lane l+1's.
+__device__ __forceinline__ float lane_up(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_down(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_up(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)h2 << 32) | l2));
+}
+__device__ __forceinline__ double lane_down(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)h2 << 32) | l2));
+}
+
 // Grid spacing.  When h is a power of two (every BASELINE config: L=1, N=2^k) x/h == x*(1/h)
 // bit for bit, which removes three IEEE divisions (~11 VALU each) from every sample.
 struct Spacing {

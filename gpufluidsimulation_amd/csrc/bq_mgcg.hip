@@ -12,6 +12,7 @@
 // Bounds: every kernel here streams fp64 arrays -- 24 B/cell per smoothing sweep (x, b in, x' out).  At
 // 256^3 the three level-0 arrays (402 MB) exceed the 256 MiB Infinity Cache, so the level-0 sweeps are
 // HBM-bound; levels >= 1 (<= 50 MB) live in the cache.
+#include "bq_device.hip.h"
 #include "bq_host.h"
 
 #include <cstdint>
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(THREADS) void mg_smooth2_kernel(const double *__res
     // one smoothing evaluation on the thread's cells; lo/ro: the values just outside the wave (edge lanes)
     auto jac = [&](const DV<VEC> &ce, const DV<VEC> &fr, const DV<VEC> &bk, const DV<VEC> &dn, const DV<VEC> &up,
                    const DV<VEC> &dv, double outside, bool boundary) -> DV<VEC> {
-        double left = __shfl_up(ce.c[VEC - 1], 1, 64), right = __shfl_down(ce.c[0], 1, 64);
+        double left = lane_up(ce.c[VEC - 1]), right = lane_down(ce.c[0]);
         if (lane == 0) left = outside;
         if (lane == 63) right = outside;
         DV<VEC> o;

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
             bk2 = BQ_LD4(p, g + sj + sk * (k + 1));
             dv2 = BQ_LD4(div, g + sk * (k + 1));
         }
-        float left = __shfl_up(pc.w, 1, 64), right = __shfl_down(pc.x, 1, 64);
+        float left = lane_up(pc.w), right = lane_down(pc.x);
         if (fix_l || tile_l) left = p[g - 1 + sk * k];
         if (fix_r || tile_r) right = p[g + 4 + sk * k];
         float4 o;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     // one Jacobi evaluation on a float4; ce = centre row (x-neighbours by shuffle), fr/bk = rows -+1,
     // dn/up = planes -+1.  Boundary cells keep the input value.
     auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, bool boundary) -> float4 {
-        const float left = __shfl_up(ce.w, 1, 64), right = __shfl_down(ce.x, 1, 64);
+        const float left = lane_up(ce.w), right = lane_down(ce.x);
         float4 o;
         o.x = (left + ce.y + fr.x + bk.x + dn.x + up.x + alpha * dv.x) * beta;
         o.y = (ce.x + ce.z + fr.y + bk.y + dn.y + up.y + alpha * dv.y) * beta;
