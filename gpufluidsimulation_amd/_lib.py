@@ -71,6 +71,7 @@ HIP_SIGS = {
     "gpu_jacobi_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f, c_f]),
     "gpu_gradient": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
     "fl_comm_selftest": (c_i, []),
+    "gpu_diffuse_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f]),
     "gpu_max_field": (c_f, [VP, C.c_size_t]),
     "gpu_smoothing_jacobi": (None, [VP, VP, VP, c_d, c_d, c_i, c_i, c_i, c_i]),
     "gpu_jacobi_sweep_range": (None, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -761,6 +761,26 @@ void gpu_diffuse_field(float *field, float *fieldTemp0, float *filedTemp1, int n
     fl_memcpy_d2d(field, out, bytes);
 }
 
+// `sweeps` sweeps of diffuse_field_kernel ping-ponging in -> out -> in ...; returns 0 when the newest iterate
+// sits in `in`, 1 when it sits in `out` (the other buffer holds the iterate before it).  No copies: the pieces
+// of gpu_diffuse_field a z-slab host needs to refresh ghost planes between chunks of sweeps.
+int gpu_diffuse_sweeps(const float *field, float *in, float *out, int ni, int nj, int nk, int sweeps, float coef)
+{
+    if (!ensure_ready("gpu_diffuse_sweeps") || !dims_ok(ni, nj, nk, "gpu_diffuse_sweeps")) return 0;
+    if (!field || !in || !out || in == out || field == in || field == out || sweeps < 0) {
+        latch(FL_ERR_BAD_ARGUMENT, "gpu_diffuse_sweeps", "null or aliased buffers"); return 0;
+    }
+    Slab dsl = slab_of(nk);
+    if (rt().slab_on) dsl.nkg += nk - rt().slab_nkl;        // nk is a BUFFER dim (nk+1 for w)
+    float *a = in, *b = out;
+    for (int it = 0; it < sweeps; it++) {
+        diffuse_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(field, a, b, ni, nj, nk, coef, dsl.koff, dsl.nkg);
+        float *t = a; a = b; b = t;
+    }
+    BQ_LAUNCH_CHECK("diffuse_kernel");
+    return a == in ? 0 : 1;
+}
+
 void gpu_conjugate_gradient(float *, float *, float *, float *, float *, float *, float *, float *, int, int, int, int, float)
 {
     latch(FL_ERR_UNSUPPORTED, "gpu_conjugate_gradient", "out of scope: alternative solver compiled out in the reference");

@@ -225,6 +225,35 @@ void BimocqGPUSolver::diffuseField(float *field, float *t0, float *t1, int ni, i
     GpuSolver->diffuseField(field, t0, t1, ni, nj, nk, iter, coef);
 }
 
+// gpu_diffuse_field (GPU_kernel.cu:855-876) on a z-slab rank: t0 <- field, `iter` sweeps in chunks of at most G
+// (one exchange of the newest iterate's ghost planes buys G sweeps, each sweep reaching one plane), field <-
+// the iterate BEFORE the last one.  bk: buffer planes (nk + 1 for w).
+void BimocqGPUSolver::diffuseFieldSlab(DeviceField &field, DeviceField &t0, DeviceField &t1, int bi, int bj, int bk,
+                                       int iter, float nu, float dt)
+{
+    gpuMapper &gs = *GpuSolver;
+    const int G = gs.slab.G;
+    const float coef = nu * (dt / (CellSize * CellSize));
+    gs.require({ &field }, G);
+    t0.copy_from(field);
+    DeviceField *in = &t0, *out = &t1;
+    gs.produced(*out, 0);
+    int left = iter;
+    while (left > 0) {
+        const int chunk = std::min(left, G);
+        gs.require({ in }, chunk);
+        const int v0 = in->valid;
+        const int where = gpu_diffuse_sweeps(field, *in, *out, bi, bj, bk, chunk, coef);
+        // sweep s of the chunk leaves min(v0 - s, field.valid) correct ghost planes in its output
+        const int newest = std::min(v0 - chunk, field.valid), older = std::min(v0 - chunk + 1, field.valid);
+        if (where) std::swap(in, out);                     // `in` = newest iterate, `out` = the one before it
+        gs.produced(*in, newest);
+        gs.produced(*out, chunk == 1 ? v0 : older);
+        left -= chunk;
+    }
+    field.copy_from(*out);
+}
+
 // :406-467, the Jacobi branch (:409-410): alpha = -1, beta = 1/6
 // Distortion-driven re-initialisation (BQ_OPT_REINIT_POLICY = 1): the two map sets follow different
 // schedules, so the scalar advector needs its own; the scalar snapshot/delta buffers the every-frame
@@ -407,12 +436,14 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
 
     if (Viscosity) {                                     // :167-172, with the reference's buffer aliasing
         if (gs.slab.on && gs.slab.nranks > 1) {
-            fl_report_error(FL_ERR_UNSUPPORTED, "viscous diffusion sweeps on z-slabs are not built yet (nu must be 0)");
-            return;
+            diffuseFieldSlab(VelocityU, VelocityUTemp, TempSrcU, g.ni + 1, g.nj, g.nk, 20, Viscosity, dt);
+            diffuseFieldSlab(VelocityV, VelocityVTemp, TempSrcV, g.ni, g.nj + 1, g.nk, 20, Viscosity, dt);
+            diffuseFieldSlab(VelocityW, VelocityWTemp, TempSrcW, g.ni, g.nj, g.nk + 1, 20, Viscosity, dt);
+        } else {
+            diffuseField(VelocityU, VelocityUTemp, TempSrcU, g.ni + 1, g.nj, g.nk, 20, Viscosity, dt);
+            diffuseField(VelocityV, VelocityVTemp, TempSrcV, g.ni, g.nj + 1, g.nk, 20, Viscosity, dt);
+            diffuseField(VelocityW, VelocityWTemp, TempSrcW, g.ni, g.nj, g.nk + 1, 20, Viscosity, dt);
         }
-        diffuseField(VelocityU, VelocityUTemp, TempSrcU, g.ni + 1, g.nj, g.nk, 20, Viscosity, dt);
-        diffuseField(VelocityV, VelocityVTemp, TempSrcV, g.ni, g.nj + 1, g.nk, 20, Viscosity, dt);
-        diffuseField(VelocityW, VelocityWTemp, TempSrcW, g.ni, g.nj, g.nk + 1, 20, Viscosity, dt);
     }
 
     // :175-177 velocity change due to external forces

@@ -39,6 +39,7 @@ public:
     void emitSmoke(int framenum, float dt);
     void addBuoyancy(float dt);
     void diffuseField(float *field, float *t0, float *t1, int ni, int nj, int nk, int iter, float nu, float dt);
+    void diffuseFieldSlab(DeviceField &field, DeviceField &t0, DeviceField &t1, int bi, int bj, int bk, int iter, float nu, float dt);
     void projection();
     void velocityReinitialize();
     void scalarReinitialize();

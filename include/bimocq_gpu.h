@@ -322,6 +322,10 @@ void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w
                                       float *du_init, float *dv_init, float *dw_init,
                                       float *forward_x, float *forward_y, float *forward_z,
                                       float h, int ni, int nj, int nk, bool is_point, float coeff);
+/* the sweeps of gpu_diffuse_field without its two copies: `sweeps` times out = (field + coef*sum6(in))/(1+6coef)
+ * on interior cells, ping-ponging in <-> out; returns 0 if the newest iterate ends in `in`, 1 if in `out`.
+ * Lets a z-slab host refresh ghost planes between chunks of sweeps. */
+int gpu_diffuse_sweeps(const float *field, float *in, float *out, int ni, int nj, int nk, int sweeps, float coef);
 /* smoothing_jacobi<double> (GPU_kernel.cu:1464-1483) on its own: `iter` (rounded up to even) sweeps of
  * x' = ((sum6 x) + alpha*b) * beta on interior cells, ping-ponging x <-> temp; the newest iterate ends in x.
  * x and temp must carry the same boundary layer (V_Cycle clears both): sweeps are fused pairwise. */

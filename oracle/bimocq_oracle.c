@@ -725,10 +725,18 @@ void orc_diffuse_field(float *field, float *tmp0, float *tmp1,
                        int ni, int nj, int nk, int iter, float coef)
 {
     size_t number = (size_t)ni * nj * nk;
-    float *in = tmp0, *out = tmp1;
+    memcpy(tmp0, field, number * sizeof(float));
+    int where = orc_diffuse_sweeps(field, tmp0, tmp1, ni, nj, nk, iter, coef);
+    /* after the loop `out` is the buffer that was the INPUT of the last sweep */
+    memcpy(field, where ? tmp0 : tmp1, number * sizeof(float));
+}
+
+/* the sweep loop of gpu_diffuse_field on its own; returns 0 if the newest iterate is in `in`, 1 if in `out` */
+int orc_diffuse_sweeps(const float *field, float *in0, float *out0, int ni, int nj, int nk, int iter, float coef)
+{
+    float *in = in0, *out = out0;
     /* nk is a BUFFER dim (nk+1 for w): in slab mode the global plane count keeps that +1 */
     const int nkgb = S_on ? S_nkg + (nk - S_nkl) : nk;
-    memcpy(in, field, number * sizeof(float));
     for (int it = 0; it < iter; it++) {
 #pragma omp parallel for collapse(2) schedule(static)
         for (int k = imax(1, KLO(1)); k < imin(nk - 1, KHI(nkgb - 1, nk)); k++)
@@ -741,7 +749,7 @@ void orc_diffuse_field(float *field, float *tmp0, float *tmp1,
                 }
         float *t = out; out = in; in = t;
     }
-    memcpy(field, out, number * sizeof(float));
+    return in == in0 ? 0 : 1;
 }
 
 /* GPU_kernel.cu:967-985 divergence_kernel (float) */

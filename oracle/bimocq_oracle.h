@@ -110,6 +110,7 @@ void orc_emit_smoke(float *u, float *v, float *w, float *rho, float *T,
                     float density, float temperature, float emiter);
 void orc_add_buoyancy(float *v, const float *rho, const float *T,
                       int ni, int nj, int nk, float alpha, float beta, float dt);
+int orc_diffuse_sweeps(const float *field, float *in, float *out, int ni, int nj, int nk, int iter, float coef);
 void orc_diffuse_field(float *field, float *tmp0, float *tmp1,
                        int ni, int nj, int nk, int iter, float coef);
 void orc_add_field(float *out, const float *f1, const float *f2, float coeff, int number);

@@ -187,6 +187,8 @@ void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
 { orc_mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter); }
+int gpu_diffuse_sweeps(const float *field, float *in, float *out, int ni, int nj, int nk, int sweeps, float coef)
+{ return orc_diffuse_sweeps(field, in, out, ni, nj, nk, sweeps, coef); }
 void *fl_malloc_host(size_t bytes) { return calloc(bytes ? bytes : 4, 1); }
 void fl_free_host(void *p) { free(p); }
 void *fl_download_begin(void *host_dst, const void *dev_src, size_t bytes) { memcpy(host_dst, dev_src, bytes); return (void *)1; }

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--keep-dmc-border", type=int, default=1,
                     help="1: bit-exact mode (see csrc/host/mapping.hpp); 0: reference-faithful mode, compared by RMS")
     ap.add_argument("--rms-tol", type=float, default=1e-5)
+    ap.add_argument("--viscosity", type=float, default=0.0)
     a = ap.parse_args()
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -69,7 +70,7 @@ def main():
     zmid = 0.5 * nk * h
     em = [(0.5 * ni * h, 0.3 * nj * h, zmid + 0.3 * h, 0.16 * ni * h, 1.0, 2.0, 0.0, 2),
           (0.4 * ni * h, 0.35 * nj * h, 0.22 * nk * h, 0.12 * ni * h, 0.7, 1.0, 0.0, 1)]
-    s = solver.BimocqGPUSolver(ni, nj, nk, a.L, 0.0, BLEND, lib=hostlib, errlib=abilib, rank=rank, nranks=world, ghost=a.ghost)
+    s = solver.BimocqGPUSolver(ni, nj, nk, a.L, a.viscosity, BLEND, lib=hostlib, errlib=abilib, rank=rank, nranks=world, ghost=a.ghost)
     s.setSmoke(0.05, 1.0, em)
     s.setProjection(a.iters, 0.5)
     s.setOption(1, a.keep_dmc_border)
@@ -77,7 +78,7 @@ def main():
         # the oracle library inside the CPU stand-in carries the slab context; the reference run below
         # uses the separately loaded liboracle.so, which stays single-domain
         pass
-    o = OracleSolver(ni, nj, nk, a.L, 0.0, BLEND)
+    o = OracleSolver(ni, nj, nk, a.L, a.viscosity, BLEND)
     o.set_smoke(0.05, 1.0, em)
     o.set_projection(a.iters, 0.5)
     o.set_option(1, a.keep_dmc_border)

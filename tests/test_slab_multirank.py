@@ -59,6 +59,18 @@ def test_three_ranks_middle_rank_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_viscous_diffusion_on_slabs_cpu():
+    """nu != 0: the 20 diffusion sweeps per component run in chunks of G with ghost refreshes in between
+    (gpu_diffuse_sweeps), including the reference's buffer aliasing; bit-exact on 2 and 3 ranks"""
+    rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--viscosity", 2e-3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 2, "--iters", 16,
+                     "--dt-cells", 1.0, "--viscosity", 2e-3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
 def test_reference_border_mode_within_tolerance_cpu():
     """Reference-faithful DMC border (zeroed): wall-adjacent nodes of the compensation gather reach planes a
     slab rank cannot hold, so slab runs are not bit-identical to a single GPU there.  On this deliberately
@@ -78,6 +90,13 @@ def test_two_ranks_bit_exact_gpu():
     rc, out = launch(2, "--backend", "gpu", "--steps", 4, threads=4)
     assert rc == 0, out
     assert "mismatches=0" in out
+
+
+@pytest.mark.gpu
+def test_two_ranks_viscous_gpu():
+    rc, out = launch(2, "--backend", "gpu", "--steps", 3, "--viscosity", 2e-3, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
 
 
 @pytest.mark.gpu
