@@ -23,6 +23,7 @@ struct Runtime {
     int         opt_jacobi_fuse = 1;        // 0 never, 1 inside gpu_projection_jacobi, 2 also in gpu_jacobi_sweeps
     int         opt_jacobi_kchunk2 = 0;     // planes per block of the fused kernel (0 = auto)    // structured (compile-time taps) map look-up on power-of-two spacing
     int         opt_jacobi_kchunk = 0;      // 0 = auto
+    int         opt_mgcg_graph = 1;         // replay the multigrid V-cycle from a captured hipGraph
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;
     // this rank owns global planes [slab_own0, slab_own1) (reductions count only those)
@@ -44,6 +45,7 @@ void *pinned(size_t bytes);
 // bq_halo.hip: in-stream all-reduce of device values across slab ranks (no-op on one rank)
 bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStream_t st);
 int  comm_ranks();
+void mgcg_release_graph();              // bq_mgcg.hip: drop the cached V-cycle graph (fl_free / fl_shutdown)
 // bq_project.hip: FL_OPT_PROFILE_JACOBI spans -- an event pair around a loop of sweep launches on the compute
 // stream, summed by fl_jacobi_profile().  profile_begin returns false when profiling is off.
 struct ProfileSpan { hipEvent_t a = nullptr, b = nullptr; };

@@ -516,6 +516,59 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
     mg_residual(residual, b, x, L[0].ni, L[0].nj, L[0].nk);
 }
 
+// The V-cycle is ~230 launches with the same arguments in every outer iteration, most of them on grids too
+// small to hide a launch gap: it is captured once into a hipGraph (stream capture on the compute stream) and
+// replayed.  The cache is keyed by everything the launches depend on; FL_OPT_PROFILE_JACOBI (event records
+// inside the cycle) and FL_OPT_MGCG_GRAPH = 0 fall back to plain launches.
+struct VCycleGraph {
+    hipGraphExec_t exec = nullptr;
+    const double *b = nullptr; double *x = nullptr, *residual = nullptr, *temp0 = nullptr;
+    SCoarseLevelInfo levels[LEVEL_COUNT];
+    int levelnum = 0, fuse = 0, rows = 0, kchunk2 = 0;
+};
+static VCycleGraph g_vcg;
+
+static bool vcg_matches(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+{
+    const VCycleGraph &c = g_vcg;
+    if (!c.exec || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
+    if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk2 != rt().opt_jacobi_kchunk2) return false;
+    for (int l = 0; l < levelnum; l++) {
+        const SCoarseLevelInfo &p = c.levels[l], &q = L[l];
+        if (p.ni != q.ni || p.nj != q.nj || p.nk != q.nk || p.number != q.number || p.alpha != q.alpha || p.beta != q.beta ||
+            p.b != q.b || p.x != q.x || p.r != q.r) return false;
+    }
+    return true;
+}
+
+static void v_cycle_replayed(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+{
+    if (!rt().opt_mgcg_graph || rt().opt_profile_jacobi) { v_cycle(b, x, residual, L, temp0, levelnum); return; }
+    hipStream_t st = rt().compute;
+    if (!vcg_matches(b, x, residual, L, temp0, levelnum)) {
+        if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
+        (void)scratch(64);                                   // no allocation may happen while capturing
+        hipGraph_t graph = nullptr;
+        bool ok = BQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (ok) {
+            v_cycle(b, x, residual, L, temp0, levelnum);
+            ok = BQ_HIP(hipStreamEndCapture(st, &graph)) && rt().err == FL_OK;
+        }
+        if (ok) ok = BQ_HIP(hipGraphInstantiate(&g_vcg.exec, graph, nullptr, nullptr, 0));
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) { g_vcg.exec = nullptr; return; }           // the error is latched
+        g_vcg.b = b; g_vcg.x = x; g_vcg.residual = residual; g_vcg.temp0 = temp0; g_vcg.levelnum = levelnum;
+        g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2;
+        for (int l = 0; l < levelnum; l++) g_vcg.levels[l] = L[l];
+    }
+    BQ_HIP(hipGraphLaunch(g_vcg.exec, st));
+}
+
+void mgcg_release_graph()
+{
+    if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
+}
+
 } // namespace bq
 
 using namespace bq;
@@ -570,7 +623,7 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
         BQ_LAUNCH_CHECK("mg_update_x_kernel");
         mg_residual(residual, div, p, ni, nj, nk);
 
-        v_cycle(div, p, residual, levels, temp0, levelNum);
+        v_cycle_replayed(div, p, residual, levels, temp0, levelNum);
         mg_max(residual, tempResult, number, 2001 + it);
 
         // updateDir (:1497-1503)

@@ -91,6 +91,7 @@ void fl_shutdown(void)
     (void)hipStreamSynchronize(g_rt.compute);
     (void)hipStreamSynchronize(g_rt.halo);
     (void)hipStreamSynchronize(g_rt.copy);
+    bq::mgcg_release_graph();
     if (g_rt.scratch) (void)hipFree(g_rt.scratch);
     if (g_rt.pinned) (void)hipHostFree(g_rt.pinned);
     (void)hipStreamDestroy(g_rt.compute);
@@ -115,6 +116,7 @@ void *fl_malloc(size_t bytes)
 void fl_free(void *p)
 {
     if (!p) return;
+    bq::mgcg_release_graph();                  // a cached graph may hold this pointer
     if (g_rt.ready) (void)hipStreamSynchronize(g_rt.compute);
     BQ_HIP(hipFree(p));
 }
@@ -243,6 +245,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_STRUCTURED_MAPS: g_rt.opt_structured_maps = value ? 1 : 0; break;
     case FL_OPT_JACOBI_FUSE:     g_rt.opt_jacobi_fuse = value; break;
     case FL_OPT_JACOBI_KCHUNK2:  g_rt.opt_jacobi_kchunk2 = value < 0 ? 0 : value; break;
+    case FL_OPT_MGCG_GRAPH:      g_rt.opt_mgcg_graph = value != 0; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -259,6 +262,7 @@ int fl_get_option(int option)
     case FL_OPT_STRUCTURED_MAPS: return g_rt.opt_structured_maps;
     case FL_OPT_JACOBI_FUSE:     return g_rt.opt_jacobi_fuse;
     case FL_OPT_JACOBI_KCHUNK2:  return g_rt.opt_jacobi_kchunk2;
+    case FL_OPT_MGCG_GRAPH:      return g_rt.opt_mgcg_graph;
     default: return -1;
     }
 }

@@ -250,7 +250,9 @@ enum {
     FL_OPT_STRUCTURED_MAPS = 7, /* 9-point kernels: compile-time taps when h is a power of two (1)  */
     FL_OPT_JACOBI_FUSE     = 8, /* two sweeps per launch: 0 never, 1 in gpu_projection_jacobi (default),
                                    2 also in gpu_jacobi_sweeps (caller vouches for equal boundary layers) */
-    FL_OPT_JACOBI_KCHUNK2  = 9  /* planes marched per block in the fused kernel (0 = auto)           */
+    FL_OPT_JACOBI_KCHUNK2  = 9, /* planes marched per block in the fused kernel (0 = auto)           */
+    FL_OPT_MGCG_GRAPH      = 10 /* 1 (default): the multigrid V-cycle is captured into a hipGraph once and
+                                 * replayed in every outer iteration; 0: plain launches                */
 };
 void fl_set_option(int option, int value);
 int  fl_get_option(int option);
