@@ -225,11 +225,14 @@ def main():
         # algorithmic bytes of a launch are 12 B/voxel x voxels x sweeps-per-launch.
         us = ms.value * 1e3 / launches.value
         spl = sweeps.value / launches.value
-        alg = JACOBI_BYTES_PER_VOXEL * n ** 3 * spl
+        # a z-slab rank sweeps its ghost planes too (communication-avoiding chunks): n x n x (n + 2G) cells per sweep;
+        # the overlapped first sweep of a chunk (three range launches) is not inside the timed spans
+        cells = n ** 3 if world == 1 else n * n * (n + 2 * args.ghost)
+        alg = JACOBI_BYTES_PER_VOXEL * cells * spl
         achieved = alg / (us * 1e-6) / 1e9
         line["roofline"] = {"bound": "hbm", "kernel": "jacobi_march2_kernel" if spl > 1.5 else "jacobi_march_kernel",
                             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl),
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl) if world == 1 else None,
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
                             "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3),
                             "algorithmic_bytes_per_launch": int(alg)}

@@ -638,15 +638,20 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *p_temp, int ni, int nj,
     if (!p || !div || !p_temp || p == p_temp) { latch(FL_ERR_BAD_ARGUMENT, "gpu_jacobi_sweeps", "null or aliased buffers"); return 0; }
     float *in = p, *out = p_temp;
     int s = 0;
+    long long launches = 0;
+    ProfileSpan span;
+    const bool prof = sweeps > 0 && profile_begin(span);      // FL_OPT_PROFILE_JACOBI (the z-slab projection runs through here)
     // FL_OPT_JACOBI_FUSE == 2: the caller vouches that p and p_temp carry the same boundary layer
     while (rt().opt_jacobi_fuse >= 2 && s + 2 <= sweeps && jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta)) {
         float *t = in; in = out; out = t;          // iterate +2 sits in the former `out`
-        s += 2;
+        s += 2; launches++;
     }
     for (; s < sweeps; s++) {
         jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta);
         float *t = in; in = out; out = t;
+        launches++;
     }
+    if (prof) profile_end(span, launches, sweeps);
     return in == p ? 0 : 1;
 }
 
