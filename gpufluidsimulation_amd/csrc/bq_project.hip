@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 // Preconditions (checked by the launcher): nx <= 256 (a row fits one wave; x-neighbours by shuffle)
 // and both ping-pong buffers carry the same boundary layer (gpu_projection_jacobi's contract: the
 // caller zeroes both), because boundary cells are never written and L1's boundary is taken from L0.
-template <int WAVES>
+template <int WAVES, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                    float *__restrict__ out, int nx, int ny, int nz,
                                                                    int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
@@ -300,25 +300,28 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     const int by = b % nby, bz = b / nby;
     const int rows = (WAVES * 64) / cw;
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
-    const int x = 4 * c, j = by * rows + r;
+    const int xraw = 4 * c, j = by * rows + r;
     // local planes a sweep may update: inside the array AND inside the global domain (z-slab ranks);
     // everything else counts as boundary and keeps its input value in L1
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
     const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
     if (kbeg >= kend) return;
-    const bool xok = x < nx;
+    const bool xok = xraw < nx;
     const bool active = xok && j >= 1 && j <= ny - 2;
+    // Out-of-range rows, planes and lanes are CLAMPED into the array instead of being zero-filled: whatever
+    // they load only ever feeds cells that are boundary (kept from L0) or not stored at all.  No branch per load.
+    const int x = xok ? xraw : nx - 4;
     const size_t sj = nx, sk = (size_t)nx * ny;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool xlo = x == 0, xhi = x + 3 == nx - 1;
+    auto rowoff = [&](int row) -> size_t { return (size_t)x + sj * (size_t)min(max(row, 0), ny - 1); };
+    const size_t o_m2 = rowoff(j - 2), o_m1 = rowoff(j - 1), o_0 = rowoff(j), o_p1 = rowoff(j + 1), o_p2 = rowoff(j + 2);
+    auto plane = [&](int pl) -> size_t { return sk * (size_t)min(max(pl, 0), nz - 1); };
+    auto ld4 = [&](const float *ptr, size_t off) -> float4 { return *reinterpret_cast<const float4 *>(ptr + off); };
+    const bool rowb_m1 = j - 1 <= 0 || j - 1 >= ny - 1, rowb_0 = j <= 0 || j >= ny - 1, rowb_p1 = j + 1 <= 0 || j + 1 >= ny - 1;
 
-    // guarded float4 load of row `row`, plane `pl` (zero outside the array)
-    auto ld4 = [&](const float *ptr, int row, int pl) -> float4 {
-        if (!xok || row < 0 || row >= ny || pl < 0 || pl >= nz) return zero4;
-        return *reinterpret_cast<const float4 *>(ptr + (size_t)x + sj * row + sk * pl);
-    };
-    // one Jacobi evaluation on a float4; ce = centre row (x-neighbours by shuffle), fr/bk = rows -+1,
-    // dn/up = planes -+1.  Boundary cells keep the input value.
+    // one Jacobi evaluation on a float4; ce = centre row (x-neighbours from the neighbouring lanes), fr/bk = rows
+    // -+1, dn/up = planes -+1.  Boundary cells keep the input value.
     auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, bool boundary) -> float4 {
         const float left = lane_up(ce.w), right = lane_down(ce.x);
         float4 o;
@@ -332,44 +335,44 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
         return o;
     };
 
-    // L0 of rows j-1, j, j+1 on planes q-1 (Lm), q (Lc), q+1 (Ln); q = plane whose L1 is being built
-    float4 Lm[3], Lc[3], Ln[3];
+    // L0 of rows j-1, j, j+1 on planes q-1 (Lm), q (Lc), q+1 (Ln) [, q+2 (Lf) when DEPTH == 2]; q = plane whose
+    // L1 is being built.  Loads run DEPTH planes ahead of their use: the kernel is bound by the round trip of
+    // one plane's loads per iteration, not by bandwidth or arithmetic.
+    float4 Lm[3], Lc[3], Ln[3], Lf[3], Dv[3], Df[3], Hf, Hb, Hf1, Hb1;
     int q = kbeg - 1;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        Lm[a] = ld4(p, j - 1 + a, q - 1);
-        Lc[a] = ld4(p, j - 1 + a, q);
-        Ln[a] = ld4(p, j - 1 + a, q + 1);
+    {
+        const size_t pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
+        Lm[0] = ld4(p, pm + o_m1); Lm[1] = ld4(p, pm + o_0); Lm[2] = ld4(p, pm + o_p1);
+        Lc[0] = ld4(p, pc + o_m1); Lc[1] = ld4(p, pc + o_0); Lc[2] = ld4(p, pc + o_p1);
+        Ln[0] = ld4(p, pn + o_m1); Ln[1] = ld4(p, pn + o_0); Ln[2] = ld4(p, pn + o_p1);
+        Dv[0] = ld4(div, pc + o_m1); Dv[1] = ld4(div, pc + o_0); Dv[2] = ld4(div, pc + o_p1);
+        Hf = ld4(p, pc + o_m2); Hb = ld4(p, pc + o_p2);
+        if constexpr (DEPTH == 2) {
+            const size_t pf = plane(q + 2);
+            Lf[0] = ld4(p, pf + o_m1); Lf[1] = ld4(p, pf + o_0); Lf[2] = ld4(p, pf + o_p1);
+            Df[0] = ld4(div, pn + o_m1); Df[1] = ld4(div, pn + o_0); Df[2] = ld4(div, pn + o_p1);
+            Hf1 = ld4(p, pn + o_m2); Hb1 = ld4(p, pn + o_p2);
+        }
     }
-    float4 Hf = ld4(p, j - 2, q), Hb = ld4(p, j + 2, q);
-    float4 Dv[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) Dv[a] = ld4(div, j - 1 + a, q);
 
     float4 Mc[3] = { zero4, zero4, zero4 };     // L1 on plane q-1
     float4 Mm = zero4;                          // L1 of row j on plane q-2
     float4 Dprev = zero4;                       // div of row j on plane q-1
 
     for (; q <= kend; q++) {
-        // prefetch what plane q+1 needs
-        float4 Ln2[3], Dv2[3], Hf2 = zero4, Hb2 = zero4;
-#pragma unroll
-        for (int a = 0; a < 3; a++) { Ln2[a] = zero4; Dv2[a] = zero4; }
-        if (q < kend) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                Ln2[a] = ld4(p, j - 1 + a, q + 2);
-                Dv2[a] = ld4(div, j - 1 + a, q + 1);
-            }
-            Hf2 = ld4(p, j - 2, q + 1);
-            Hb2 = ld4(p, j + 2, q + 1);
-        }
+        // prefetch: L0 of plane q+1+DEPTH, div and the j-+2 rows of plane q+DEPTH
+        const size_t pa = plane(q + 1 + DEPTH), pb = plane(q + DEPTH);
+        float4 La[3], Da[3];
+        La[0] = ld4(p, pa + o_m1); La[1] = ld4(p, pa + o_0); La[2] = ld4(p, pa + o_p1);
+        Da[0] = ld4(div, pb + o_m1); Da[1] = ld4(div, pb + o_0); Da[2] = ld4(div, pb + o_p1);
+        const float4 Hfa = ld4(p, pb + o_m2), Hba = ld4(p, pb + o_p2);
+
         // L1 on plane q for rows j-1, j, j+1
         const bool qb = q < kA || q >= kB;
         float4 M[3];
-        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], qb || j - 1 <= 0 || j - 1 >= ny - 1);
-        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], qb || j <= 0 || j >= ny - 1);
-        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], qb || j + 1 <= 0 || j + 1 >= ny - 1);
+        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], qb || rowb_m1);
+        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], qb || rowb_0);
+        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], qb || rowb_p1);
         // L2 on plane q-1 for row j
         const int k = q - 1;
         const float4 o = jac(Mc[1], Mc[0], Mc[2], Mm, M[1], Dprev, false);
@@ -388,8 +391,13 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
         Mm = Mc[1];
         Dprev = Dv[1];
 #pragma unroll
-        for (int a = 0; a < 3; a++) { Mc[a] = M[a]; Lm[a] = Lc[a]; Lc[a] = Ln[a]; Ln[a] = Ln2[a]; Dv[a] = Dv2[a]; }
-        Hf = Hf2; Hb = Hb2;
+        for (int a = 0; a < 3; a++) {
+            Mc[a] = M[a]; Lm[a] = Lc[a]; Lc[a] = Ln[a];
+            if constexpr (DEPTH == 2) { Ln[a] = Lf[a]; Lf[a] = La[a]; Dv[a] = Df[a]; Df[a] = Da[a]; }
+            else                      { Ln[a] = La[a]; Dv[a] = Da[a]; }
+        }
+        if constexpr (DEPTH == 2) { Hf = Hf1; Hb = Hb1; Hf1 = Hfa; Hb1 = Hba; }
+        else                      { Hf = Hfa; Hb = Hba; }
     }
 }
 
@@ -560,7 +568,10 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 32;
     while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
     const int nbz = (nk + kchunk - 1) / kchunk;
-    jacobi_march2_kernel<4><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
+    // loads run one plane ahead of their use; two planes ahead (FL_OPT_JACOBI_ROWS == 2, kept for tuning) measured
+    // no better at 256^3 (19.4 vs 19.1 us per sweep)
+    if (rt().opt_jacobi_rows != 2) jacobi_march2_kernel<4, 1><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
+    else                           jacobi_march2_kernel<4, 2><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
     return true;
 }

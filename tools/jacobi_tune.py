@@ -48,7 +48,7 @@ def main():
             fused = v[0] == 4
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0 if fused else v[0])
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2 if fused else 0)
-            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0 if fused else v[1])
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, v[1])   # fused: 1 = one-plane prefetch, else two planes ahead
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0 if fused else v[2])
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, v[2] if fused else 0)
             lib.fl_event_record(e0)
