@@ -221,21 +221,22 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 
     const int rows = (WAVES * 64) / cw;             // rows of the tile (cw float4 columns each)
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
-    const int x = (bx * cw + c) * 4, j = by * rows + r;
+    const int xraw = (bx * cw + c) * 4, j = by * rows + r;
     const int kbeg = max(max(max(1, 1 - sl.koff), sl.klo), bz * kchunk);
     const int kend = min(min(min(nz - 1, sl.nkg - 1 - sl.koff), sl.khi), bz * kchunk + kchunk);
     if (kbeg >= kend) return;
-    const bool active = x < nx && j >= 1 && j <= ny - 2;
+    const bool active = xraw < nx && j >= 1 && j <= ny - 2;
+    const int x = xraw < nx ? xraw : nx - 4;                    // lanes past the row read its last float4, never store
     const size_t sj = nx, sk = (size_t)nx * ny;
     const size_t g = (size_t)x + sj * (active ? j : 1);         // inactive lanes read a valid row, never store
-    const bool xok = x < nx;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int lane = threadIdx.x & 63;
     // a lane at a wave edge whose x-neighbour lives in another wave (rows longer than one wave)
     const bool fix_l = lane == 0 && c > 0, fix_r = lane == 63 && c < cw - 1;
     const bool tile_l = c == 0 && x > 0, tile_r = c == cw - 1 && x + 4 < nx;   // neighbour in another block
 
-#define BQ_LD4(ptr, off) (xok ? *reinterpret_cast<const float4 *>((ptr) + (off)) : zero4)
+    // no branch or select per load: out-of-range lanes and the plane past the chunk's end are clamped into the
+    // array, what they load is never used for a stored cell
+#define BQ_LD4(ptr, off) (*reinterpret_cast<const float4 *>((ptr) + (off)))
     float4 pm = BQ_LD4(p, g + sk * (kbeg - 1));
     float4 pc = BQ_LD4(p, g + sk * kbeg);
     float4 pn = BQ_LD4(p, g + sk * (kbeg + 1));
@@ -245,13 +246,11 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 
     for (int k = kbeg; k < kend; k++) {
         // prefetch everything plane k+1 needs (its k+2 centre, its j+-1 rows, its div)
-        float4 pn2 = zero4, fr2 = zero4, bk2 = zero4, dv2 = zero4;
-        if (k + 1 < kend) {
-            pn2 = BQ_LD4(p, g + sk * (k + 2));
-            fr2 = BQ_LD4(p, g - sj + sk * (k + 1));
-            bk2 = BQ_LD4(p, g + sj + sk * (k + 1));
-            dv2 = BQ_LD4(div, g + sk * (k + 1));
-        }
+        const size_t k2 = (size_t)min(k + 2, nz - 1);       // k + 1 <= kend <= nz - 1 needs no clamp
+        const float4 pn2 = BQ_LD4(p, g + sk * k2);
+        const float4 fr2 = BQ_LD4(p, g - sj + sk * (k + 1));
+        const float4 bk2 = BQ_LD4(p, g + sj + sk * (k + 1));
+        const float4 dv2 = BQ_LD4(div, g + sk * (k + 1));
         float left = lane_up(pc.w), right = lane_down(pc.x);
         if (fix_l || tile_l) left = p[g - 1 + sk * k];
         if (fix_r || tile_r) right = p[g + 4 + sk * k];

@@ -348,8 +348,10 @@ void BimocqGPUSolver::projection()
     const int fuse_was = fl_get_option(FL_OPT_JACOBI_FUSE);
     if (fuse_was == 1) fl_set_option(FL_OPT_JACOBI_FUSE, 2);
     int left = jacobi_iters - 1;                                         // iterate iter-1 is applied
+    // an odd chunk = the overlapped first sweep + an even number of sweeps, which all run as fused pairs
+    const int chunk_max = (G % 2 == 0 && G > 1) ? G - 1 : G;
     while (left > 0) {
-        const int chunk = std::min(left, G);
+        const int chunk = std::min(left, chunk_max);
         int where;
         if (cur->valid < chunk) {
             // exchange the ghost planes of `cur` on the halo stream and meanwhile sweep the planes whose
