@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 // Preconditions (checked by the launcher): nx <= 256 (a row fits one wave; x-neighbours by shuffle)
 // and both ping-pong buffers carry the same boundary layer (gpu_projection_jacobi's contract: the
 // caller zeroes both), because boundary cells are never written and L1's boundary is taken from L0.
-template <int WAVES, int DEPTH>
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                    float *__restrict__ out, int nx, int ny, int nz,
                                                                    int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
@@ -334,38 +334,31 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
         return o;
     };
 
-    // L0 of rows j-1, j, j+1 on planes q-1 (Lm), q (Lc), q+1 (Ln) [, q+2 (Lf) when DEPTH == 2]; q = plane whose
-    // L1 is being built.  Loads run DEPTH planes ahead of their use: the kernel is bound by the round trip of
-    // one plane's loads per iteration, not by bandwidth or arithmetic.
-    float4 Lm[3], Lc[3], Ln[3], Lf[3], Dv[3], Df[3], Hf, Hb, Hf1, Hb1;
+    // L0 of rows j-1, j, j+1 on three consecutive planes; q = plane whose L1 is being built.  The loads of plane
+    // q+2 are issued before plane q is computed.  The three plane sets rotate roles (below, centre, above) from
+    // one plane to the next: the loop body is written once as `phase` and instantiated three times with the
+    // sets permuted, so that no register moves are needed to rotate them.
+    float4 A[3], B[3], C[3], Dv[3], Hf, Hb;
     int q = kbeg - 1;
     {
         const size_t pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
-        Lm[0] = ld4(p, pm + o_m1); Lm[1] = ld4(p, pm + o_0); Lm[2] = ld4(p, pm + o_p1);
-        Lc[0] = ld4(p, pc + o_m1); Lc[1] = ld4(p, pc + o_0); Lc[2] = ld4(p, pc + o_p1);
-        Ln[0] = ld4(p, pn + o_m1); Ln[1] = ld4(p, pn + o_0); Ln[2] = ld4(p, pn + o_p1);
+        A[0] = ld4(p, pm + o_m1); A[1] = ld4(p, pm + o_0); A[2] = ld4(p, pm + o_p1);
+        B[0] = ld4(p, pc + o_m1); B[1] = ld4(p, pc + o_0); B[2] = ld4(p, pc + o_p1);
+        C[0] = ld4(p, pn + o_m1); C[1] = ld4(p, pn + o_0); C[2] = ld4(p, pn + o_p1);
         Dv[0] = ld4(div, pc + o_m1); Dv[1] = ld4(div, pc + o_0); Dv[2] = ld4(div, pc + o_p1);
         Hf = ld4(p, pc + o_m2); Hb = ld4(p, pc + o_p2);
-        if constexpr (DEPTH == 2) {
-            const size_t pf = plane(q + 2);
-            Lf[0] = ld4(p, pf + o_m1); Lf[1] = ld4(p, pf + o_0); Lf[2] = ld4(p, pf + o_p1);
-            Df[0] = ld4(div, pn + o_m1); Df[1] = ld4(div, pn + o_0); Df[2] = ld4(div, pn + o_p1);
-            Hf1 = ld4(p, pn + o_m2); Hb1 = ld4(p, pn + o_p2);
-        }
     }
-
     float4 Mc[3] = { zero4, zero4, zero4 };     // L1 on plane q-1
     float4 Mm = zero4;                          // L1 of row j on plane q-2
     float4 Dprev = zero4;                       // div of row j on plane q-1
 
-    for (; q <= kend; q++) {
-        // prefetch: L0 of plane q+1+DEPTH, div and the j-+2 rows of plane q+DEPTH
-        const size_t pa = plane(q + 1 + DEPTH), pb = plane(q + DEPTH);
+    // one plane: Lm/Lc/Ln = L0 on planes q-1/q/q+1; on return Lm holds plane q+2 (it becomes the next "above")
+    auto phase = [&](float4 (&Lm)[3], float4 (&Lc)[3], float4 (&Ln)[3]) {
+        const size_t pa = plane(q + 2), pb = plane(q + 1);
         float4 La[3], Da[3];
         La[0] = ld4(p, pa + o_m1); La[1] = ld4(p, pa + o_0); La[2] = ld4(p, pa + o_p1);
         Da[0] = ld4(div, pb + o_m1); Da[1] = ld4(div, pb + o_0); Da[2] = ld4(div, pb + o_p1);
         const float4 Hfa = ld4(p, pb + o_m2), Hba = ld4(p, pb + o_p2);
-
         // L1 on plane q for rows j-1, j, j+1
         const bool qb = q < kA || q >= kB;
         float4 M[3];
@@ -386,17 +379,19 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
                 if (x + 3 < nx - 1) dst[3] = o.w;
             }
         }
-        // rotate
         Mm = Mc[1];
         Dprev = Dv[1];
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            Mc[a] = M[a]; Lm[a] = Lc[a]; Lc[a] = Ln[a];
-            if constexpr (DEPTH == 2) { Ln[a] = Lf[a]; Lf[a] = La[a]; Dv[a] = Df[a]; Df[a] = Da[a]; }
-            else                      { Ln[a] = La[a]; Dv[a] = Da[a]; }
-        }
-        if constexpr (DEPTH == 2) { Hf = Hf1; Hb = Hb1; Hf1 = Hfa; Hb1 = Hba; }
-        else                      { Hf = Hfa; Hb = Hba; }
+        for (int a = 0; a < 3; a++) { Mc[a] = M[a]; Lm[a] = La[a]; Dv[a] = Da[a]; }
+        Hf = Hfa; Hb = Hba;
+        q++;
+    };
+    while (q <= kend) {
+        phase(A, B, C);
+        if (q > kend) break;
+        phase(B, C, A);
+        if (q > kend) break;
+        phase(C, A, B);
     }
 }
 
@@ -567,10 +562,8 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 32;
     while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
     const int nbz = (nk + kchunk - 1) / kchunk;
-    // loads run one plane ahead of their use; two planes ahead (FL_OPT_JACOBI_ROWS == 2, kept for tuning) measured
-    // no better at 256^3 (19.4 vs 19.1 us per sweep)
-    if (rt().opt_jacobi_rows != 2) jacobi_march2_kernel<4, 1><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
-    else                           jacobi_march2_kernel<4, 2><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
+    // (loads two planes ahead instead of one measured no better at 256^3: 19.4 vs 19.1 us per sweep)
+    jacobi_march2_kernel<4><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
     return true;
 }
