@@ -84,6 +84,7 @@ HIP_SIGS = {
     "gpu_compensate_error_field2": (None, [VP] * 9 + _G + [c_b]),
     "gpu_accumulate_field2": (None, [VP, VP, c_f, VP, VP, c_f] + [VP] * 3 + _G + [c_b]),
     "gpu_accumulate_velocity2": (None, [VP] * 3 + [c_f] + [VP] * 3 + [c_f] + [VP] * 6 + _G + [c_b]),
+    "gpu_accumulate_component": (None, [VP, c_f, VP, c_f, VP, VP, VP, VP] + _G + [c_i, c_b]),
     "gpu_accumulate_velocity_identity": (None, [VP] * 9 + _G + [c_b, c_f]),
     "fl_report_error": (None, [c_i, C.c_char_p]),
     # 4. multi-GPU

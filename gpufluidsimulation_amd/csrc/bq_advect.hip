@@ -701,6 +701,24 @@ void gpu_accumulate_velocity2(float *u_change1, float *v_change1, float *w_chang
     cumulate_multi<2>(CumulateArgs<2>{{w_change1, w_change2}, {dw_init, dw_init}, {coeff1, coeff2}}, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, false);
 }
 
+// One velocity component of gpu_accumulate_velocity (axis 0/1/2 = u/v/w) with one or two sources:
+//   d_init += blend9(coeff1 * change1(psi(x))) [ ; += blend9(coeff2 * change2(psi(x))) when change2 != NULL ]
+// lets a host skip a component's source that is known to be identically zero.
+void gpu_accumulate_component(float *change1, float coeff1, float *change2, float coeff2, float *d_init,
+                              float *forward_x, float *forward_y, float *forward_z,
+                              float h, int ni, int nj, int nk, int axis, bool is_point)
+{
+    BQ_ENTER("gpu_accumulate_component", change1, d_init, forward_x, forward_y, forward_z)
+    BQ_REQUIRE(axis >= 0 && axis <= 2, "gpu_accumulate_component");
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    const int dx = axis == 0, dy = axis == 1, dz = axis == 2;
+    if (change2)
+        cumulate_multi<2>(CumulateArgs<2>{{change1, change2}, {d_init, d_init}, {coeff1, coeff2}}, forward_x, forward_y, forward_z,
+                          sp, g, dx, dy, dz, is_point, false);
+    else
+        cumulate_comp(change1, d_init, forward_x, forward_y, forward_z, sp, g, dx, dy, dz, is_point, coeff1);
+}
+
 // gpu_accumulate_velocity for a forward map that IS the identity map of gpu_init_maps (right after a
 // re-initialisation): the caller vouches for that; the map buffers are still passed and are read on every
 // path without the shortcut (spacing not a power of two, FL_OPT_STRUCTURED_MAPS off).

@@ -448,13 +448,20 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
         }
     }
 
-    // :175-177 velocity change due to external forces
-    gs.addFields(duExtern, VelocityU, VelocityUTemp, -1.f, g.nu());
+    // :175-177 velocity change due to external forces.  Buoyancy acts on v only: unless a source imposed its
+    // velocity ring this frame or viscosity smoothed all three components, u and w still equal their snapshots,
+    // U - UTemp is identically +0, and accumulating blend9 of a zero field (:213) changes no value -- neither the
+    // difference nor its look-up is executed for u and w then.
+    bool forces_touch_uw = Viscosity != 0.f;
+    for (const Emitter &e : sim_emitter) forces_touch_uw = forces_touch_uw || framenum < e.emitFrame;
+    if (forces_touch_uw) {
+        gs.addFields(duExtern, VelocityU, VelocityUTemp, -1.f, g.nu());
+        gs.addFields(dwExtern, VelocityW, VelocityWTemp, -1.f, g.nw());
+        gs.produced(duExtern, std::min(VelocityU.valid, VelocityUTemp.valid));
+        gs.produced(dwExtern, std::min(VelocityW.valid, VelocityWTemp.valid));
+    }
     gs.addFields(dvExtern, VelocityV, VelocityVTemp, -1.f, g.nv());
-    gs.addFields(dwExtern, VelocityW, VelocityWTemp, -1.f, g.nw());
-    gs.produced(duExtern, std::min(VelocityU.valid, VelocityUTemp.valid));
     gs.produced(dvExtern, std::min(VelocityV.valid, VelocityVTemp.valid));
-    gs.produced(dwExtern, std::min(VelocityW.valid, VelocityWTemp.valid));
     // :179-181
     VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
 
@@ -496,7 +503,7 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
 
     // :213-214
     VelocityAdvector.accumulateVelocity2(VelocityUInit, VelocityVInit, VelocityWInit,
-                                         duExtern, dvExtern, dwExtern, 1.f, duProj, dvProj, dwProj, proj_coeff);
+                                         duExtern, dvExtern, dwExtern, 1.f, duProj, dvProj, dwProj, proj_coeff, !forces_touch_uw);
     if (policy1) {                                       // BimocqSolver.cpp:191-192 (:215-216 here adds zeros)
         ScalarAdvector.accumulateField(DensityInit, DensityExtern);
         ScalarAdvector.accumulateField(TemperatureInit, TemperatureExtern);

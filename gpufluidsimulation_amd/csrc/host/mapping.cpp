@@ -285,11 +285,21 @@ void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, Devic
 
 void MapperBaseGPU::accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
                                         DeviceField &Uc1, DeviceField &Vc1, DeviceField &Wc1, float coeff1,
-                                        DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2)
+                                        DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2, bool first_uw_zero)
 {
     MapSet &m = *maps;
     gpuMapper &gs = *gpuSolver;
     gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
+    if (first_uw_zero) {
+        gs.require({ &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd));
+        gpu_accumulate_component(Uc2, coeff2, nullptr, 0.f, dUi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 0, false);
+        gpu_accumulate_component(Vc1, coeff1, Vc2, coeff2, dVi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 1, false);
+        gpu_accumulate_component(Wc2, coeff2, nullptr, 0.f, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 2, false);
+        gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
+                                                        gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
+                                                        gpuMapper::minValid({ &Vc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
+        return;
+    }
     gs.require({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd));
     gpu_accumulate_velocity2(Uc1, Vc1, Wc1, coeff1, Uc2, Vc2, Wc2, coeff2, dUi, dVi, dWi,
                              m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false);

@@ -53,9 +53,11 @@ public:
     void accumulateVelocity(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
                             DeviceField &Uc, DeviceField &Vc, DeviceField &Wc, float coeff);
     // accumulateVelocity(change 1, coeff1) ; accumulateVelocity(change 2, coeff2), one map look-up
+    // first_uw_zero: the caller knows Uc1 and Wc1 to be identically zero (adding blend9 of a zero field changes
+    // nothing): their look-ups are skipped and u, w take the second source only
     void accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, DeviceField &dWi,
                              DeviceField &Uc1, DeviceField &Vc1, DeviceField &Wc1, float coeff1,
-                             DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2);
+                             DeviceField &Uc2, DeviceField &Vc2, DeviceField &Wc2, float coeff2, bool first_uw_zero = false);
     void accumulateField(DeviceField &dfInit, DeviceField &fChange);
     void reinitializeMapping();
     // Mapping.cpp:495-519: sqrt of the largest round-trip error |x - fwd(back(x))|, |x - back(fwd(x))|

@@ -316,6 +316,12 @@ void gpu_accumulate_velocity2(float *u_change1, float *v_change1, float *w_chang
                               float *du_init, float *dv_init, float *dw_init,
                               float *forward_x, float *forward_y, float *forward_z,
                               float h, int ni, int nj, int nk, bool is_point);
+/* one component (axis 0/1/2 = u/v/w) of gpu_accumulate_velocity with one or two sources (change2 may be NULL):
+ * d_init += blend9(coeff1*change1(psi(x))) [then += blend9(coeff2*change2(psi(x)))].  For hosts that know a
+ * component's source to be identically zero (no force acts on u and w when only buoyancy is on). */
+void gpu_accumulate_component(float *change1, float coeff1, float *change2, float coeff2, float *d_init,
+                              float *forward_x, float *forward_y, float *forward_z,
+                              float h, int ni, int nj, int nk, int axis, bool is_point);
 /* gpu_accumulate_velocity when the caller KNOWS the forward map is the identity map gpu_init_maps wrote
  * (BimocqGPUSolver.cpp:222-223: accumulate right after reinitializeMapping): with power-of-two spacing
  * the mapped positions follow from the node indices alone, by the same lerps, and the map is not read.

@@ -522,6 +522,14 @@ void orc_accumulate_velocity(const float *uc, const float *vc, const float *wc,
     cumulate_comp(wc, dw_init, f, h, ni, nj, nk, 0, 0, 1, is_point, coeff);
 }
 
+/* one component (axis 0/1/2) of the launch trio above */
+void orc_accumulate_component(const float *change, float *d_init, const float *fx, const float *fy, const float *fz,
+                              float h, int ni, int nj, int nk, int axis, int is_point, float coeff)
+{
+    map3 f = { fx, fy, fz };
+    cumulate_comp(change, d_init, f, h, ni, nj, nk, axis == 0, axis == 1, axis == 2, is_point, coeff);
+}
+
 /* GPU_kernel.cu:698-705 */
 void orc_accumulate_field(const float *change, float *dfield_init,
                           const float *fx, const float *fy, const float *fz,

@@ -70,6 +70,8 @@ void orc_accumulate_velocity(const float *uc, const float *vc, const float *wc,
                              float *du_init, float *dv_init, float *dw_init,
                              const float *fx, const float *fy, const float *fz,
                              float h, int ni, int nj, int nk, int is_point, float coeff);
+void orc_accumulate_component(const float *change, float *d_init, const float *fx, const float *fy, const float *fz,
+                              float h, int ni, int nj, int nk, int axis, int is_point, float coeff);
 void orc_accumulate_field(const float *change, float *dfield_init,
                           const float *fx, const float *fy, const float *fz,
                           float h, int ni, int nj, int nk, int is_point, float coeff);

@@ -182,6 +182,12 @@ void gpu_accumulate_velocity2(float *u1, float *v1, float *w1, float k1, float *
     orc_accumulate_velocity(u1, v1, w1, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, k1);
     orc_accumulate_velocity(u2, v2, w2, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, k2);
 }
+void gpu_accumulate_component(float *c1, float k1, float *c2, float k2, float *d, float *fx, float *fy, float *fz,
+                              float h, int ni, int nj, int nk, int axis, bool pt)
+{
+    orc_accumulate_component(c1, d, fx, fy, fz, h, ni, nj, nk, axis, pt, k1);
+    if (c2) orc_accumulate_component(c2, d, fx, fy, fz, h, ni, nj, nk, axis, pt, k2);
+}
 void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du, float *dv, float *dw,
                                       float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt, float coeff)
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
