@@ -546,7 +546,11 @@ static void double_comp(float *f, const float *prev, const float *bx, const floa
                         const float *px, const float *py, const float *pz,
                         Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float blend)
 {
-    if (blend == 1.0f && rt().opt_skip_unit_blend) {
+    // blend == 1: field*1 + 0*prev.  For finite prev that is field + (+-0): the value of every node is unchanged
+    // (only a -0 would turn into +0, which no consumer can tell apart).  FL_OPT_SKIP_UNIT_BLEND = 1 (default): nothing
+    // is launched; 2: the one-pass `field + 0` kernel (bit pattern of the reference); 0: the full kernel.
+    if (blend == 1.0f && rt().opt_skip_unit_blend == 1) return;
+    if (blend == 1.0f && rt().opt_skip_unit_blend == 2) {
         unit_blend_kernel<<<grid_for(g.ni + dx, g.nj + dy, g.nk + dz), kBlock, 0, rt().compute>>>(f, g, dx, dy, dz);
         BQ_LAUNCH_CHECK("unit_blend_kernel");
         return;

@@ -237,7 +237,7 @@ void fl_set_option(int option, int value)
 {
     switch (option) {
     case FL_OPT_RESIDUAL_STRIDE: g_rt.opt_residual_stride = value < 0 ? 0 : value; break;
-    case FL_OPT_SKIP_UNIT_BLEND: g_rt.opt_skip_unit_blend = value ? 1 : 0; break;
+    case FL_OPT_SKIP_UNIT_BLEND: g_rt.opt_skip_unit_blend = (value == 1 || value == 2) ? value : 0; break;
     case FL_OPT_JACOBI_VARIANT:  g_rt.opt_jacobi_variant = value; break;
     case FL_OPT_PROFILE_JACOBI:  g_rt.opt_profile_jacobi = value ? 1 : 0; break;
     case FL_OPT_JACOBI_KCHUNK:   g_rt.opt_jacobi_kchunk = value < 0 ? 0 : value; break;

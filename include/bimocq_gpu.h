@@ -241,8 +241,9 @@ void *fl_compute_stream(void);
 
 enum {
     FL_OPT_RESIDUAL_STRIDE = 1, /* evaluate Jacobi residual norms every k-th iterate (default 0)  */
-    FL_OPT_SKIP_UNIT_BLEND = 2, /* gpu_advect_*_double with blend==1: write field+0 instead of
-                                   evaluating prev (exact for finite prev; default 1)              */
+    FL_OPT_SKIP_UNIT_BLEND = 2, /* gpu_advect_*_double with blend==1 (field*1 + 0*prev): 1 (default) = no launch, the
+                                   values cannot change for finite prev; 2 = one-pass field+0 kernel (turns -0
+                                   into +0 like the reference); 0 = the full two-level kernel               */
     FL_OPT_JACOBI_VARIANT  = 3, /* 0 = auto, 1 = generic scalar kernel, 2 = LDS-tiled kernel      */
     FL_OPT_PROFILE_JACOBI  = 4, /* record a hipEvent pair around each projection's sweep loop      */
     FL_OPT_JACOBI_KCHUNK   = 5, /* planes marched per block in the tiled kernel (0 = auto)         */

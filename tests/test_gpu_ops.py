@@ -108,7 +108,7 @@ def test_advect_double(gm, ni, nj, nk, h, blend):
     oracle().orc_advect_vel_double(*map(fp, ref), *map(fp, vel), *map(fp, back), *map(fp, backp),
                                    h, ni, nj, nk, 0, blend)
     m = gm(ni, nj, nk, h)
-    for skip in (1, 0):                    # unit-blend fast path and the full kernel must agree
+    for skip in (1, 2, 0):                 # no launch, the field+0 kernel and the full kernel must agree
         bq.hip_lib().fl_set_option(bq._lib.FL_OPT_SKIP_UNIT_BLEND, skip)
         d = dev(*cur)
         m.advectVelocityDouble(*d, *dev(*vel), *dev(*back), *dev(*backp), False, blend)
