@@ -428,8 +428,14 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     const bool policy1 = reinit_policy == 1;
     trace_stage(*this, "advect", framenum);
 
+    // Dead state: what :213-214 accumulates into *Init before a re-initialisation moves to *Prev (:503-511), and *Prev
+    // is read by the two-level advection only when blend != 1 (Mapping.cpp:383-390).  With blend == 1 and a
+    // re-initialisation every frame (the reference's GPU solver) nothing ever reads it: the force delta, its
+    // snapshot and that accumulation are not executed (BQ_OPT_FULL_STATE = 1 executes them; every field a caller
+    // can observe is the same either way, tests/test_gpu_solver.py).
+    const bool prev_dead = !keep_full_state && reinit_policy == 0 && VelocityAdvector.BlendCoeff == 1.f;
     // :157-159
-    VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
+    if (!prev_dead) { VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW); }
     // policy 1 follows the CPU solver (BimocqSolver.cpp:129-133): scalar snapshots BEFORE the sources act
     if (policy1) { DensityTemp.copy_from(Density); TemperatureTemp.copy_from(Temperature); }
 
@@ -454,14 +460,18 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     // difference nor its look-up is executed for u and w then.
     bool forces_touch_uw = Viscosity != 0.f;
     for (const Emitter &e : sim_emitter) forces_touch_uw = forces_touch_uw || framenum < e.emitFrame;
-    if (forces_touch_uw) {
+    if (prev_dead) {
+        // nothing: d*Extern only feeds the accumulation that is dead
+    } else if (forces_touch_uw) {
         gs.addFields(duExtern, VelocityU, VelocityUTemp, -1.f, g.nu());
         gs.addFields(dwExtern, VelocityW, VelocityWTemp, -1.f, g.nw());
         gs.produced(duExtern, std::min(VelocityU.valid, VelocityUTemp.valid));
         gs.produced(dwExtern, std::min(VelocityW.valid, VelocityWTemp.valid));
     }
-    gs.addFields(dvExtern, VelocityV, VelocityVTemp, -1.f, g.nv());
-    gs.produced(dvExtern, std::min(VelocityV.valid, VelocityVTemp.valid));
+    if (!prev_dead) {
+        gs.addFields(dvExtern, VelocityV, VelocityVTemp, -1.f, g.nv());
+        gs.produced(dvExtern, std::min(VelocityV.valid, VelocityVTemp.valid));
+    }
     // :179-181
     VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
 
@@ -502,8 +512,9 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     }
 
     // :213-214
-    VelocityAdvector.accumulateVelocity2(VelocityUInit, VelocityVInit, VelocityWInit,
-                                         duExtern, dvExtern, dwExtern, 1.f, duProj, dvProj, dwProj, proj_coeff, !forces_touch_uw);
+    if (!prev_dead)
+        VelocityAdvector.accumulateVelocity2(VelocityUInit, VelocityVInit, VelocityWInit,
+                                             duExtern, dvExtern, dwExtern, 1.f, duProj, dvProj, dwProj, proj_coeff, !forces_touch_uw);
     if (policy1) {                                       // BimocqSolver.cpp:191-192 (:215-216 here adds zeros)
         ScalarAdvector.accumulateField(DensityInit, DensityExtern);
         ScalarAdvector.accumulateField(TemperatureInit, TemperatureExtern);

@@ -58,6 +58,7 @@ public:
     long dump(unsigned frame, const std::string &filepath) { return outputResult(frame, filepath); }
 
     // projection variant (compile-time `#if` in the reference, BimocqGPUSolver.cpp:408-466)
+    bool  keep_full_state = false;      // BQ_OPT_FULL_STATE: also compute state nothing reads (see advanceBimocq)
     int   reinit_policy = 0;            // BQ_OPT_REINIT_POLICY
     bool  setReinitPolicy(int policy);
     int   vel_reinits = 0, scalar_reinits = 0;

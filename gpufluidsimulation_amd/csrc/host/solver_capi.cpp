@@ -88,6 +88,8 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
     if (option == BQ_OPT_KEEP_DMC_BORDER) {
         s->solver->VelocityAdvector.keepDmcBorder = value != 0;
         s->solver->ScalarAdvector.keepDmcBorder = value != 0;
+    } else if (option == BQ_OPT_FULL_STATE) {
+        s->solver->keep_full_state = value != 0;
     } else if (option == BQ_OPT_REINIT_POLICY) {
         s->solver->setReinitPolicy(value);
         s->solver->ScalarAdvector.keepDmcBorder = s->solver->VelocityAdvector.keepDmcBorder;

@@ -63,7 +63,12 @@ enum {
      * frames, scalar maps above 5 or after 30 frames; the scalar snapshots are taken before the sources act
      * so that emission reaches DensityInit through the accumulation.  Set before the first advance().
      * Single GPU only. */
-    BQ_OPT_REINIT_POLICY = 2
+    BQ_OPT_REINIT_POLICY = 2,
+    /* 0 (default): state that nothing can read is not computed -- with blend == 1 and a re-initialisation every
+     * frame the *Prev fields are never sampled, so the pre-reinit accumulation into *Init (which only survives as
+     * *Prev) and the force delta feeding it are skipped.  1: execute the reference's full sequence.  Every field
+     * reachable through this API, and every dump, is identical either way. */
+    BQ_OPT_FULL_STATE = 3
 };
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
  * last step measured (policy 1; 0 otherwise) */

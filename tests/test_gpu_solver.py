@@ -241,3 +241,21 @@ def test_async_dump_overlaps_next_step(tmp_path):
     fa, fb = os.path.join(a, "density_render_0003.bqd"), os.path.join(b, "density_render_0003.bqd")
     assert open(fa, "rb").read() == open(fb, "rb").read()
     s.close()
+
+
+def test_dead_state_elision_changes_no_observable_field():
+    """blend == 1 + re-initialisation every frame: the pre-reinit accumulation only survives in the *Prev fields,
+    which nothing samples; the default skips it, BQ_OPT_FULL_STATE = 1 executes it -- every field and the
+    oracle (which always executes it) agree bit for bit"""
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    n = 32
+    em = [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 2)]
+    o = OracleSolver(n, n, n, 1.0, 0.0, 1.0); o.set_smoke(0.0, 1.0, em); o.set_projection(30, 0.5)
+    a = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0); a.setSmoke(0.0, 1.0, em); a.setProjection(30, 0.5)
+    b = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0); b.setSmoke(0.0, 1.0, em); b.setProjection(30, 0.5); b.setOption(3, 1)
+    for f in range(6):
+        o.advance(f, 2.0 / n); a.advance(f, 2.0 / n); b.advance(f, 2.0 / n)
+        for name in FIELDS:
+            assert F.same(o.field(name), a.field(name)), (f, name)
+            assert F.same(o.field(name), b.field(name)), (f, name)
+    a.close(); b.close(); o.close()
