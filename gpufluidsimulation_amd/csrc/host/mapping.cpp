@@ -326,8 +326,11 @@ void MapperBaseGPU::reinitializeMapping()
     MapSet &m = *maps;
     TotalReinitCount++;
     m.BackwardXPrev.swap(m.BackwardX); m.BackwardYPrev.swap(m.BackwardY); m.BackwardZPrev.swap(m.BackwardZ);
-    m.BackwardX.copy_from(m.InitX); m.BackwardY.copy_from(m.InitY); m.BackwardZ.copy_from(m.InitZ);
-    m.ForwardX.copy_from(m.InitX); m.ForwardY.copy_from(m.InitY); m.ForwardZ.copy_from(m.InitZ);
+    // the two identity refills (:438-443 copy Init*): written by the same kernel that filled Init*, which costs
+    // a write instead of a read and a write per array
+    gpu_init_maps(m.BackwardX, m.BackwardY, m.BackwardZ, g.h, g.ni, g.nj, g.nk);
+    gpu_init_maps(m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk);
+    gpuSolver->producedAll({ &m.BackwardX, &m.BackwardY, &m.BackwardZ, &m.ForwardX, &m.ForwardY, &m.ForwardZ }, DeviceField::kAlwaysValid);
     m.DbackPrev = m.Dback;
     m.Dback = 0;
     m.Dfwd = 0;
