@@ -125,8 +125,9 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
+    force_fail = os.environ.get("BENCH_FORCE_RCCL_FAILURE") == "1"      # test hook for the fallback below
     if local_rank >= torch.cuda.device_count():
-        if args.transport != "host":
+        if args.transport != "host" and not force_fail:
             sys.exit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
         local_rank %= torch.cuda.device_count()         # debug transport: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
@@ -134,9 +135,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.transport == "rccl":
+        if args.transport == "rccl" and not force_fail:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
+        else:                                   # (the fallback test hook shares one GPU: no NCCL group possible)
             dist.init_process_group("gloo")
 
     import gpufluidsimulation_amd as bq
@@ -149,9 +150,33 @@ def main():
     # N > 1: weak scaling -- the grid grows along z, n x n x (n*N), one z-slab of n planes per GPU, one
     # source per slab (same work everywhere); N = 1 is exactly BASELINE's n^3 workload
     keep = None
+    side = None                                 # gloo side channel: agreement on the transport, fallback exchange
     if world > 1:
         if args.transport == "rccl":
-            transport.init_rccl(lib, dist)
+            # RCCL neighbour exchange is the product path.  If its set-up fails on any rank (binding self-test,
+            # unique id, communicator), all ranks agree over gloo to fall back to the host-staged transport, so that
+            # a broken fabric yields a slow, clearly labelled number instead of none.
+            side = dist.new_group(backend="gloo")
+            failure = ""
+            try:
+                if force_fail:
+                    raise RuntimeError("BENCH_FORCE_RCCL_FAILURE=1")
+                if lib.fl_comm_selftest() != 0:
+                    raise RuntimeError(lib.fl_last_error_string().decode(errors="replace"))
+                transport.init_rccl(lib, dist)
+            except Exception as e:              # noqa: BLE001 -- any set-up failure takes the same exit
+                failure = str(e) or type(e).__name__
+            ok = torch.tensor([0 if failure else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=side)
+            if int(ok.item()) == 0:
+                if rank == 0:
+                    print(f"[bench] RCCL set-up failed ({failure or 'on another rank'}); falling back to the host-staged "
+                          f"transport over gloo", file=sys.stderr, flush=True)
+                lib.fl_comm_destroy()
+                lib.fl_clear_error()
+                keep = transport.HostStagedTransport(lib, dist, group=side)
+                args.transport = "host"
+                args.transport_note = "host-staged over gloo (FALLBACK: RCCL set-up failed)"
         else:
             keep = transport.HostStagedTransport(lib, dist)
         s = BimocqGPUSolver(n, n, n * world, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
@@ -172,7 +197,7 @@ def main():
         lib.fl_sync()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=side) if (side is not None and args.transport == "host") else dist.barrier()
         lib.fl_sync()
 
     frame = 0
@@ -204,7 +229,7 @@ def main():
     lib.fl_jacobi_profile(C.byref(ms), C.byref(launches), C.byref(sweeps))
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.transport == "rccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=side if (side is not None and args.transport == "host") else None)
         el = float(t.item())
 
     voxels = n ** 3 * world                     # weak scaling: every rank advances its own n^3 grid
@@ -221,7 +246,8 @@ def main():
                                + f"halfrdx {args.halfrdx}, reinit every step",
                    "grid_per_gpu": [n, n, n], "global_grid": [n, n, n * world], "dt": dt,
                    "parallelism": "1 GPU" if world == 1 else
-                   f"{world} z-slabs of {n} planes, {args.ghost} ghost planes, neighbour exchange over {args.transport}"},
+                   f"{world} z-slabs of {n} planes, {args.ghost} ghost planes, neighbour exchange over "
+                   + getattr(args, "transport_note", args.transport)},
     }
     line["extra"] = {"dead_state_elision": {"value": round(n ** 3 * world * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
                                             "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
@@ -263,7 +289,7 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     s.close()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=side) if (side is not None and args.transport == "host") else dist.barrier()
         lib.fl_comm_destroy()
         dist.destroy_process_group()
     if rank == 0:
