@@ -288,7 +288,11 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 // Preconditions (checked by the launcher): nx <= 256 (a row fits one wave; x-neighbours by shuffle)
 // and both ping-pong buffers carry the same boundary layer (gpu_projection_jacobi's contract: the
 // caller zeroes both), because boundary cells are never written and L1's boundary is taken from L0.
-template <int WAVES>
+// WIDE: a row spans several waves (nx > 256 floats).  x-neighbours across a wave boundary cannot be shuffled:
+// lane 0 / lane 63 fetch the L0 values of the cell just outside the wave from memory and evaluate the single L1
+// value there themselves (a few one-lane loads per plane; no LDS, no barrier) -- the same scheme as the fp64
+// smoother mg_smooth2_kernel (bq_mgcg.hip).
+template <int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                    float *__restrict__ out, int nx, int ny, int nz,
                                                                    int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
@@ -318,11 +322,26 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     auto plane = [&](int pl) -> size_t { return sk * (size_t)min(max(pl, 0), nz - 1); };
     auto ld4 = [&](const float *ptr, size_t off) -> float4 { return *reinterpret_cast<const float4 *>(ptr + off); };
     const bool rowb_m1 = j - 1 <= 0 || j - 1 >= ny - 1, rowb_0 = j <= 0 || j >= ny - 1, rowb_p1 = j + 1 <= 0 || j + 1 >= ny - 1;
+    // edge lanes (WIDE): lane 0 looks after the cell just left of the wave, lane 63 after the cell just right of it
+    const int lane = threadIdx.x & 63;
+    const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 4 < nx;
+    const bool edge = edgeL || edgeR;
+    const int xe = edgeL ? xraw - 1 : xraw + 4;                        // the outside cell
+    const int xo = edgeL ? xe - 1 : xe + 1;                            // its own outer x-neighbour
+    const size_t e_m1 = (size_t)min(max(xe, 0), nx - 1) + sj * (size_t)min(max(j - 1, 0), ny - 1),
+                 e_0 = (size_t)min(max(xe, 0), nx - 1) + sj * (size_t)min(max(j, 0), ny - 1),
+                 e_p1 = (size_t)min(max(xe, 0), nx - 1) + sj * (size_t)min(max(j + 1, 0), ny - 1),
+                 e_o = (size_t)min(max(xo, 0), nx - 1) + sj * (size_t)min(max(j, 0), ny - 1);
+    const bool xe_boundary = xe <= 0 || xe >= nx - 1;
 
-    // one Jacobi evaluation on a float4; ce = centre row (x-neighbours from the neighbouring lanes), fr/bk = rows
-    // -+1, dn/up = planes -+1.  Boundary cells keep the input value.
-    auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, bool boundary) -> float4 {
-        const float left = lane_up(ce.w), right = lane_down(ce.x);
+    // one Jacobi evaluation on a float4; ce = centre row (x-neighbours from the neighbouring lanes, or `outside`
+    // at a wave edge), fr/bk = rows -+1, dn/up = planes -+1.  Boundary cells keep the input value.
+    auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, float outside, bool boundary) -> float4 {
+        float left = lane_up(ce.w), right = lane_down(ce.x);
+        if (WIDE) {
+            if (lane == 0) left = outside;
+            if (lane == 63) right = outside;
+        }
         float4 o;
         o.x = (left + ce.y + fr.x + bk.x + dn.x + up.x + alpha * dv.x) * beta;
         o.y = (ce.x + ce.z + fr.y + bk.y + dn.y + up.y + alpha * dv.y) * beta;
@@ -351,6 +370,14 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     float4 Mc[3] = { zero4, zero4, zero4 };     // L1 on plane q-1
     float4 Mm = zero4;                          // L1 of row j on plane q-2
     float4 Dprev = zero4;                       // div of row j on plane q-1
+    // the outside cell (edge lanes, WIDE only): L0 on rows j-1..j+1 at plane q (Ec), on row j at planes q-1 (Em) and
+    // q+1 (En), its outer x-neighbour at plane q (Eo), its div (Eb); Xp: its L1 on row j, plane q-1
+    float Ec[3] = { 0.f, 0.f, 0.f }, Em = 0.f, En = 0.f, Eo = 0.f, Eb = 0.f, Xp = 0.f;
+    if (edge) {
+        const size_t pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
+        Ec[0] = p[pc + e_m1]; Ec[1] = p[pc + e_0]; Ec[2] = p[pc + e_p1];
+        Em = p[pm + e_0]; En = p[pn + e_0]; Eo = p[pc + e_o]; Eb = div[pc + e_0];
+    }
 
     // one plane: Lm/Lc/Ln = L0 on planes q-1/q/q+1; on return Lm holds plane q+2 (it becomes the next "above")
     auto phase = [&](float4 (&Lm)[3], float4 (&Lc)[3], float4 (&Ln)[3]) {
@@ -359,15 +386,26 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
         La[0] = ld4(p, pa + o_m1); La[1] = ld4(p, pa + o_0); La[2] = ld4(p, pa + o_p1);
         Da[0] = ld4(div, pb + o_m1); Da[1] = ld4(div, pb + o_0); Da[2] = ld4(div, pb + o_p1);
         const float4 Hfa = ld4(p, pb + o_m2), Hba = ld4(p, pb + o_p2);
+        float E2[3] = { 0.f, En, 0.f }, En2 = 0.f, Eo2 = 0.f, Eb2 = 0.f;
+        if (edge) {
+            E2[0] = p[pb + e_m1]; E2[2] = p[pb + e_p1];
+            En2 = p[pa + e_0]; Eo2 = p[pb + e_o]; Eb2 = div[pb + e_0];
+        }
         // L1 on plane q for rows j-1, j, j+1
         const bool qb = q < kA || q >= kB;
         float4 M[3];
-        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], qb || rowb_m1);
-        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], qb || rowb_0);
-        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], qb || rowb_p1);
+        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], Ec[0], qb || rowb_m1);
+        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], Ec[1], qb || rowb_0);
+        M[2] = jac(Lc[2], Lc[1], Hb, Lm[2], Ln[2], Dv[2], Ec[2], qb || rowb_p1);
+        // L1 of the outside cell on row j, plane q (edge lanes; a boundary cell keeps L0)
+        float X = Ec[1];
+        if (edge && !(qb || rowb_0 || xe_boundary)) {
+            const float l = edgeL ? Eo : Lc[1].w, rr = edgeL ? Lc[1].x : Eo;
+            X = (l + rr + Ec[0] + Ec[2] + Em + En + alpha * Eb) * beta;
+        }
         // L2 on plane q-1 for row j
         const int k = q - 1;
-        const float4 o = jac(Mc[1], Mc[0], Mc[2], Mm, M[1], Dprev, false);
+        const float4 o = jac(Mc[1], Mc[0], Mc[2], Mm, M[1], Dprev, Xp, false);
         if (active && k >= kbeg && k < kend) {
             float *dst = out + (size_t)x + sj * j + sk * k;
             if (x >= 4 && x + 4 < nx) {
@@ -381,8 +419,10 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
         }
         Mm = Mc[1];
         Dprev = Dv[1];
+        Xp = X;
+        Em = Ec[1]; En = En2; Eo = Eo2; Eb = Eb2;
 #pragma unroll
-        for (int a = 0; a < 3; a++) { Mc[a] = M[a]; Lm[a] = La[a]; Dv[a] = Da[a]; }
+        for (int a = 0; a < 3; a++) { Mc[a] = M[a]; Lm[a] = La[a]; Dv[a] = Da[a]; Ec[a] = E2[a]; }
         Hf = Hfa; Hb = Hba;
         q++;
     };
@@ -554,16 +594,19 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     if (ni < 3 || nj < 3 || nk < 3) return false;
     const int variant = rt().opt_jacobi_variant;
     if (variant != 0 && variant != 3) return false;
-    if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
+    if (!((ni % 4 == 0) && ni >= 32 && ni <= 1024 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
     int cw = 16;
-    while (cw * 4 < ni) cw *= 2;                         // <= 64: one row per wave at most
+    while (cw * 4 < ni) cw *= 2;                         // float4 lanes per row: <= 64 one wave, 128/256 = 2/4 waves
+    const bool wide = cw > 64;
     const int rows = 256 / cw;
     const int nby = (nj + rows - 1) / rows;
-    int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 32;
+    // planes per block: 32 measured best at 256^3 (one wave per row), 64 at 512^3 (248 vs 254 us per sweep)
+    int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : (wide ? 64 : 32);
     while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
     const int nbz = (nk + kchunk - 1) / kchunk;
     // (loads two planes ahead instead of one measured no better at 256^3: 19.4 vs 19.1 us per sweep)
-    jacobi_march2_kernel<4><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
+    if (wide) jacobi_march2_kernel<4, true><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
+    else      jacobi_march2_kernel<4, false><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
     return true;
 }

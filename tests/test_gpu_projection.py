@@ -154,7 +154,8 @@ def test_projection_quarter_strength(hip):
     m.check()
 
 
-@pytest.mark.parametrize("ni,nj,nk", [(32, 32, 32), (64, 48, 40), (128, 37, 19), (256, 32, 24), (200, 20, 12), (36, 5, 3)])
+@pytest.mark.parametrize("ni,nj,nk", [(32, 32, 32), (64, 48, 40), (128, 37, 19), (256, 32, 24), (200, 20, 12), (36, 5, 3),
+                                      (512, 9, 7), (260, 20, 12), (516, 6, 5), (1024, 5, 4), (384, 10, 40)])   # rows of 2-4 waves
 @pytest.mark.parametrize("sweeps", [2, 3, 4, 9])
 def test_fused_two_sweep_kernel(hip, ni, nj, nk, sweeps):
     """jacobi_march2_kernel (two sweeps per launch) against single oracle sweeps; both ping-pong buffers
