@@ -116,6 +116,13 @@ __device__ __forceinline__ float lerp_const(float a, float b, float c, double om
     return (float)__builtin_fma(omc, (double)a, (double)cb);
 }
 
+__device__ __forceinline__ int floor_to_int(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // Cell + weights of one sample position (GPU_kernel.cu:45-51)
 struct Cell {
     unsigned base;          // byte offset of corner 000; 2 GiB (out of range) when its flat index is negative
@@ -128,8 +135,9 @@ __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off
     float qx = div_h<P2>(pos.x - off.x, sp);
     float qy = div_h<P2>(pos.y - off.y, sp);
     float qz = div_h<P2>(pos.z - off.z, sp);
-    float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
-    int i = (int)flx, j = (int)fly, k = (int)flz;
+    // int(floorf(q)) (GPU_kernel.cu:47-49) in one instruction: v_cvt_flr_i32_f32 converts with round-toward-minus-
+    // infinity, which is floor followed by the (exact) conversion for every |q| < 2^31
+    const int i = floor_to_int(qx), j = floor_to_int(qy), k = floor_to_int(qz);
     Cell c;
     c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k;
     int idx = i + f.nx * j + f.nx * f.ny * (k - f.koff);
