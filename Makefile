@@ -28,8 +28,13 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_host.h include/b
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(PKG)/libbimocq_hip.so: $(KERNEL_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(KERNEL_OBJS) $(RCCL_LIB)
+# the gather kernels a second time with one-fma lerps (bq_device.hip.h: inline namespace bq::fast, entry points *_fast)
+$(OBJDIR)/bq_advect_fast.o: $(CSRC)/bq_advect.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DBQ_FAST_LERP -c $< -o $@
+
+$(PKG)/libbimocq_hip.so: $(KERNEL_OBJS) $(OBJDIR)/bq_advect_fast.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(KERNEL_OBJS) $(OBJDIR)/bq_advect_fast.o $(RCCL_LIB)
 
 $(OBJDIR)/host_%.o: $(CSRC)/host/%.cpp $(wildcard $(CSRC)/host/*.hpp) include/bimocq_gpu.h include/bimocq_solver.h
 	@mkdir -p $(OBJDIR)

@@ -225,6 +225,17 @@ def main():
         frame += 1
     barrier()
     el_extra = time.perf_counter() - t1
+    # ... and with the fast arithmetic variant on top (FL_OPT_FAST_LERP: one fp32 fma per lerp; within 1e-6 RMS of
+    # the exact fields after 200 steps, tests/test_gpu_solver.py::test_fast_lerp_variant) -- extra information too
+    lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 1)
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(extra_steps):
+        s.advance(frame, dt)
+        frame += 1
+    barrier()
+    el_fast = time.perf_counter() - t2
+    lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
     ms, launches, sweeps = C.c_double(0.0), C.c_longlong(0), C.c_longlong(0)
     lib.fl_jacobi_profile(C.byref(ms), C.byref(launches), C.byref(sweeps))
     if dist is not None:
@@ -253,7 +264,12 @@ def main():
                                             "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
                                             "note": "library default: with blend == 1 and a re-initialisation every frame the "
                                                     "*Prev fields are never read, so the accumulation that only feeds them is "
-                                                    "skipped; every observable field is identical (DESIGN.md section 3)"}}
+                                                    "skipped; every observable field is identical (DESIGN.md section 3)"},
+                     "fast_lerp_variant": {"value": round(n ** 3 * world * extra_steps / el_fast / 1e6, 2), "unit": "Mvoxels/s",
+                                           "ms_per_step": round(el_fast / extra_steps * 1e3, 3), "steps": extra_steps,
+                                           "note": "FL_OPT_FAST_LERP = 1 on top of the elision: every lerp of the gather kernels is "
+                                                   "one fp32 fma; NOT bit-identical to the reference arithmetic, within 1e-6 RMS "
+                                                   "after 200 steps (tolerance 1e-5; DESIGN.md section 12)"}}
     if launches.value > 0 and mg:
         # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_smooth2_kernel:
         # 24 B/cell/sweep (x, rhs in, x' out)

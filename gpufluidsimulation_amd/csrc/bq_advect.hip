@@ -10,6 +10,7 @@
 #include <type_traits>
 
 namespace bq {
+inline namespace BQ_VARIANT {
 
 #define BQ_IJK(nbi, nbj, nbk)                                   \
     const int i = blockIdx.x * 64 + threadIdx.x;                \
@@ -565,9 +566,23 @@ static void clamp_box(const float *before, float *after, int ni, int nj, int nk,
     BQ_LAUNCH_CHECK("clamp_box_kernel");
 }
 
+} // inline namespace BQ_VARIANT
 } // namespace bq
 
 using namespace bq;
+
+// Entry points of this file exist twice in the library: this translation unit is compiled once as is (exact
+// arithmetic, the C-ABI names) and once with -DBQ_FAST_LERP (names suffixed _fast).  The exact build's entry
+// point forwards to its _fast twin when FL_OPT_FAST_LERP is set.
+#ifdef BQ_FAST_LERP
+#define BQ_ENTRY(name, params, args) void name##_fast params
+#else
+#define BQ_ENTRY(name, params, args)                                                     \
+    void name##_fast params;                                                             \
+    static void name##_impl params;                                                      \
+    void name params { if (rt().opt_fast_lerp) { name##_fast args; return; } name##_impl args; } \
+    static void name##_impl params
+#endif
 
 #define BQ_ENTER(op, ...)                                                  \
     if (!ensure_ready(op)) return;                                         \
@@ -580,8 +595,8 @@ using namespace bq;
 
 extern "C" {
 
-void gpu_solve_forward(float *u, float *v, float *w, float *x_fwd, float *y_fwd, float *z_fwd,
-                       float h, int ni, int nj, int nk, float cfldt, float dt)
+BQ_ENTRY(gpu_solve_forward, (float *u, float *v, float *w, float *x_fwd, float *y_fwd, float *z_fwd,
+                       float h, int ni, int nj, int nk, float cfldt, float dt), (u, v, w, x_fwd, y_fwd, z_fwd, h, ni, nj, nk, cfldt, dt))
 {
     BQ_ENTER("gpu_solve_forward", u, v, w, x_fwd, y_fwd, z_fwd)
     BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_solve_forward");     // cfldt <= 0 would never terminate
@@ -589,9 +604,9 @@ void gpu_solve_forward(float *u, float *v, float *w, float *x_fwd, float *y_fwd,
     BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt);
 }
 
-void gpu_solve_backwardDMC(float *u, float *v, float *w, float *x_in, float *y_in, float *z_in,
+BQ_ENTRY(gpu_solve_backwardDMC, (float *u, float *v, float *w, float *x_in, float *y_in, float *z_in,
                            float *x_out, float *y_out, float *z_out,
-                           float h, int ni, int nj, int nk, float substep)
+                           float h, int ni, int nj, int nk, float substep), (u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, h, ni, nj, nk, substep))
 {
     BQ_ENTER("gpu_solve_backwardDMC", u, v, w, x_in, y_in, z_in, x_out, y_out, z_out)
     BQ_REQUIRE(x_in != x_out && y_in != y_out && z_in != z_out, "gpu_solve_backwardDMC");
@@ -599,9 +614,9 @@ void gpu_solve_backwardDMC(float *u, float *v, float *w, float *x_in, float *y_i
     BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep);
 }
 
-void gpu_advect_velocity(float *u, float *v, float *w, float *u_init, float *v_init, float *w_init,
+BQ_ENTRY(gpu_advect_velocity, (float *u, float *v, float *w, float *u_init, float *v_init, float *w_init,
                          float *backward_x, float *backward_y, float *backward_z,
-                         float h, int ni, int nj, int nk, bool is_point)
+                         float h, int ni, int nj, int nk, bool is_point), (u, v, w, u_init, v_init, w_init, backward_x, backward_y, backward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_advect_velocity", u, v, w, u_init, v_init, w_init, backward_x, backward_y, backward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -610,10 +625,10 @@ void gpu_advect_velocity(float *u, float *v, float *w, float *u_init, float *v_i
     advect_comp(w, w_init, backward_x, backward_y, backward_z, sp, g, 0, 0, 1, is_point);
 }
 
-void gpu_advect_vel_double(float *u, float *v, float *w, float *utemp, float *vtemp, float *wtemp,
+BQ_ENTRY(gpu_advect_vel_double, (float *u, float *v, float *w, float *utemp, float *vtemp, float *wtemp,
                            float *backward_x, float *backward_y, float *backward_z,
                            float *backward_xprev, float *backward_yprev, float *backward_zprev,
-                           float h, int ni, int nj, int nk, bool is_point, float blend_coeff)
+                           float h, int ni, int nj, int nk, bool is_point, float blend_coeff), (u, v, w, utemp, vtemp, wtemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, h, ni, nj, nk, is_point, blend_coeff))
 {
     BQ_ENTER("gpu_advect_vel_double", u, v, w, utemp, vtemp, wtemp, backward_x, backward_y, backward_z,
              backward_xprev, backward_yprev, backward_zprev)
@@ -623,17 +638,17 @@ void gpu_advect_vel_double(float *u, float *v, float *w, float *utemp, float *vt
     double_comp(w, wtemp, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 1, is_point, blend_coeff);
 }
 
-void gpu_advect_field(float *field, float *field_init, float *backward_x, float *backward_y, float *backward_z,
-                      float h, int ni, int nj, int nk, bool is_point)
+BQ_ENTRY(gpu_advect_field, (float *field, float *field_init, float *backward_x, float *backward_y, float *backward_z,
+                      float h, int ni, int nj, int nk, bool is_point), (field, field_init, backward_x, backward_y, backward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_advect_field", field, field_init, backward_x, backward_y, backward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     advect_comp(field, field_init, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point);
 }
 
-void gpu_advect_field_double(float *field, float *field_prev, float *backward_x, float *backward_y, float *backward_z,
+BQ_ENTRY(gpu_advect_field_double, (float *field, float *field_prev, float *backward_x, float *backward_y, float *backward_z,
                              float *backward_xprev, float *backward_yprev, float *backward_zprev,
-                             float h, int ni, int nj, int nk, bool is_point, float blend_coeff)
+                             float h, int ni, int nj, int nk, bool is_point, float blend_coeff), (field, field_prev, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, h, ni, nj, nk, is_point, blend_coeff))
 {
     BQ_ENTER("gpu_advect_field_double", field, field_prev, backward_x, backward_y, backward_z,
              backward_xprev, backward_yprev, backward_zprev)
@@ -641,10 +656,10 @@ void gpu_advect_field_double(float *field, float *field_prev, float *backward_x,
     double_comp(field, field_prev, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 0, is_point, blend_coeff);
 }
 
-void gpu_accumulate_velocity(float *u_change, float *v_change, float *w_change,
+BQ_ENTRY(gpu_accumulate_velocity, (float *u_change, float *v_change, float *w_change,
                              float *du_init, float *dv_init, float *dw_init,
                              float *forward_x, float *forward_y, float *forward_z,
-                             float h, int ni, int nj, int nk, bool is_point, float coeff)
+                             float h, int ni, int nj, int nk, bool is_point, float coeff), (u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point, coeff))
 {
     BQ_ENTER("gpu_accumulate_velocity", u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -653,8 +668,8 @@ void gpu_accumulate_velocity(float *u_change, float *v_change, float *w_change,
     cumulate_comp(w_change, dw_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, coeff);
 }
 
-void gpu_accumulate_field(float *field_change, float *dfield_init, float *forward_x, float *forward_y, float *forward_z,
-                          float h, int ni, int nj, int nk, bool is_point, float coeff)
+BQ_ENTRY(gpu_accumulate_field, (float *field_change, float *dfield_init, float *forward_x, float *forward_y, float *forward_z,
+                          float h, int ni, int nj, int nk, bool is_point, float coeff), (field_change, dfield_init, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point, coeff))
 {
     BQ_ENTER("gpu_accumulate_field", field_change, dfield_init, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -662,27 +677,27 @@ void gpu_accumulate_field(float *field_change, float *dfield_init, float *forwar
 }
 
 // ---- batched / shortcut forms of the entry points above (additive; same arithmetic) ----------------
-void gpu_advect_field2(float *field1, float *field1_init, float *field2, float *field2_init,
+BQ_ENTRY(gpu_advect_field2, (float *field1, float *field1_init, float *field2, float *field2_init,
                        float *backward_x, float *backward_y, float *backward_z,
-                       float h, int ni, int nj, int nk, bool is_point)
+                       float h, int ni, int nj, int nk, bool is_point), (field1, field1_init, field2, field2_init, backward_x, backward_y, backward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_advect_field2", field1, field1_init, field2, field2_init, backward_x, backward_y, backward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     advect_multi<2>(AdvectArgs<2>{{field1, field2}, {field1_init, field2_init}}, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point);
 }
 
-void gpu_compensate_error_field2(float *u1, float *du1, float *u1_src, float *u2, float *du2, float *u2_src,
+BQ_ENTRY(gpu_compensate_error_field2, (float *u1, float *du1, float *u1_src, float *u2, float *du2, float *u2_src,
                                  float *forward_x, float *forward_y, float *forward_z,
-                                 float h, int ni, int nj, int nk, bool is_point)
+                                 float h, int ni, int nj, int nk, bool is_point), (u1, du1, u1_src, u2, du2, u2_src, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_compensate_error_field2", u1, du1, u1_src, u2, du2, u2_src, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     compensate_multi<2>(CompensateArgs<2>{{u1, u2}, {du1, du2}, {u1_src, u2_src}}, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point);
 }
 
-void gpu_accumulate_field2(float *change1, float *dinit1, float coeff1, float *change2, float *dinit2, float coeff2,
+BQ_ENTRY(gpu_accumulate_field2, (float *change1, float *dinit1, float coeff1, float *change2, float *dinit2, float coeff2,
                            float *forward_x, float *forward_y, float *forward_z,
-                           float h, int ni, int nj, int nk, bool is_point)
+                           float h, int ni, int nj, int nk, bool is_point), (change1, dinit1, coeff1, change2, dinit2, coeff2, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_accumulate_field2", change1, dinit1, change2, dinit2, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -691,11 +706,11 @@ void gpu_accumulate_field2(float *change1, float *dinit1, float coeff1, float *c
 
 // du_init += blend9(coeff1 * change1(psi(x))), then += blend9(coeff2 * change2(psi(x))): two
 // gpu_accumulate_velocity calls with one map look-up
-void gpu_accumulate_velocity2(float *u_change1, float *v_change1, float *w_change1, float coeff1,
+BQ_ENTRY(gpu_accumulate_velocity2, (float *u_change1, float *v_change1, float *w_change1, float coeff1,
                               float *u_change2, float *v_change2, float *w_change2, float coeff2,
                               float *du_init, float *dv_init, float *dw_init,
                               float *forward_x, float *forward_y, float *forward_z,
-                              float h, int ni, int nj, int nk, bool is_point)
+                              float h, int ni, int nj, int nk, bool is_point), (u_change1, v_change1, w_change1, coeff1, u_change2, v_change2, w_change2, coeff2, du_init, dv_init, dw_init, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_accumulate_velocity2", u_change1, v_change1, w_change1, u_change2, v_change2, w_change2,
              du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
@@ -708,9 +723,9 @@ void gpu_accumulate_velocity2(float *u_change1, float *v_change1, float *w_chang
 // One velocity component of gpu_accumulate_velocity (axis 0/1/2 = u/v/w) with one or two sources:
 //   d_init += blend9(coeff1 * change1(psi(x))) [ ; += blend9(coeff2 * change2(psi(x))) when change2 != NULL ]
 // lets a host skip a component's source that is known to be identically zero.
-void gpu_accumulate_component(float *change1, float coeff1, float *change2, float coeff2, float *d_init,
+BQ_ENTRY(gpu_accumulate_component, (float *change1, float coeff1, float *change2, float coeff2, float *d_init,
                               float *forward_x, float *forward_y, float *forward_z,
-                              float h, int ni, int nj, int nk, int axis, bool is_point)
+                              float h, int ni, int nj, int nk, int axis, bool is_point), (change1, coeff1, change2, coeff2, d_init, forward_x, forward_y, forward_z, h, ni, nj, nk, axis, is_point))
 {
     BQ_ENTER("gpu_accumulate_component", change1, d_init, forward_x, forward_y, forward_z)
     BQ_REQUIRE(axis >= 0 && axis <= 2, "gpu_accumulate_component");
@@ -726,10 +741,10 @@ void gpu_accumulate_component(float *change1, float coeff1, float *change2, floa
 // gpu_accumulate_velocity for a forward map that IS the identity map of gpu_init_maps (right after a
 // re-initialisation): the caller vouches for that; the map buffers are still passed and are read on every
 // path without the shortcut (spacing not a power of two, FL_OPT_STRUCTURED_MAPS off).
-void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w_change,
+BQ_ENTRY(gpu_accumulate_velocity_identity, (float *u_change, float *v_change, float *w_change,
                                       float *du_init, float *dv_init, float *dw_init,
                                       float *forward_x, float *forward_y, float *forward_z,
-                                      float h, int ni, int nj, int nk, bool is_point, float coeff)
+                                      float h, int ni, int nj, int nk, bool is_point, float coeff), (u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point, coeff))
 {
     BQ_ENTER("gpu_accumulate_velocity_identity", u_change, v_change, w_change, du_init, dv_init, dw_init, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -738,19 +753,19 @@ void gpu_accumulate_velocity_identity(float *u_change, float *v_change, float *w
     cumulate_comp(w_change, dw_init, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point, coeff, true);
 }
 
-void gpu_estimate_distortion(float *du, float *x_init, float *y_init, float *z_init,
-                             float *x_fwd, float *y_fwd, float *z_fwd, float h, int ni, int nj, int nk)
+BQ_ENTRY(gpu_estimate_distortion, (float *du, float *x_init, float *y_init, float *z_init,
+                             float *x_fwd, float *y_fwd, float *z_fwd, float h, int ni, int nj, int nk), (du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd, h, ni, nj, nk))
 {
     BQ_ENTER("gpu_estimate_distortion", du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     BQ_DISPATCH1(estimate_kernel, sp.pow2, grid_for(ni, nj, nk), du, x_init, y_init, z_init, x_fwd, y_fwd, z_fwd, sp, g);
 }
 
-void gpu_compensate_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+BQ_ENTRY(gpu_compensate_velocity, (float *u, float *v, float *w, float *du, float *dv, float *dw,
                              float *u_src, float *v_src, float *w_src,
                              float *forward_x, float *forward_y, float *forward_z,
                              float *backward_x, float *backward_y, float *backward_z,
-                             float h, int ni, int nj, int nk, bool is_point)
+                             float h, int ni, int nj, int nk, bool is_point), (u, v, w, du, dv, dw, u_src, v_src, w_src, forward_x, forward_y, forward_z, backward_x, backward_y, backward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_compensate_velocity", u, v, w, du, dv, dw, u_src, v_src, w_src,
              forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
@@ -774,10 +789,10 @@ void gpu_compensate_velocity(float *u, float *v, float *w, float *du, float *dv,
     clamp_box(dw, w, ni, nj, nk + 1, 1);
 }
 
-void gpu_compensate_field(float *u, float *du, float *u_src,
+BQ_ENTRY(gpu_compensate_field, (float *u, float *du, float *u_src,
                           float *forward_x, float *forward_y, float *forward_z,
                           float *backward_x, float *backward_y, float *backward_z,
-                          float h, int ni, int nj, int nk, bool is_point)
+                          float h, int ni, int nj, int nk, bool is_point), (u, du, u_src, forward_x, forward_y, forward_z, backward_x, backward_y, backward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_compensate_field", u, du, u_src, forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -787,8 +802,8 @@ void gpu_compensate_field(float *u, float *du, float *u_src,
     clamp_box(du, u, ni, nj, nk, 0);
 }
 
-void gpu_semilag(float *field, float *field_src, float *u, float *v, float *w,
-                 int dim_x, int dim_y, int dim_z, float h, int ni, int nj, int nk, float cfldt, float dt)
+BQ_ENTRY(gpu_semilag, (float *field, float *field_src, float *u, float *v, float *w,
+                 int dim_x, int dim_y, int dim_z, float h, int ni, int nj, int nk, float cfldt, float dt), (field, field_src, u, v, w, dim_x, dim_y, dim_z, h, ni, nj, nk, cfldt, dt))
 {
     BQ_ENTER("gpu_semilag", field, field_src, u, v, w)
     BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_semilag");
@@ -797,9 +812,9 @@ void gpu_semilag(float *field, float *field_src, float *u, float *v, float *w,
     BQ_DISPATCH1(semilag_kernel, sp.pow2, grid_for(ni + dim_x, nj + dim_y, nk + dim_z), field, field_src, u, v, w, sp, g, dim_x, dim_y, dim_z, cfldt, dt);
 }
 
-void gpu_clamp_extrema(float *field, float *fieldTemp, float *u, float *v, float *w,
+BQ_ENTRY(gpu_clamp_extrema, (float *field, float *fieldTemp, float *u, float *v, float *w,
                        int ni, int nj, int nk, int dimx, int dimy, int dimz,
-                       float ox, float oy, float oz, float h, float dt)
+                       float ox, float oy, float oz, float h, float dt), (field, fieldTemp, u, v, w, ni, nj, nk, dimx, dimy, dimz, ox, oy, oz, h, dt))
 {
     BQ_ENTER("gpu_clamp_extrema", field, fieldTemp, u, v, w)
     BQ_REQUIRE(field != fieldTemp && ((dimx | dimy | dimz) == 0 || (dimx + dimy + dimz) == 1) &&
@@ -810,22 +825,22 @@ void gpu_clamp_extrema(float *field, float *fieldTemp, float *u, float *v, float
                  dimx, dimy, dimz, ox, oy, oz, dt);
 }
 
-void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk)
+BQ_ENTRY(gpu_clamp_extrema_box, (const float *before, float *after, int ni, int nj, int nk), (before, after, ni, nj, nk))
 {
     BQ_ENTER("gpu_clamp_extrema_box", before, after)
     clamp_box(before, after, ni, nj, nk, 0);
 }
 
-void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
+BQ_ENTRY(gpu_clamp_extrema_box_w, (const float *before, float *after, int ni, int nj, int nk), (before, after, ni, nj, nk))
 {
     BQ_ENTER("gpu_clamp_extrema_box_w", before, after)
     clamp_box(before, after, ni, nj, nk, 1);
 }
 
-void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
+BQ_ENTRY(gpu_compensate_error_velocity, (float *u, float *v, float *w, float *du, float *dv, float *dw,
                                    float *u_src, float *v_src, float *w_src,
                                    float *forward_x, float *forward_y, float *forward_z,
-                                   float h, int ni, int nj, int nk, bool is_point)
+                                   float h, int ni, int nj, int nk, bool is_point), (u, v, w, du, dv, dw, u_src, v_src, w_src, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_compensate_error_velocity", u, v, w, du, dv, dw, u_src, v_src, w_src, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
@@ -834,9 +849,9 @@ void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, floa
     compensate_comp(w, dw, w_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point);
 }
 
-void gpu_compensate_error_field(float *u, float *du, float *u_src,
+BQ_ENTRY(gpu_compensate_error_field, (float *u, float *du, float *u_src,
                                 float *forward_x, float *forward_y, float *forward_z,
-                                float h, int ni, int nj, int nk, bool is_point)
+                                float h, int ni, int nj, int nk, bool is_point), (u, du, u_src, forward_x, forward_y, forward_z, h, ni, nj, nk, is_point))
 {
     BQ_ENTER("gpu_compensate_error_field", u, du, u_src, forward_x, forward_y, forward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);

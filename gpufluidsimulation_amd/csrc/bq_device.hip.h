@@ -9,11 +9,25 @@
 // eight raw buffer loads + seven lerps.  Loads go through a buffer resource descriptor whose
 // num_records is the field's byte size: the hardware range check returns 0 for any corner that
 // falls outside the allocation (the oracle's `ld`), per dword, with no compare in the shader.
+//
+// Two arithmetic variants of everything in this file exist side by side in the library (inline namespaces
+// bq::exact / bq::fast, selected per translation unit by BQ_FAST_LERP): `exact` is the contract above; `fast`
+// evaluates a lerp as ONE fp32 fma, fmaf(c, b - a, a), and changes nothing else (oracle: orc_set_fast_lerp).
+// The gather kernels are bound by the issue rate of the double-evaluated lerp (4 conversions and 2 fp64
+// operations each), so `fast` is the variant SURVEY 8(d) calls for next to the exact one; it stays 3 orders
+// of magnitude inside the 1e-5 RMS tolerance over 200 steps (tests/test_gpu_solver.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
 
+#ifdef BQ_FAST_LERP
+#define BQ_VARIANT fast
+#else
+#define BQ_VARIANT exact
+#endif
+
 namespace bq {
+inline namespace BQ_VARIANT {
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
@@ -103,8 +117,13 @@ __device__ __forceinline__ f3 clamp3(f3 p, f3 lo, f3 hi)
 // GPU_kernel.cu:22-25 with the (1.0 - c) factor hoisted (it is exact to hoist: same value)
 __device__ __forceinline__ float lerp_w(float a, float b, float c, double omc)
 {
+#ifdef BQ_FAST_LERP
+    (void)omc;
+    return __builtin_fmaf(c, b - a, a);
+#else
     float cb = c * b;
     return (float)(omc * (double)a + (double)cb);
+#endif
 }
 
 // lerp with a compile-time weight c in {0, 1/4, 1/2, 3/4}: omc*a has at most 26 significant bits, so it
@@ -112,8 +131,13 @@ __device__ __forceinline__ float lerp_w(float a, float b, float c, double omc)
 // -- one f64 instruction instead of two.
 __device__ __forceinline__ float lerp_const(float a, float b, float c, double omc)
 {
+#ifdef BQ_FAST_LERP
+    (void)omc;
+    return __builtin_fmaf(c, b - a, a);
+#else
     float cb = c * b;
     return (float)__builtin_fma(omc, (double)a, (double)cb);
+#endif
 }
 
 __device__ __forceinline__ int floor_to_int(float x)
@@ -377,4 +401,5 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+} // inline namespace BQ_VARIANT
 } // namespace bq

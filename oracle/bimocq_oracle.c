@@ -49,8 +49,13 @@ static inline f3 clamp3(f3 p, f3 lo, f3 hi)
 
 /* GPU_kernel.cu:22-25: `(1.0-c)*a + c*b` -- (1.0-c) and the first product are double,
  * c*b is a float product, the sum is double, the return rounds to float. */
+static int g_fast_lerp = 0;
+/* the library's FL_OPT_FAST_LERP variant: every lerp is one fp32 fma, nothing else changes */
+void orc_set_fast_lerp(int on) { g_fast_lerp = on != 0; }
+
 float orc_lerp(float a, float b, float c)
 {
+    if (g_fast_lerp) return fmaf(c, b - a, a);
     float cb = c * b;
     return (float)((1.0 - (double)c) * (double)a + (double)cb);
 }

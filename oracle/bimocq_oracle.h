@@ -38,6 +38,7 @@ void orc_set_slab(int koff, int nk_global, int own0, int own1, int nk_local);
 
 /* ---- math helpers exposed for tests ---- */
 float orc_expf(float x);
+void  orc_set_fast_lerp(int on);
 float orc_lerp(float a, float b, float c);
 float orc_sample(const float *b, int nx, int ny, int nz, float h,
                  float ox, float oy, float oz, float px, float py, float pz);

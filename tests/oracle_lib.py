@@ -56,6 +56,7 @@ class Emitter(C.Structure):
 _SIGS = {
     "orc_expf": (c_f, [c_f]),
     "orc_lerp": (c_f, [c_f, c_f, c_f]),
+    "orc_set_fast_lerp": (None, [c_i]),
     "orc_sample": (c_f, [FP, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "orc_solve_forward": (None, [FP] * 6 + [c_f, c_i, c_i, c_i, c_f, c_f]),
     "orc_solve_backwardDMC": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_f]),

@@ -259,3 +259,41 @@ def test_dead_state_elision_changes_no_observable_field():
             assert F.same(o.field(name), a.field(name)), (f, name)
             assert F.same(o.field(name), b.field(name)), (f, name)
     a.close(); b.close(); o.close()
+
+
+def test_fast_lerp_variant():
+    """FL_OPT_FAST_LERP (SURVEY 8d "fast variant"): every lerp of the gather kernels is one fp32 fma.
+    (1) against the oracle in the same mode the trajectory is bit-identical (the variant is a specification, not an
+    approximation of unknown size); (2) against the EXACT oracle rho, u, v, w stay within the north star's 1e-5 RMS
+    after 200 steps -- measured margin: three orders of magnitude."""
+    import gpufluidsimulation_amd as bq
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    from oracle_lib import lib as oracle
+    hip = bq.hip_lib()
+    n = 32
+    em = [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)]
+    exact = OracleSolver(n, n, n, 1.0, 0.0, 1.0); exact.set_smoke(0.0, 1.0, em); exact.set_projection(40, 0.5)
+    fast = OracleSolver(n, n, n, 1.0, 0.0, 1.0); fast.set_smoke(0.0, 1.0, em); fast.set_projection(40, 0.5)
+    s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0); s.setSmoke(0.0, 1.0, em); s.setProjection(40, 0.5)
+    hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 1)
+    try:
+        for f in range(200):
+            exact.advance(f, 2.0 / n)
+            oracle().orc_set_fast_lerp(1)
+            fast.advance(f, 2.0 / n)
+            oracle().orc_set_fast_lerp(0)
+            s.advance(f, 2.0 / n)
+            if f % 40 == 39:
+                for name in ("rho", "T", "u", "v", "w"):
+                    assert F.same(fast.field(name), s.field(name)), (f, name, F.maxdiff(fast.field(name), s.field(name)))
+        worst = 0.0
+        for name in ("rho", "u", "v", "w"):
+            a, b = exact.field(name).astype(np.float64), s.field(name).astype(np.float64)
+            assert not F.same(exact.field(name), s.field(name))          # it really is a different arithmetic
+            worst = max(worst, float(np.sqrt(np.mean((a - b) ** 2))))
+        assert worst <= 1e-5, worst                                      # the north star's tolerance
+        assert worst <= 1e-6, worst                                      # what it actually achieves, with margin
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
+        oracle().orc_set_fast_lerp(0)
+    s.close(); exact.close(); fast.close()
