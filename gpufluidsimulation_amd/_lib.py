@@ -74,6 +74,7 @@ HIP_SIGS = {
     "gpu_diffuse_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f]),
     "gpu_max_field": (c_f, [VP, C.c_size_t]),
     "gpu_smoothing_jacobi": (None, [VP, VP, VP, c_d, c_d, c_i, c_i, c_i, c_i]),
+    "gpu_gradient_delta": (None, [VP] * 7 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweep_range": (None, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "gpu_residual_norms": (None, [VP, VP, c_i, c_i, c_i, C.POINTER(c_d), C.POINTER(c_f)]),
     "gpu_clamp_extrema_box": (None, [VP, VP, c_i, c_i, c_i]),

@@ -51,6 +51,37 @@ __global__ __launch_bounds__(256) void gradient_kernel(float *__restrict__ u, fl
     w[ic] -= halfrdx * (p0 - p[ic - (size_t)ni * nj]);
 }
 
+// The same update that also hands out what it changed: d = u_new - u_old on the window, 0 elsewhere -- exactly
+// the d*Proj = U - UTemp that BimocqGPUSolver.cpp:188-193 forms from a snapshot taken before the projection
+// (u_new and u_old are the very floats that subtraction sees), without the three snapshot copies and the three
+// subtraction passes.  One thread per node of the (ni+1, nj+1, nk+1) super-grid.
+__global__ __launch_bounds__(256) void gradient_delta_kernel(float *__restrict__ u, float *__restrict__ v, float *__restrict__ w,
+                                                             const float *__restrict__ p,
+                                                             float *__restrict__ du, float *__restrict__ dv, float *__restrict__ dw,
+                                                             int ni, int nj, int nk, float halfrdx, Slab sl)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i > ni || j > nj || k > nk) return;
+    const int kg = k + sl.koff;
+    const bool win = !(i < 2 || i >= ni || j < 2 || j >= nj || kg < 2 || kg >= sl.nkg || k < 1 || k >= nk);
+    const size_t iu = (size_t)i + (size_t)(ni + 1) * ((size_t)j + (size_t)nj * k);
+    const size_t iv = (size_t)i + (size_t)ni * ((size_t)j + (size_t)(nj + 1) * k);
+    const size_t ic = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+    if (win) {
+        const float p0 = p[ic];
+        const float uo = u[iu], vo = v[iv], wo = w[ic];
+        const float un = uo - halfrdx * (p0 - p[ic - 1]);
+        const float vn = vo - halfrdx * (p0 - p[ic - ni]);
+        const float wn = wo - halfrdx * (p0 - p[ic - (size_t)ni * nj]);
+        u[iu] = un; v[iv] = vn; w[ic] = wn;
+        du[iu] = un - uo; dv[iv] = vn - vo; dw[ic] = wn - wo;
+    } else {
+        if (j < nj && k < nk) du[iu] = 0.f;                  // the u buffer has ni+1 columns
+        if (i < ni && k < nk) dv[iv] = 0.f;                  // the v buffer has nj+1 rows
+        if (i < ni && j < nj) dw[ic] = 0.f;                  // the w buffer has nk+1 planes
+    }
+}
+
 // ---- generic Jacobi sweep: any dims, one thread per cell (GPU_kernel.cu:1819-1837) --------
 __global__ __launch_bounds__(256) void jacobi_generic_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                              float *__restrict__ out, int ni, int nj, int nk,
@@ -718,6 +749,14 @@ void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, 
     BQ_ENTER("gpu_gradient", u, v, w, p)
     gradient_kernel<<<grid2(ni, nj, nk), kBlock2, 0, rt().compute>>>(u, v, w, p, ni, nj, nk, halfrdx, slab_of(nk));
     BQ_LAUNCH_CHECK("gradient_kernel");
+}
+
+void gpu_gradient_delta(float *u, float *v, float *w, const float *p, float *du, float *dv, float *dw,
+                        int ni, int nj, int nk, float halfrdx)
+{
+    BQ_ENTER("gpu_gradient_delta", u, v, w, p, du, dv, dw)
+    gradient_delta_kernel<<<grid2(ni + 1, nj + 1, nk + 1), kBlock2, 0, rt().compute>>>(u, v, w, p, du, dv, dw, ni, nj, nk, halfrdx, slab_of(nk));
+    BQ_LAUNCH_CHECK("gradient_delta_kernel");
 }
 
 void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk, double *sum_sq, float *max_abs)

@@ -314,24 +314,40 @@ std::vector<double> BimocqGPUSolver::mgHistory() const
     return h;
 }
 
-void BimocqGPUSolver::projection()
+// with_delta: d*Proj = (projected - unprojected) velocity comes out of the gradient pass itself
+// (gpu_gradient_delta) instead of a snapshot before and a subtraction after; Jacobi branch only (returns
+// whether it did).
+bool BimocqGPUSolver::projection(bool with_delta)
 {
     gpuMapper &gs = *GpuSolver;
     const float alpha = -1.f, beta = (float)(1.0 / 6.0);
     if (projection_kind == BQ_PROJECTION_MGCG) {            // :443-446
         if (gs.slab.on && gs.slab.nranks > 1) {
             fl_report_error(FL_ERR_UNSUPPORTED, "the multigrid-CG projection is single-GPU (use the Jacobi projection on z-slabs)");
-            return;
+            return false;
         }
-        if (!allocMgcg()) return;
+        if (!allocMgcg()) return false;
         gpu_multi_grid_conjugate_gradient(VelocityU, VelocityV, VelocityW, mg.div.f64(), mg.p.f64(), mg.dir.f64(),
                                           mg.residual.f64(), mg.temp0.f64(), mg.temp1.f64(), mg.result.f64(),
                                           mg.levels.data(), (int)mg.levels.size(), mg_iters, (double)halfrdx);
-        return;
+        return false;
     }
     if (!gs.slab.on || gs.slab.nranks <= 1) {
-        gs.projectionJacobi(VelocityU, VelocityV, VelocityW, div, p, p_temp, debugParam, jacobi_iters, halfrdx, alpha, beta);
-        return;
+        if (!with_delta) {
+            gs.projectionJacobi(VelocityU, VelocityV, VelocityW, div, p, p_temp, debugParam, jacobi_iters, halfrdx, alpha, beta);
+            return false;
+        }
+        // gpu_projection_jacobi (GPU_kernel.cu:1839-1895) in its pieces: divergence, iter-1 sweeps, the
+        // newest iterate made `p` by a buffer swap instead of the copy-back, gradient with the change handed out
+        div.zero(); p.zero(); p_temp.zero();                             // GPU_Advection.h:604-606
+        gpu_divergence(VelocityU, VelocityV, VelocityW, div, g.ni, g.nj, g.nk, halfrdx);
+        const int fuse_was = fl_get_option(FL_OPT_JACOBI_FUSE);
+        if (fuse_was == 1) fl_set_option(FL_OPT_JACOBI_FUSE, 2);        // p and p_temp carry the same (zero) boundary layer
+        const int where = jacobi_iters > 1 ? gpu_jacobi_sweeps(p, div, p_temp, g.ni, g.nj, g.nk, jacobi_iters - 1, alpha, beta) : 0;
+        fl_set_option(FL_OPT_JACOBI_FUSE, fuse_was);
+        if (where) p.swap(p_temp);
+        gpu_gradient_delta(VelocityU, VelocityV, VelocityW, p, duProj, dvProj, dwProj, g.ni, g.nj, g.nk, halfrdx);
+        return true;
     }
     // z-slab form of gpu_projection_jacobi (GPU_kernel.cu:1839-1895): same three kernels, with the
     // sweeps issued in chunks of G: one exchange of G ghost planes of p buys G sweeps, because each
@@ -377,12 +393,19 @@ void BimocqGPUSolver::projection()
         left -= chunk;
     }
     fl_set_option(FL_OPT_JACOBI_FUSE, fuse_was);
-    if (cur != &p) p.copy_from(*cur);
+    if (cur != &p) p.swap(p_temp);                                       // the newest iterate becomes `p` (no copy-back)
     gs.require({ &p }, 1);
-    gpu_gradient(VelocityU, VelocityV, VelocityW, p, g.ni, g.nj, g.nk, halfrdx);
-    gs.produced(VelocityU, std::min(VelocityU.valid, p.valid));
-    gs.produced(VelocityV, std::min(VelocityV.valid, p.valid));
-    gs.produced(VelocityW, std::min(VelocityW.valid, p.valid - 1));
+    const int vu = std::min(VelocityU.valid, p.valid), vv = std::min(VelocityV.valid, p.valid), vw = std::min(VelocityW.valid, p.valid - 1);
+    if (with_delta) {
+        gpu_gradient_delta(VelocityU, VelocityV, VelocityW, p, duProj, dvProj, dwProj, g.ni, g.nj, g.nk, halfrdx);
+        gs.produced(duProj, vu); gs.produced(dvProj, vv); gs.produced(dwProj, vw);
+    } else {
+        gpu_gradient(VelocityU, VelocityV, VelocityW, p, g.ni, g.nj, g.nk, halfrdx);
+    }
+    gs.produced(VelocityU, vu);
+    gs.produced(VelocityV, vv);
+    gs.produced(VelocityW, vw);
+    return with_delta;
 }
 
 // :503-516.  UPrev <- UInit by swap (UInit is refilled right after), UInit <- U by copy.
@@ -472,21 +495,25 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
         gs.addFields(dvExtern, VelocityV, VelocityVTemp, -1.f, g.nv());
         gs.produced(dvExtern, std::min(VelocityV.valid, VelocityVTemp.valid));
     }
-    // :179-181
-    VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);
+    // :179-193: UTemp <- U, projection, dProj = U - UTemp.  With the Jacobi projection the gradient pass hands the
+    // change out itself (same floats, same subtraction): no snapshot, no subtraction pass.
+    const bool delta_from_gradient = projection_kind == BQ_PROJECTION_JACOBI;
+    if (!delta_from_gradient) { VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW); }
 
     trace_stage(*this, "forces", framenum);
-    projection();                                        // :183
+    const bool have_delta = projection(delta_from_gradient);             // :183
     trace_stage(*this, "projection", framenum);
 
-    // :188-193 dProj = U - UTemp.  The reference copies U into dProj and then adds -1*UTemp in
-    // place; out = U + (-1)*UTemp is the same expression in one pass.
-    gs.addFields(duProj, VelocityU, VelocityUTemp, -1.f, g.nu());
-    gs.addFields(dvProj, VelocityV, VelocityVTemp, -1.f, g.nv());
-    gs.addFields(dwProj, VelocityW, VelocityWTemp, -1.f, g.nw());
-    gs.produced(duProj, std::min(VelocityU.valid, VelocityUTemp.valid));
-    gs.produced(dvProj, std::min(VelocityV.valid, VelocityVTemp.valid));
-    gs.produced(dwProj, std::min(VelocityW.valid, VelocityWTemp.valid));
+    if (!have_delta) {
+        // :188-193 dProj = U - UTemp.  The reference copies U into dProj and then adds -1*UTemp in
+        // place; out = U + (-1)*UTemp is the same expression in one pass.
+        gs.addFields(duProj, VelocityU, VelocityUTemp, -1.f, g.nu());
+        gs.addFields(dvProj, VelocityV, VelocityVTemp, -1.f, g.nv());
+        gs.addFields(dwProj, VelocityW, VelocityWTemp, -1.f, g.nw());
+        gs.produced(duProj, std::min(VelocityU.valid, VelocityUTemp.valid));
+        gs.produced(dvProj, std::min(VelocityV.valid, VelocityVTemp.valid));
+        gs.produced(dwProj, std::min(VelocityW.valid, VelocityWTemp.valid));
+    }
     // :185-186,195-198: DensityExtern = Density - DensityTemp right after DensityTemp <- Density is
     // identically zero, and accumulating a zero field (:215-216) adds 0: not executed.
 

@@ -40,7 +40,7 @@ public:
     void addBuoyancy(float dt);
     void diffuseField(float *field, float *t0, float *t1, int ni, int nj, int nk, int iter, float nu, float dt);
     void diffuseFieldSlab(DeviceField &field, DeviceField &t0, DeviceField &t1, int bi, int bj, int bk, int iter, float nu, float dt);
-    void projection();
+    bool projection(bool with_delta = false);
     void velocityReinitialize();
     void scalarReinitialize();
     void setSmoke(float drop, float raise, const std::vector<Emitter> &emitters);

@@ -281,6 +281,10 @@ int  gpu_jacobi_sweeps(float *p, const float *div, float *p_temp,
                        int ni, int nj, int nk, int sweeps, float alpha, float beta);
 void gpu_gradient(float *u, float *v, float *w, const float *p,
                   int ni, int nj, int nk, float halfrdx);
+/* gpu_gradient that also returns what it changed: (du, dv, dw) = new - old on the update window, 0 elsewhere --
+ * the d*Proj = U - UTemp of BimocqGPUSolver.cpp:188-193 without the snapshot copies and the subtraction passes */
+void gpu_gradient_delta(float *u, float *v, float *w, const float *p, float *du, float *dv, float *dw,
+                        int ni, int nj, int nk, float halfrdx);
 /* one Jacobi sweep in -> out over the local planes [k_begin, k_end) only: lets a z-slab host sweep the
  * planes that do not depend on ghost planes while those are still being exchanged */
 void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,

@@ -218,6 +218,16 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *pt, int ni, int nj, int
     for (int s = 0; s < sweeps; s++) { orc_jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta); float *t = in; in = out; out = t; }
     return in == p ? 0 : 1;
 }
+void gpu_gradient_delta(float *u, float *v, float *w, const float *p, float *du, float *dv, float *dw,
+                        int ni, int nj, int nk, float hr)
+{
+    size_t nu = (size_t)(ni + 1) * nj * nk, nv = (size_t)ni * (nj + 1) * nk, nw = (size_t)ni * nj * (nk + 1);
+    memcpy(du, u, nu * sizeof(float)); memcpy(dv, v, nv * sizeof(float)); memcpy(dw, w, nw * sizeof(float));
+    gpu_gradient(u, v, w, p, ni, nj, nk, hr);
+    for (size_t q = 0; q < nu; q++) du[q] = u[q] - du[q];
+    for (size_t q = 0; q < nv; q++) dv[q] = v[q] - dv[q];
+    for (size_t q = 0; q < nw; q++) dw[q] = w[q] - dw[q];
+}
 void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,
                             int k_begin, int k_end, float alpha, float beta)
 { orc_jacobi_sweep_range(in, div, out, ni, nj, nk, k_begin, k_end, alpha, beta); }
