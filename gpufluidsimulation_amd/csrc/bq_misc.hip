@@ -102,9 +102,18 @@ __global__ __launch_bounds__(256) void max_abs3_partial_kernel(const float *__re
 {
     float m = 0.f;
     const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (size_t i = t0; i < nu; i += stride) m = fmaxf(m, fabsf(u[i]));
-    for (size_t i = t0; i < nv; i += stride) m = fmaxf(m, fabsf(v[i]));
-    for (size_t i = t0; i < nw; i += stride) m = fmaxf(m, fabsf(w[i]));
+    // 16-byte loads over the aligned bulk of each array (a maximum does not care about the order), scalars for the rest
+    auto scan = [&](const float *f, size_t n) {
+        const size_t head = min(n, (size_t)((16 - ((uintptr_t)f & 15u)) & 15u) / 4), bulk = (n - head) / 4;
+        const float4 *f4 = reinterpret_cast<const float4 *>(f + head);
+        for (size_t i = t0; i < bulk; i += stride) {
+            const float4 q = f4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+        }
+        for (size_t i = t0; i < head; i += stride) m = fmaxf(m, fabsf(f[i]));
+        for (size_t i = head + 4 * bulk + t0; i < n; i += stride) m = fmaxf(m, fabsf(f[i]));
+    };
+    scan(u, nu); scan(v, nv); scan(w, nw);
     __shared__ float smax[4];
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
