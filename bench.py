@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=180)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", dest="n", type=int, default=256, help="grid is size^3 (per rank when --gpus > 1)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (BASELINE config 4: 512^3 across 8 GPUs): the global grid is size^3 and each of the N "
+                         "ranks owns size/N planes; default is weak scaling, size^3 per GPU")
     ap.add_argument("--jacobi-iters", type=int, default=200)
     ap.add_argument("--halfrdx", type=float, default=0.5)
     ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi",
@@ -179,10 +182,17 @@ def main():
                 args.transport_note = "host-staged over gloo (FALLBACK: RCCL set-up failed)"
         else:
             keep = transport.HostStagedTransport(lib, dist)
-        s = BimocqGPUSolver(n, n, n * world, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
+        if args.strong and n % world:
+            sys.exit("--strong needs size divisible by the number of ranks")
+        nz_global = n if args.strong else n * world
+        s = BimocqGPUSolver(n, n, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
     else:
+        nz_global = n
         s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
-    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(world)])
+    if args.strong:
+        s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])         # BASELINE's one source in the n^3 box
+    else:
+        s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(world)])
     mg = args.projection == "mgcg"
     if mg and world > 1:
         sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
@@ -243,29 +253,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=side if (side is not None and args.transport == "host") else None)
         el = float(t.item())
 
-    voxels = n ** 3 * world                     # weak scaling: every rank advances its own n^3 grid
+    voxels = n * n * nz_global                  # weak scaling: every rank advances its own n^3 grid; strong: n^3 in all
     ms_per_step = el / args.steps * 1e3
     value = voxels * args.steps / el / 1e6
     line = {
         "metric": "Mvoxels/s per step (bimocq3D rising smoke" + (", multigrid-CG projection)" if mg else ")"),
         "value": round(value, 2), "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if mg else "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64" if mg else "f32", "data": "synthetic",
         "config": {"workload": f"bimocq3D {n}^3 rising smoke, "
                                + (f"fp64 multigrid-CG projection ({args.mg_iters} outer iterations, 6 levels), fp32 advection, "
                                   if mg else f"{args.jacobi_iters} Jacobi iters, fp32, ")
                                + f"halfrdx {args.halfrdx}, reinit every step",
-                   "grid_per_gpu": [n, n, n], "global_grid": [n, n, n * world], "dt": dt,
+                   "grid_per_gpu": [n, n, nz_global // world], "global_grid": [n, n, nz_global], "dt": dt,
                    "parallelism": "1 GPU" if world == 1 else
-                   f"{world} z-slabs of {n} planes, {args.ghost} ghost planes, neighbour exchange over "
+                   f"{world} z-slabs of {nz_global // world} planes, {args.ghost} ghost planes, neighbour exchange over "
                    + getattr(args, "transport_note", args.transport)},
     }
-    line["extra"] = {"dead_state_elision": {"value": round(n ** 3 * world * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
+    line["extra"] = {"dead_state_elision": {"value": round(voxels * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
                                             "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
                                             "note": "library default: with blend == 1 and a re-initialisation every frame the "
                                                     "*Prev fields are never read, so the accumulation that only feeds them is "
                                                     "skipped; every observable field is identical (DESIGN.md section 3)"},
-                     "fast_lerp_variant": {"value": round(n ** 3 * world * extra_steps / el_fast / 1e6, 2), "unit": "Mvoxels/s",
+                     "fast_lerp_variant": {"value": round(voxels * extra_steps / el_fast / 1e6, 2), "unit": "Mvoxels/s",
                                            "ms_per_step": round(el_fast / extra_steps * 1e3, 3), "steps": extra_steps,
                                            "note": "FL_OPT_FAST_LERP = 1 on top of the elision: every lerp of the gather kernels is "
                                                    "one fp32 fma; NOT bit-identical to the reference arithmetic, within 1e-6 RMS "
@@ -289,7 +299,7 @@ def main():
         spl = sweeps.value / launches.value
         # a z-slab rank sweeps its ghost planes too (communication-avoiding chunks): n x n x (n + 2G) cells per sweep;
         # the overlapped first sweep of a chunk (three range launches) is not inside the timed spans
-        cells = n ** 3 if world == 1 else n * n * (n + 2 * args.ghost)
+        cells = n ** 3 if world == 1 else n * n * (nz_global // world + 2 * args.ghost)
         alg = JACOBI_BYTES_PER_VOXEL * cells * spl
         achieved = alg / (us * 1e-6) / 1e9
         line["roofline"] = {"bound": "hbm", "kernel": "jacobi_march2_kernel" if spl > 1.5 else "jacobi_march_kernel",
