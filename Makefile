@@ -22,7 +22,7 @@ KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(KERNEL_SRCS))
 HOST_SRCS   := $(wildcard $(CSRC)/host/*.cpp)
 HOST_OBJS   := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(HOST_SRCS))
 
-all: $(PKG)/libbimocq_hip.so $(PKG)/libbimocq_host.so oracle
+all: $(PKG)/libbimocq_hip.so $(PKG)/libbimocq_host.so oracle example
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
 	@mkdir -p $(OBJDIR)
@@ -44,10 +44,15 @@ $(OBJDIR)/host_%.o: $(CSRC)/host/%.cpp $(wildcard $(CSRC)/host/*.hpp) include/bi
 $(PKG)/libbimocq_host.so: $(HOST_OBJS) $(PKG)/libbimocq_hip.so
 	g++ -shared -fPIC -pthread -o $@ $(HOST_OBJS) -L$(PKG) -lbimocq_hip $(VDB_LIBS) -Wl,-rpath,'$$ORIGIN'
 
+# the reference's driver loop (main.cpp:137-159) on this library
+example: build/bimocq3d
+build/bimocq3d: examples/bimocq3d_main.cpp $(PKG)/libbimocq_host.so
+	g++ -O2 -std=c++17 -pthread -Iinclude -I$(CSRC)/host $< -o $@ -L$(PKG) -lbimocq_host -lbimocq_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
 oracle:
 	$(MAKE) -s -C oracle
 
 clean:
 	rm -rf build $(PKG)/*.so oracle/_build tests/_build
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean example
