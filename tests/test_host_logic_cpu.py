@@ -157,3 +157,23 @@ def test_async_dump_equals_blocking_dump(cpu_host, tmp_path):
 def test_create_rejects_bad_arguments(cpu_host):
     assert not cpu_host.bq_solver_create(0, 4, 16, 16, 1.0, 0.0, 1.0, 0)       # too small
     assert not cpu_host.bq_solver_create(0, 16, 16, 16, 1.0, 0.0, 1.0, 1)      # SEMILAG: the GPU solver has no such scheme
+
+
+def test_option_errors_are_latched(cpu_host):
+    """run-time switches that cannot apply are refused loudly: unknown projection kind, re-initialisation policy after the
+    first step, unknown policy value"""
+    from gpufluidsimulation_amd import BimocqError
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    s = BimocqGPUSolver(16, 16, 16, 1.0, 0.0, 1.0, lib=cpu_host, errlib=cpu_host)
+    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.2, 1.0, 1.0, 0.0, 1)])
+    with pytest.raises(BimocqError):
+        s.setProjection(10, 0.5, kind=7)
+    with pytest.raises(BimocqError):
+        s.setOption(2, 5)                              # BQ_OPT_REINIT_POLICY: 0 or 1
+    s.setProjection(6, 0.5)
+    s.advance(0, 0.1)
+    with pytest.raises(BimocqError):
+        s.setOption(2, 1)                              # too late: the maps have been updated once
+    s.setOption(3, 1); s.setOption(3, 0)               # BQ_OPT_FULL_STATE may be toggled at any time
+    s.advance(1, 0.1)
+    assert np.isfinite(s.field("rho")).all()
