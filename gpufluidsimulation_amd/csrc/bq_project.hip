@@ -631,8 +631,22 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     const bool wide = cw > 64;
     const int rows = 256 / cw;
     const int nby = (nj + rows - 1) / rows;
-    // planes per block: 32 measured best at 256^3 (one wave per row), 64 at 512^3 (248 vs 254 us per sweep)
-    int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : (wide ? 64 : 32);
+    // planes per block: ~32 measured best at 256^3 (one wave per row), ~64 at 512^3 (248 vs 254 us per sweep).  What
+    // matters more is that the blocks fill the 256 CUs in whole rounds of two blocks per CU: at 256^3, 512 blocks
+    // (chunks of 32) run 19.1 us per sweep, 576 or 448 blocks (chunks of 28 or 40) 22.7; a z-slab rank with 272
+    // planes runs 25.4 us with chunks of 32 (9 of them) and 20.0 with chunks of 34 (8).  So: the number of chunks is
+    // the multiple of 512 / gcd(row blocks, 512) closest to planes / target.
+    int kchunk = rt().opt_jacobi_kchunk2;
+    if (kchunk <= 0) {
+        const int target = wide ? 64 : 32;
+        int gcd = nby, rem = 512;
+        while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+        const int quantum = 512 / gcd;                          // chunk counts that make nby * nbz a multiple of 512
+        int nchunks = ((2 * nk + target) / (2 * target) + quantum / 2) / quantum * quantum;
+        if (nchunks < quantum) nchunks = quantum;
+        kchunk = (nk + nchunks - 1) / nchunks;
+        if (kchunk < 16) kchunk = target;                       // small grids: no whole round to fill anyway
+    }
     while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
     const int nbz = (nk + kchunk - 1) / kchunk;
     // (loads two planes ahead instead of one measured no better at 256^3: 19.4 vs 19.1 us per sweep)
