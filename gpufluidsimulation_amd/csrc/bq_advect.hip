@@ -24,6 +24,17 @@ inline namespace BQ_VARIANT {
 static inline dim3 grid_for(int nbi, int nbj, int nbk) { return dim3((nbi + 63) / 64, (nbj + 3) / 4, nbk); }
 static const dim3 kBlock(64, 4, 1);
 
+// The 9-point kernels on the structured power-of-two path stage the map nodes of their block in LDS
+// (bq_device.hip.h: stage_tiles), so every thread of a block has to reach the barrier: the index window
+// ilo < i < ihi, jlo < j < jhi, klo < kg < khi is tested as a predicate, only whole blocks leave early.
+#define BQ_IJK_WINDOW(ilo, ihi, jlo, jhi, klo, khi)                                           \
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 4;                                      \
+    const int i = i0 + threadIdx.x, j = j0 + threadIdx.y, k = blockIdx.z;                     \
+    const int kg = k + g.koff;                                                                \
+    if (!((klo) < kg && kg < (khi)) || i0 + 63 <= (ilo) || i0 >= (ihi) || j0 + 3 <= (jlo) || j0 >= (jhi)) return; \
+    const bool active = (ilo) < i && i < (ihi) && (jlo) < j && j < (jhi);
+template <bool P2, bool PT, int SD> constexpr bool kStaged = P2 && !PT && SD >= 0;
+
 // CELL dims of the LOCAL buffers plus the z-slab context: local plane k is global plane k + koff of a
 // grid with nkg cell planes (single GPU: koff = 0, nkg = nk).  Index windows, positions and clamps
 // are evaluated in GLOBAL coordinates so that a slab rank computes exactly what one GPU would.
@@ -160,15 +171,23 @@ __global__ __launch_bounds__(256) void advect_kernel(AdvectArgs<NF> a,
                                                      Spacing sp, Grid g, int dx, int dy, int dz)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
-    BQ_IJK(nbi, nbj, nbk)
-    if (!(2 + dx < i && i < nbi - 3 && 2 + dy < j && j < nbj - 3 && 2 + dz < kg && kg < g.nkg + dz - 3)) return;
+    BQ_IJK_WINDOW(2 + dx, nbi - 3, 2 + dy, nbj - 3, 2 + dz, g.nkg + dz - 3)
     const float h = sp.h;
     Map3 back{make_field(bx, g.ni, g.nj, g.nk, g.koff), make_field(by, g.ni, g.nj, g.nk, g.koff), make_field(bz, g.ni, g.nj, g.nk, g.koff)};
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
     f3 c = nine_centre(n, i, j, kg);
     f3 mp[9];
-    mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
+    if constexpr (kStaged<P2, PT, SD>) {
+        __shared__ float tile[3 * kTile];
+        const Field mf[3] = {back.x, back.y, back.z};
+        stage_tiles<3>(mf, i0, j0, k, tile);
+        if (!active) return;
+        map9_lds<SD == 1, SD == 2, SD == 3>(tile, mp);
+    } else {
+        if (!active) return;
+        mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
+    }
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
     // taps outermost: cell and weights of a tap are found once and serve every field of the batch
@@ -237,14 +256,14 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
                                                        Spacing sp, Grid g, int dx, int dy, int dz)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
-    BQ_IJK(nbi, nbj, nbk)
-    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
+    BQ_IJK_WINDOW(1 + dx, nbi - 2, 1 + dy, nbj - 2, 1 + dz, g.nkg + dz - 2)
     const float h = sp.h;
     Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
     const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    __shared__ float tile[kStaged<P2, PT, SD> && !ID ? 3 * kTile : 1];
     if constexpr (ID) {
         // Identity map (node n holds n*h), power-of-two spacing.  A map component then varies along its
         // own axis only; map9's lerps along the other two axes combine equal values (lerp(a, a, c) == a
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
         // structured look-up with compile-time cells and weights (map9_component, unstaggered pattern)
         // applied to the field itself performs the very lerps locate() + gather() would.
         static_assert(P2 && !PT && SD >= 0, "identity shortcut: structured power-of-two path only");
+        if (!active) return;                    // (this light kernel reads its nodes directly: staging them was slower)
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             Field src = make_field(a.src[f], nbi, nbj, nbk, g.koff);
@@ -270,7 +290,15 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
         return;
     }
     f3 mp[9];
-    mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
+    if constexpr (kStaged<P2, PT, SD>) {
+        const Field mf[3] = {m.x, m.y, m.z};
+        stage_tiles<3>(mf, i0, j0, k, tile);
+        if (!active) return;
+        map9_lds<SD == 1, SD == 2, SD == 3>(tile, mp);
+    } else {
+        if (!active) return;
+        mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
+    }
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
     Field src[NF];
@@ -296,15 +324,23 @@ __global__ __launch_bounds__(256) void compensate_kernel(CompensateArgs<NF> a,
                                                          Spacing sp, Grid g, int dx, int dy, int dz)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
-    BQ_IJK(nbi, nbj, nbk)
-    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
+    BQ_IJK_WINDOW(1 + dx, nbi - 2, 1 + dy, nbj - 2, 1 + dz, g.nkg + dz - 2)
     const float h = sp.h;
     Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
     f3 c = nine_centre(n, i, j, kg);
     f3 mp[9];
-    mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
+    if constexpr (kStaged<P2, PT, SD>) {
+        __shared__ float tile[3 * kTile];
+        const Field mf[3] = {m.x, m.y, m.z};
+        stage_tiles<3>(mf, i0, j0, k, tile);
+        if (!active) return;
+        map9_lds<SD == 1, SD == 2, SD == 3>(tile, mp);
+    } else {
+        if (!active) return;
+        mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
+    }
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
     const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;

@@ -140,6 +140,25 @@ __device__ __forceinline__ float lerp_const(float a, float b, float c, double om
 #endif
 }
 
+// The same compile-time-weight lerp, cheaper where that is provably bit-identical.  On gfx950 a wave64 VALU
+// instruction costs one 4-cycle issue slot whatever its type (only packed fp32 is faster), so what counts is the
+// instruction count: lerp_const is 5 (mul, 2 cvt, fma_f64, cvt), fmaf(1 - c, a, c*b) is 2.  c*b is the very float
+// product of the contract and (1 - c)*a is exact inside the fma, so the fp32 form differs from lerp_const by one
+// rounding (to float) instead of two (to double, then to float).  The two can only disagree when the double sum lands
+// exactly on a float midpoint that the exact sum misses:
+//   c = 0, 1/2, 3/4: (1 - c)*a is itself a float and the sum of two floats cannot do that -- always identical;
+//   c = 1/4: 3/4*a can sit on a float midpoint (results differ when 0 < |c*b| <= 2^-53 |3/4 a|) -- stays lerp_const.
+// tools/lerp_q_check.c compares both forms on 1.2e9 random and adversarial operand pairs per weight.
+__device__ __forceinline__ float lerp_q(float a, float b, float c)
+{
+#ifdef BQ_FAST_LERP
+    return __builtin_fmaf(c, b - a, a);
+#else
+    if (c == 0.25f) return lerp_const(a, b, c, 0.75);
+    return __builtin_fmaf(1.0f - c, a, c * b);
+#endif
+}
+
 __device__ __forceinline__ int floor_to_int(float x)
 {
     int r;
@@ -236,32 +255,30 @@ __device__ constexpr float tap_frac(int S, int t)
 
 // out[0..7]: corners in the reference's order (bit2 x, bit1 y, bit0 z; 0 = '+'), out[8]: centre.
 // (i, j, kl): node indices in the map's LOCAL index space.
-template <int SX, int SY, int SZ>
-__device__ __forceinline__ void map9_component(const Field &f, int i, int j, int kl, float out[9])
+// node(x, y, z): value of map node (i - 1 + x, j - 1 + y, kl - 1 + z) by flat index (see NodesGlobal / NodesLds)
+template <int SX, int SY, int SZ, class Nodes>
+__device__ __forceinline__ void map9_nodes(const Nodes &node, float out[9])
 {
     constexpr int NX = SX ? 2 : 3, NY = SY ? 2 : 3, NZ = SZ ? 2 : 3;
     float N[NZ][NY][NX];
-    const int base = (i - 1) + f.nx * (j - 1) + f.nx * f.ny * (kl - 1);
 #pragma unroll
     for (int z = 0; z < NZ; z++)
 #pragma unroll
         for (int y = 0; y < NY; y++)
 #pragma unroll
             for (int x = 0; x < NX; x++)
-                N[z][y][x] = ldf(f, (unsigned)(base + x + f.nx * y + f.nx * f.ny * z) * 4u);
+                N[z][y][x] = node(x, y, z);
     // level 1: along x, for taps '+' (0), '-' (1) on every node row, centre (2) on the rows it needs
     float LX[3][NZ][NY];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        constexpr int dummy = 0; (void)dummy;
         const int r = tap_rel(SX, t);
         const float c = tap_frac(SX, t);
-        const double omc = 1.0 - (double)c;
 #pragma unroll
         for (int z = 0; z < NZ; z++)
 #pragma unroll
             for (int y = 0; y < NY; y++)
-                LX[t][z][y] = lerp_const(N[z][y][r], N[z][y][r + 1], c, omc);
+                LX[t][z][y] = lerp_q(N[z][y][r], N[z][y][r + 1], c);
     }
     // level 2: along y
     float LY[3][3][NZ];     // [tx][ty][z]; centre only pairs with centre
@@ -272,24 +289,82 @@ __device__ __forceinline__ void map9_component(const Field &f, int i, int j, int
             if ((tx == 2) != (ty == 2)) continue;
             const int r = tap_rel(SY, ty);
             const float c = tap_frac(SY, ty);
-            const double omc = 1.0 - (double)c;
 #pragma unroll
             for (int z = 0; z < NZ; z++)
-                LY[tx][ty][z] = lerp_const(LX[tx][z][r], LX[tx][z][r + 1], c, omc);
+                LY[tx][ty][z] = lerp_q(LX[tx][z][r], LX[tx][z][r + 1], c);
         }
     // level 3: along z
 #pragma unroll
     for (int ii = 0; ii < 8; ii++) {
         const int tx = (ii >> 2) & 1, ty = (ii >> 1) & 1, tz = ii & 1;
         const int r = tap_rel(SZ, tz);
-        const float c = tap_frac(SZ, tz);
-        out[ii] = lerp_const(LY[tx][ty][r], LY[tx][ty][r + 1], c, 1.0 - (double)c);
+        out[ii] = lerp_q(LY[tx][ty][r], LY[tx][ty][r + 1], tap_frac(SZ, tz));
     }
     {
         const int r = tap_rel(SZ, 2);
-        const float c = tap_frac(SZ, 2);
-        out[8] = lerp_const(LY[2][2][r], LY[2][2][r + 1], c, 1.0 - (double)c);
+        out[8] = lerp_q(LY[2][2][r], LY[2][2][r + 1], tap_frac(SZ, 2));
     }
+}
+
+// the 3x3x3 block straight from memory (one buffer load per node)
+struct NodesGlobal {
+    const Field &f; int base;
+    __device__ __forceinline__ float operator()(int x, int y, int z) const
+    {
+        return ldf(f, (unsigned)(base + x + f.nx * y + f.nx * f.ny * z) * 4u);
+    }
+};
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ void map9_component(const Field &f, int i, int j, int kl, float out[9])
+{
+    map9_nodes<SX, SY, SZ>(NodesGlobal{f, (i - 1) + f.nx * (j - 1) + f.nx * f.ny * (kl - 1)}, out);
+}
+
+// ---- the same look-up from a tile staged in LDS ------------------------------------------------
+// A 64 x 4 block at (i0, j0) on plane kl needs the nodes x in [i0-1, i0+64], y in [j0-1, j0+4], z in [kl-1, kl+1]:
+// 66 x 6 x 3 per component.  Neighbouring threads share 26 of their 27 nodes, so reading them through L1 costs
+// 27 wave-loads per component and wave; staged, a wave issues 4.5 aligned row loads and reads the rest from LDS.
+// Each tile element is loaded by the same flat index the direct path uses (a column left of 0 / right of nx - 1
+// is the neighbouring row's end, outside the allocation reads 0), so both paths see identical values.
+constexpr int kTileX = 66, kTileY = 6, kTileZ = 3, kTile = kTileX * kTileY * kTileZ;
+
+// all 256 threads of the block call this (no early exit before it); ends with a barrier
+template <int NC>
+__device__ __forceinline__ void stage_tiles(const Field (&f)[NC], int i0, int j0, int kl, float *tile)
+{
+    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int nx = f[0].nx, sk = f[0].nx * f[0].ny;
+    for (int r = wv; r < kTileY * kTileZ; r += 4) {
+        const int z = r / kTileY, y = r - z * kTileY;
+        const unsigned off = (unsigned)((i0 + lane) + nx * (j0 - 1 + y) + sk * (kl - 1 + z)) * 4u;
+#pragma unroll
+        for (int c = 0; c < NC; c++) tile[c * kTile + r * kTileX + 1 + lane] = ldf(f[c], off);
+    }
+    if (wv == 0 && lane < 2 * kTileY * kTileZ) {            // the two edge columns
+        const int r = lane >> 1, X = (lane & 1) ? kTileX - 1 : 0;
+        const int z = r / kTileY, y = r - z * kTileY;
+        const unsigned off = (unsigned)((i0 - 1 + X) + nx * (j0 - 1 + y) + sk * (kl - 1 + z)) * 4u;
+#pragma unroll
+        for (int c = 0; c < NC; c++) tile[c * kTile + r * kTileX + X] = ldf(f[c], off);
+    }
+    __syncthreads();
+}
+
+struct NodesLds {
+    const float *t;         // tile + (threadIdx.y * kTileX + threadIdx.x): this thread's node (i - 1, j - 1, kl - 1)
+    __device__ __forceinline__ float operator()(int x, int y, int z) const { return t[(z * kTileY + y) * kTileX + x]; }
+};
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ void map9_lds(const float *tile, f3 out[9])
+{
+    const float *t = tile + threadIdx.y * kTileX + threadIdx.x;
+    float x[9], y[9], z[9];
+    map9_nodes<SX, SY, SZ>(NodesLds{t}, x);
+    map9_nodes<SX, SY, SZ>(NodesLds{t + kTile}, y);
+    map9_nodes<SX, SY, SZ>(NodesLds{t + 2 * kTile}, z);
+#pragma unroll
+    for (int a = 0; a < 9; a++) out[a] = mk3(x[a], y[a], z[a]);
 }
 
 template <int SX, int SY, int SZ>
