@@ -128,33 +128,48 @@ __device__ __forceinline__ void mapped9(const Map3 &m, const Spacing &sp, const 
 // The 9-point blend of NF co-located fields at the (clamped) positions mp[0..8]: per field
 //     sum = sum_ii w * field(mp[ii])  (ii = 0..7 in order; point mode: the centre alone),  value = field(mp[8])
 // with the tap's cell and weights located once for all fields (they share dims and origin).
-template <bool P2, bool PT, int NF>
+// Positions are inside the grid and origins are <= 0, so pos - org >= 0 (locate's NONNEG form).
+// GE1: every position is >= h on every axis, hence q >= 1 and the lerps may take their one-fma form (lerp_w<true>).
+template <bool P2, bool PT, int NF, bool GE1>
 __device__ __forceinline__ void blend9_gather_w(const Field (&src)[NF], const Spacing &sp, f3 org, const f3 (&mp)[9],
                                                 const float (&w)[NF], float (&sum)[NF], float (&value)[NF])
 {
     if (!PT) {
 #pragma unroll
         for (int ii = 0; ii < 8; ii++) {
-            const Cell c = locate<P2>(src[0], sp, org, mp[ii]);
+            const Cell c = locate<P2, true>(src[0], sp, org, mp[ii]);
 #pragma unroll
-            for (int f = 0; f < NF; f++) sum[f] += w[f] * gather(src[f], c);
+            for (int f = 0; f < NF; f++) sum[f] += w[f] * gather<GE1>(src[f], c);
         }
     }
-    const Cell c = locate<P2>(src[0], sp, org, mp[8]);
+    const Cell c = locate<P2, true>(src[0], sp, org, mp[8]);
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        value[f] = gather(src[f], c);
+        value[f] = gather<GE1>(src[f], c);
         if (PT) sum[f] += w[f] * value[f];
     }
 }
-template <bool P2, bool PT, int NF>
+template <bool P2, bool PT, int NF, bool GE1>
 __device__ __forceinline__ void blend9_gather(const Field (&src)[NF], const Spacing &sp, f3 org, const f3 (&mp)[9],
                                               float (&sum)[NF], float (&value)[NF])
 {
     float w[NF];
 #pragma unroll
     for (int f = 0; f < NF; f++) w[f] = PT ? 1.0f : 0.125f;
-    blend9_gather_w<P2, PT, NF>(src, sp, org, mp, w, sum, value);
+    blend9_gather_w<P2, PT, NF, GE1>(src, sp, org, mp, w, sum, value);
+}
+// true when every lane of the wave has all nine mapped positions (point mode: the centre) >= h on every axis.  Tested
+// before the clamp to [0, hi], which cannot lower a value that is >= h.  fminf skips a NaN: such a position is clamped
+// to 0, where q is 0 or 1/2 and the weights are multiples of 2^-28 all the same.
+template <bool PT>
+__device__ __forceinline__ bool wave_all_ge(const f3 (&mp)[9], float h)
+{
+    float m = fminf(mp[8].x, fminf(mp[8].y, mp[8].z));
+    if (!PT) {
+#pragma unroll
+        for (int a9 = 0; a9 < 8; a9++) m = fminf(m, fminf(mp[a9].x, fminf(mp[a9].y, mp[a9].z)));
+    }
+    return __all(m >= h);
 }
 
 // Batches: NF fields that live on the same nodes share one map look-up (density + temperature; the
@@ -166,7 +181,7 @@ template <int NF> struct CompensateArgs { const float *src[NF]; const float *ini
 
 // ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
 template <bool P2, bool PT, int SD, int NF>
-__global__ __launch_bounds__(256) void advect_kernel(AdvectArgs<NF> a,
+__global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void advect_kernel(AdvectArgs<NF> a,
                                                      const float *bx, const float *by, const float *bz,
                                                      Spacing sp, Grid g, int dx, int dy, int dz)
 {
@@ -188,14 +203,15 @@ __global__ __launch_bounds__(256) void advect_kernel(AdvectArgs<NF> a,
         if (!active) return;
         mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
     }
+    // (an active thread implies ni, nj >= 7 and nkg >= 7, so lo = h <= hi)
 #pragma unroll
-    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3_ordered(mp[a9], lo, hi);
     // taps outermost: cell and weights of a tap are found once and serve every field of the batch
     Field src[NF];
     float sum[NF], value[NF];
 #pragma unroll
     for (int f = 0; f < NF; f++) { src[f] = make_field(a.init[f], nbi, nbj, nbk, g.koff); sum[f] = 0.f; }
-    blend9_gather<P2, PT, NF>(src, sp, n.org, mp, sum, value);
+    blend9_gather<P2, PT, NF, true>(src, sp, n.org, mp, sum, value);       // positions clamped to >= h
 #pragma unroll
     for (int f = 0; f < NF; f++)
         a.field[f][(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.5f * sum[f] + 0.5f * value[f];
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 // ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
 // ID: the map is the identity map of gpu_init_maps (mx/my/mz are not read).
 template <bool P2, bool PT, int SD, int NF, bool ID>
-__global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
+__global__ __launch_bounds__(256, 6) void cumulate_kernel(CumulateArgs<NF> a,
                                                        const float *mx, const float *my, const float *mz,
                                                        Spacing sp, Grid g, int dx, int dy, int dz)
 {
@@ -299,8 +315,9 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
         if (!active) return;
         mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
     }
+    const bool ge1 = NF == 1 && wave_all_ge<PT>(mp, h);   // (two fields: both code paths together need too many registers)
 #pragma unroll
-    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3_ordered(mp[a9], lo, hi);
     Field src[NF];
     float sum[NF], value[NF], w[NF];
 #pragma unroll
@@ -309,7 +326,8 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
         sum[f] = 0.f;
         w[f] = (PT ? 1.0f : 0.125f) * a.coeff[f];   // (0.125f * coeff) * sample: the reference's left-to-right product
     }
-    blend9_gather_w<P2, PT, NF>(src, sp, n.org, mp, w, sum, value);
+    if (NF == 1 && ge1) blend9_gather_w<P2, PT, NF, true>(src, sp, n.org, mp, w, sum, value);
+    else                blend9_gather_w<P2, PT, NF, false>(src, sp, n.org, mp, w, sum, value);
 #pragma unroll
     for (int f = 0; f < NF; f++) {
         const float v = a.coeff[f] * value[f];
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(256) void cumulate_kernel(CumulateArgs<NF> a,
 
 // ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
 template <bool P2, bool PT, int SD, int NF>
-__global__ __launch_bounds__(256) void compensate_kernel(CompensateArgs<NF> a,
+__global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a,
                                                          const float *mx, const float *my, const float *mz,
                                                          Spacing sp, Grid g, int dx, int dy, int dz)
 {
@@ -341,14 +359,16 @@ __global__ __launch_bounds__(256) void compensate_kernel(CompensateArgs<NF> a,
         if (!active) return;
         mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
     }
+    const bool ge1 = NF == 1 && wave_all_ge<PT>(mp, h);   // (two fields: both code paths together need too many registers)
 #pragma unroll
-    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3(mp[a9], lo, hi);
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3_ordered(mp[a9], lo, hi);
     const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     Field src[NF];
     float sum[NF], value[NF];
 #pragma unroll
     for (int f = 0; f < NF; f++) { src[f] = make_field(a.src[f], nbi, nbj, nbk, g.koff); sum[f] = 0.f; }
-    blend9_gather<P2, PT, NF>(src, sp, n.org, mp, sum, value);
+    if (NF == 1 && ge1) blend9_gather<P2, PT, NF, true>(src, sp, n.org, mp, sum, value);
+    else                blend9_gather<P2, PT, NF, false>(src, sp, n.org, mp, sum, value);
 #pragma unroll
     for (int f = 0; f < NF; f++)
         a.err[f][id] = (float)(0.5 * (double)sum[f] + 0.5 * (double)value[f]) - a.init[f][id];

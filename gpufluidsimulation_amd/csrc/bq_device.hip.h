@@ -113,8 +113,18 @@ __device__ __forceinline__ f3 clamp3(f3 p, f3 lo, f3 hi)
 {
     return mk3(clampf(p.x, lo.x, hi.x), clampf(p.y, lo.y, hi.y), clampf(p.z, lo.z, hi.z));
 }
+// The same clamp as one v_med3_f32 per component, for lo <= hi: the median of (a, lo, hi) is the clamped value, and
+// for a NaN the instruction returns min3 = lo, which is what fminf(fmaxf(lo, NaN), hi) gives.
+__device__ __forceinline__ f3 clamp3_ordered(f3 p, f3 lo, f3 hi)
+{
+    return mk3(__builtin_amdgcn_fmed3f(p.x, lo.x, hi.x), __builtin_amdgcn_fmed3f(p.y, lo.y, hi.y), __builtin_amdgcn_fmed3f(p.z, lo.z, hi.z));
+}
 
 // GPU_kernel.cu:22-25 with the (1.0 - c) factor hoisted (it is exact to hoist: same value)
+// FMA: the caller vouches that c is a multiple of 2^-28 (true for c = q - floor(q) whenever q >= 2^-5; the kernels test
+// q >= 1).  Then omc = 1 - c has at most 29 significant bits, omc*a at most 53: the product is exact in double and
+// fma(omc, a, cb) rounds exactly like the contract's separate multiply and add -- one f64 instruction fewer per lerp.
+template <bool FMA = false>
 __device__ __forceinline__ float lerp_w(float a, float b, float c, double omc)
 {
 #ifdef BQ_FAST_LERP
@@ -122,6 +132,7 @@ __device__ __forceinline__ float lerp_w(float a, float b, float c, double omc)
     return __builtin_fmaf(c, b - a, a);
 #else
     float cb = c * b;
+    if (FMA) return (float)__builtin_fma(omc, (double)a, (double)cb);
     return (float)(omc * (double)a + (double)cb);
 #endif
 }
@@ -172,7 +183,9 @@ struct Cell {
     float fx, fy, fz;
 };
 
-template <bool P2>
+// NONNEG: the caller vouches that pos - off >= 0 on every axis (positions clamped into the grid, origins <= 0).
+// Then q - floor(q) is exact and below 1, which is what v_fract_f32 returns: one instruction instead of two.
+template <bool P2, bool NONNEG = false>
 __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off, f3 pos)
 {
     float qx = div_h<P2>(pos.x - off.x, sp);
@@ -182,7 +195,8 @@ __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off
     // infinity, which is floor followed by the (exact) conversion for every |q| < 2^31
     const int i = floor_to_int(qx), j = floor_to_int(qy), k = floor_to_int(qz);
     Cell c;
-    c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k;
+    if (NONNEG) { c.fx = __builtin_amdgcn_fractf(qx); c.fy = __builtin_amdgcn_fractf(qy); c.fz = __builtin_amdgcn_fractf(qz); }
+    else { c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k; }
     int idx = i + f.nx * j + f.nx * f.ny * (k - f.koff);
     c.base = idx < 0 ? 0x80000000u : (unsigned)idx * 4u;    // negative base: every corner out of range (see corners())
     return c;
@@ -205,18 +219,19 @@ __device__ __forceinline__ void corners(const Field &f, const Cell &c, float (&v
 }
 
 // GPU_kernel.cu:27-41 + :53-61
+template <bool FMA = false>
 __device__ __forceinline__ float gather(const Field &f, const Cell &c)
 {
     float v[8];
     corners(f, c, v);
     double ox = 1.0 - (double)c.fx, oy = 1.0 - (double)c.fy, oz = 1.0 - (double)c.fz;
-    float l00 = lerp_w(v[0], v[1], c.fx, ox);
-    float l01 = lerp_w(v[2], v[3], c.fx, ox);
-    float l10 = lerp_w(v[4], v[5], c.fx, ox);
-    float l11 = lerp_w(v[6], v[7], c.fx, ox);
-    float m0 = lerp_w(l00, l01, c.fy, oy);
-    float m1 = lerp_w(l10, l11, c.fy, oy);
-    return lerp_w(m0, m1, c.fz, oz);
+    float l00 = lerp_w<FMA>(v[0], v[1], c.fx, ox);
+    float l01 = lerp_w<FMA>(v[2], v[3], c.fx, ox);
+    float l10 = lerp_w<FMA>(v[4], v[5], c.fx, ox);
+    float l11 = lerp_w<FMA>(v[6], v[7], c.fx, ox);
+    float m0 = lerp_w<FMA>(l00, l01, c.fy, oy);
+    float m1 = lerp_w<FMA>(l10, l11, c.fy, oy);
+    return lerp_w<FMA>(m0, m1, c.fz, oz);
 }
 
 // GPU_kernel.cu:43-62 sample_buffer

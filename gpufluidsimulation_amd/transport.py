@@ -50,6 +50,7 @@ class HostStagedTransport:
         lib.fl_comm_set_custom(self.rank, self.world, C.cast(self._ex, C.c_void_p), C.cast(self._ar, C.c_void_p))
         self.exchanges = 0
         self.planes_moved = 0
+        self.trace = None                       # set to [] to record (fields, depth, bytes sent per neighbour) per exchange
 
     def _get(self, ptr, offset_elems, count):
         out = np.empty(count, dtype=np.float32)
@@ -87,6 +88,8 @@ class HostStagedTransport:
             self._put(ptr, off, recv.numpy())
         self.exchanges += 1
         self.planes_moved += n * depth
+        if self.trace is not None:
+            self.trace.append((n, depth, 4 * sum(plane_elems[f] * depth for f in range(n))))
 
     def _allreduce(self, host, count, is_double, is_max):
         torch, dist = self.torch, self.dist

@@ -86,7 +86,11 @@ def main():
     names = ["rho", "T", "div", "p", "u", "v", "w", "uinit", "vinit", "winit", "rhoinit", "Tinit"]
     plane = {"u": (ni + 1) * nj, "uinit": (ni + 1) * nj, "v": ni * (nj + 1), "vinit": ni * (nj + 1)}
     bad = 0
+    if os.environ.get("SLAB_TEST_TRACE") == "1":
+        tr.trace = []
     for f in range(a.steps):
+        if tr.trace is not None:
+            tr.trace.append(("step", f, 0))
         o.advance(f, dt)
         s.advance(f, dt)
         s._check()
@@ -114,6 +118,8 @@ def main():
     moved = np.abs(o.field("v")).max()
     print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} "
           f"max|v|={moved:.4f} mismatches={bad}", flush=True)
+    if tr.trace is not None and rank == 0:
+        print(f"[rank 0] exchange trace (fields, depth, bytes per neighbour): {[t for t in tr.trace if not (t[0] == 1 and t[1] == a.ghost)]}", flush=True)
     ok = torch.tensor([bad])
     dist.all_reduce(ok)
     s.close()
