@@ -410,3 +410,94 @@ def test_clamp_extrema_corrected(gm, ni, nj, nk, h):
         assert F.same(ref, dc.numpy()), (dx, dy, dz)
         assert F.same(field, df.numpy())
     bq.check()
+
+
+def wild_maps(ni, nj, nk, h, phase):
+    """Maps that leave the comfortable range on purpose: the zero border the DMC update leaves behind,
+    positions inside the first cell (q < 1: the lerps must take the contract's two-rounding form), exact zeros,
+    positions outside the domain on both sides, tiny values next to large ones (the 3/4*a midpoint case of the
+    constant-weight lerps), infinities and NaNs.  Deterministic (no RNG)."""
+    maps = F.warped_maps(ni, nj, nk, h, 0.9, phase)
+    n = ni * nj * nk
+    idx = np.arange(n)
+    k, j, i = idx // (ni * nj), (idx // ni) % nj, idx % ni
+    border = (i <= 1) | (i >= ni - 2) | (j <= 1) | (j >= nj - 2) | (k <= 1) | (k >= nk - 2)
+    out = []
+    for c, m in enumerate(maps):
+        m = m.copy()
+        m[border] = 0.0                                                  # Q13
+        sel = (idx * 7 + c * 3) % 23
+        m[sel == 0] *= np.float32(0.01)                                  # inside the first cell
+        m[sel == 1] = np.float32(h) * np.float32(0.999)
+        m[sel == 2] = -m[sel == 2]                                       # below the domain
+        m[sel == 3] *= np.float32(3.0)                                   # possibly above it
+        m[sel == 4] = np.float32(1e-30)                                  # tiny next to O(1)
+        m[sel == 5] = np.float32(2.0 ** -60)
+        m[(idx % 997) == 5 + c] = np.nan
+        m[(idx % 1013) == 7 + c] = np.inf
+        m[(idx % 1019) == 11 + c] = -np.inf
+        out.append(np.ascontiguousarray(m.astype(np.float32)))
+    return out
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS + [(40, 24, 16, 1.0 / 64)])
+def test_gather_ops_on_wild_maps(gm, ni, nj, nk, h):
+    """advect / compensate-error / accumulate, one and two fields, on maps that hit every special case of the
+    structured look-up and of the sample weights (see wild_maps): still bit-identical to the oracle."""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    h = float(np.float32(h))
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    vel = F.velocity(ni, nj, nk, h)
+    fwd, back = wild_maps(ni, nj, nk, h, 0.3), wild_maps(ni, nj, nk, h, 1.1)
+    m = gm(ni, nj, nk, h)
+    dfwd, dback, dvel = dev(*fwd), dev(*back), dev(*vel)
+    # advect (backward map), three staggered components + a scalar
+    ref = [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+    oracle().orc_advect_velocity(*map(fp, ref), *map(fp, vel), *map(fp, back), h, ni, nj, nk, 0)
+    out = dev(*[np.zeros(c, np.float32) for c in (nu, nv, nw)])
+    m.advectVelocity(*out, *dvel, *dback, False)
+    for r, g in zip(ref, out):
+        assert F.same(r, g.numpy())
+    # accumulate (forward map), coefficient != 1
+    init = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    racc = [a.copy() for a in init]
+    oracle().orc_accumulate_velocity(*map(fp, vel), *map(fp, racc), *map(fp, fwd), h, ni, nj, nk, 0, -0.5)
+    dacc = dev(*init)
+    m.accumulateVelocity(*dvel, *dacc, *dfwd, False, -0.5)
+    for r, g in zip(racc, dacc):
+        assert F.same(r, g.numpy())
+    # full compensation of the velocity (error, back-mapped correction, limiter)
+    cur = [F.scalar(ni + 1, nj, nk, 1.1), F.scalar(ni, nj + 1, nk, 1.2), F.scalar(ni, nj, nk + 1, 1.3)]
+    ru, ri, rs = [a.copy() for a in cur], [a.copy() for a in vel], [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+    oracle().orc_compensate_velocity(*map(fp, ru), *map(fp, ri), *map(fp, rs), *map(fp, fwd), *map(fp, back), h, ni, nj, nk, 0)
+    du, di = dev(*cur), dev(*vel)
+    m.compensateVelocity(*du, *di, *dfwd, *dback, False)
+    for r, g in zip(ru + ri, du + di):
+        assert F.same(r, g.numpy())
+    # the two-field forms
+    a_init, b_init = F.scalar(ni, nj, nk, 0.4), F.scalar(ni, nj, nk, 1.9, amp=2.0)
+    ra, rb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oracle().orc_advect_field(fp(ra), fp(a_init), *map(fp, back), h, ni, nj, nk, 0)
+    oracle().orc_advect_field(fp(rb), fp(b_init), *map(fp, back), h, ni, nj, nk, 0)
+    da, db, dai, dbi = dev(np.zeros(n, np.float32), np.zeros(n, np.float32), a_init, b_init)
+    hip.gpu_advect_field2(da.ptr, dai.ptr, db.ptr, dbi.ptr, *[x.ptr for x in dback], h, ni, nj, nk, False)
+    assert F.same(ra, da.numpy()) and F.same(rb, db.numpy())
+    ea, eb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oracle().orc_compensate_error_field(fp(ra), fp(a_init), fp(ea), *map(fp, fwd), h, ni, nj, nk, 0)
+    oracle().orc_compensate_error_field(fp(rb), fp(b_init), fp(eb), *map(fp, fwd), h, ni, nj, nk, 0)
+    dea, deb = dev(np.zeros(n, np.float32), np.zeros(n, np.float32))
+    hip.gpu_compensate_error_field2(da.ptr, dai.ptr, dea.ptr, db.ptr, dbi.ptr, deb.ptr, *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+    assert F.same(ea, dea.numpy()) and F.same(eb, deb.numpy())
+    oracle().orc_accumulate_field(fp(ea), fp(ra), *map(fp, back), h, ni, nj, nk, 0, -0.5)
+    oracle().orc_accumulate_field(fp(eb), fp(rb), *map(fp, back), h, ni, nj, nk, 0, 2.0)
+    hip.gpu_accumulate_field2(dea.ptr, da.ptr, -0.5, deb.ptr, db.ptr, 2.0, *[x.ptr for x in dback], h, ni, nj, nk, False)
+    assert F.same(ra, da.numpy()) and F.same(rb, db.numpy())
+    # the structured look-up and the generic one agree on these maps too
+    hip.fl_set_option(bq._lib.FL_OPT_STRUCTURED_MAPS, 0)
+    out2 = dev(*[np.zeros(c, np.float32) for c in (nu, nv, nw)])
+    m.advectVelocity(*out2, *dvel, *dback, False)
+    hip.fl_set_option(bq._lib.FL_OPT_STRUCTURED_MAPS, 1)
+    for r, g in zip(ref, out2):
+        assert F.same(r, g.numpy())
+    bq.check()
