@@ -121,9 +121,9 @@ __device__ __forceinline__ f3 clamp3_ordered(f3 p, f3 lo, f3 hi)
 }
 
 // GPU_kernel.cu:22-25 with the (1.0 - c) factor hoisted (it is exact to hoist: same value)
-// FMA: the caller vouches that c is a multiple of 2^-28 (true for c = q - floor(q) whenever q >= 2^-5; the kernels test
-// q >= 1).  Then omc = 1 - c has at most 29 significant bits, omc*a at most 53: the product is exact in double and
-// fma(omc, a, cb) rounds exactly like the contract's separate multiply and add -- one f64 instruction fewer per lerp.
+// FMA: the caller vouches that c = q - floor(q) with q >= 1, i.e. c is a multiple of 2^-23.  Then omc = 1 - c has at
+// most 24 significant bits, omc*a at most 48: the product is exact in double and fma(omc, a, cb) rounds exactly like
+// the contract's separate multiply and add -- one f64 instruction fewer per lerp.
 template <bool FMA = false>
 __device__ __forceinline__ float lerp_w(float a, float b, float c, double omc)
 {
@@ -166,6 +166,7 @@ __device__ __forceinline__ float lerp_q(float a, float b, float c)
     return __builtin_fmaf(c, b - a, a);
 #else
     if (c == 0.25f) return lerp_const(a, b, c, 0.75);
+    if (c == 0.0f) return __builtin_fmaf(0.0f, b, a);     // 1*a + 0*b: a for a finite b, NaN otherwise -- one instruction
     return __builtin_fmaf(1.0f - c, a, c * b);
 #endif
 }
@@ -188,9 +189,18 @@ struct Cell {
 template <bool P2, bool NONNEG = false>
 __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off, f3 pos)
 {
-    float qx = div_h<P2>(pos.x - off.x, sp);
-    float qy = div_h<P2>(pos.y - off.y, sp);
-    float qz = div_h<P2>(pos.z - off.z, sp);
+    float qx, qy, qz;
+    if (P2 && NONNEG) {
+        // (pos - off) * (1/h) with 1/h a power of two: scaling commutes with the rounding of the difference, so this
+        // is fl(pos/h - off/h) -- one fma (the product is exact); -off/h is 0 or 1/2
+        qx = __builtin_fmaf(pos.x, sp.inv_h, -off.x * sp.inv_h);
+        qy = __builtin_fmaf(pos.y, sp.inv_h, -off.y * sp.inv_h);
+        qz = __builtin_fmaf(pos.z, sp.inv_h, -off.z * sp.inv_h);
+    } else {
+        qx = div_h<P2>(pos.x - off.x, sp);
+        qy = div_h<P2>(pos.y - off.y, sp);
+        qz = div_h<P2>(pos.z - off.z, sp);
+    }
     // int(floorf(q)) (GPU_kernel.cu:47-49) in one instruction: v_cvt_flr_i32_f32 converts with round-toward-minus-
     // infinity, which is floor followed by the (exact) conversion for every |q| < 2^31
     const int i = floor_to_int(qx), j = floor_to_int(qy), k = floor_to_int(qz);
@@ -224,7 +234,12 @@ __device__ __forceinline__ float gather(const Field &f, const Cell &c)
 {
     float v[8];
     corners(f, c, v);
-    double ox = 1.0 - (double)c.fx, oy = 1.0 - (double)c.fy, oz = 1.0 - (double)c.fz;
+    double ox, oy, oz;
+    if (FMA) {      // weights are multiples of 2^-23 here (q >= 1), so 1 - c is exact in fp32 as well
+        ox = (double)(1.0f - c.fx); oy = (double)(1.0f - c.fy); oz = (double)(1.0f - c.fz);
+    } else {
+        ox = 1.0 - (double)c.fx; oy = 1.0 - (double)c.fy; oz = 1.0 - (double)c.fz;
+    }
     float l00 = lerp_w<FMA>(v[0], v[1], c.fx, ox);
     float l01 = lerp_w<FMA>(v[2], v[3], c.fx, ox);
     float l10 = lerp_w<FMA>(v[4], v[5], c.fx, ox);
