@@ -104,6 +104,7 @@ FL_OK, FL_ERR_NO_DEVICE, FL_ERR_HIP, FL_ERR_BAD_ARGUMENT, FL_ERR_UNSUPPORTED, FL
 FL_OPT_RESIDUAL_STRIDE, FL_OPT_SKIP_UNIT_BLEND, FL_OPT_JACOBI_VARIANT = 1, 2, 3
 FL_OPT_PROFILE_JACOBI, FL_OPT_JACOBI_KCHUNK, FL_OPT_JACOBI_ROWS, FL_OPT_STRUCTURED_MAPS = 4, 5, 6, 7
 FL_OPT_JACOBI_FUSE, FL_OPT_JACOBI_KCHUNK2, FL_OPT_MGCG_GRAPH, FL_OPT_FAST_LERP = 8, 9, 10, 11
+FL_OPT_FUSED_HOUSEKEEPING = 12
 
 
 class BimocqLibraryMissing(RuntimeError):

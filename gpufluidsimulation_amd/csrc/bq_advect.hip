@@ -27,12 +27,13 @@ static const dim3 kBlock(64, 4, 1);
 // The 9-point kernels on the structured power-of-two path stage the map nodes of their block in LDS
 // (bq_device.hip.h: stage_tiles), so every thread of a block has to reach the barrier: the index window
 // ilo < i < ihi, jlo < j < jhi, klo < kg < khi is tested as a predicate, only whole blocks leave early.
+// block_out: no thread of the block is inside the window (block-uniform, so leaving on it skips no barrier).
 #define BQ_IJK_WINDOW(ilo, ihi, jlo, jhi, klo, khi)                                           \
     const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 4;                                      \
     const int i = i0 + threadIdx.x, j = j0 + threadIdx.y, k = blockIdx.z;                     \
     const int kg = k + g.koff;                                                                \
-    if (!((klo) < kg && kg < (khi)) || i0 + 63 <= (ilo) || i0 >= (ihi) || j0 + 3 <= (jlo) || j0 >= (jhi)) return; \
-    const bool active = (ilo) < i && i < (ihi) && (jlo) < j && j < (jhi);
+    const bool block_out = !((klo) < kg && kg < (khi)) || i0 + 63 <= (ilo) || i0 >= (ihi) || j0 + 3 <= (jlo) || j0 >= (jhi); \
+    const bool active = !block_out && (ilo) < i && i < (ihi) && (jlo) < j && j < (jhi);
 template <bool P2, bool PT, int SD> constexpr bool kStaged = P2 && !PT && SD >= 0;
 
 // CELL dims of the LOCAL buffers plus the z-slab context: local plane k is global plane k + koff of a
@@ -89,10 +90,20 @@ template <bool P2>
 __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v, const float *w,
                                                   const float *xi, const float *yi, const float *zi,
                                                   float *xo, float *yo, float *zo,
-                                                  Spacing sp, Grid g, float substep)
+                                                  Spacing sp, Grid g, float substep, int border)
 {
     BQ_IJK(g.ni, g.nj, g.nk)
-    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) return;
+    if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) {
+        // border nodes are not updated (GPU_kernel.cu:175).  FL_OPT_FUSED_HOUSEKEEPING bits 4 / 8: the kernel itself
+        // leaves there what the caller would otherwise have to prepare -- zeros (the reference's cleared scratch)
+        // or the input map's value
+        if (border) {
+            const size_t b = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
+            const bool copy = border == 2;
+            xo[b] = copy ? xi[b] : 0.f; yo[b] = copy ? yi[b] : 0.f; zo[b] = copy ? zi[b] : 0.f;
+        }
+        return;
+    }
     const float h = sp.h;
     Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk, g.koff), make_field(v, g.ni, g.nj + 1, g.nk, g.koff), make_field(w, g.ni, g.nj, g.nk + 1, g.koff)};
     Map3 in{make_field(xi, g.ni, g.nj, g.nk, g.koff), make_field(yi, g.ni, g.nj, g.nk, g.koff), make_field(zi, g.ni, g.nj, g.nk, g.koff)};
@@ -177,16 +188,22 @@ __device__ __forceinline__ bool wave_all_ge(const f3 (&mp)[9], float h)
 // launches in the same order produce.
 template <int NF> struct AdvectArgs { float *field[NF]; const float *init[NF]; };
 template <int NF> struct CumulateArgs { const float *src[NF]; float *dst[NF]; float coeff[NF]; };
-template <int NF> struct CompensateArgs { const float *src[NF]; const float *init[NF]; float *err[NF]; };
+template <int NF> struct CompensateArgs { const float *src[NF]; float *init[NF]; float *err[NF]; };
 
 // ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
 template <bool P2, bool PT, int SD, int NF>
 __global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void advect_kernel(AdvectArgs<NF> a,
                                                      const float *bx, const float *by, const float *bz,
-                                                     Spacing sp, Grid g, int dx, int dy, int dz)
+                                                     Spacing sp, Grid g, int dx, int dy, int dz, int fused)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK_WINDOW(2 + dx, nbi - 3, 2 + dy, nbj - 3, 2 + dz, g.nkg + dz - 3)
+    // FL_OPT_FUSED_HOUSEKEEPING bit 1: nodes outside the window get the zero the caller's clear would have left
+    if ((fused & 1) && !active && i < nbi && j < nbj) {
+#pragma unroll
+        for (int f = 0; f < NF; f++) a.field[f][(size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k] = 0.f;
+    }
+    if (block_out) return;
     const float h = sp.h;
     Map3 back{make_field(bx, g.ni, g.nj, g.nk, g.koff), make_field(by, g.ni, g.nj, g.nk, g.koff), make_field(bz, g.ni, g.nj, g.nk, g.koff)};
     Nine n = nine_setup(h, dx, dy, dz);
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(256, 6) void cumulate_kernel(CumulateArgs<NF> a,
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK_WINDOW(1 + dx, nbi - 2, 1 + dy, nbj - 2, 1 + dz, g.nkg + dz - 2)
+    if (block_out) return;
     const float h = sp.h;
     Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
     Nine n = nine_setup(h, dx, dy, dz);
@@ -339,10 +357,25 @@ __global__ __launch_bounds__(256, 6) void cumulate_kernel(CumulateArgs<NF> a,
 template <bool P2, bool PT, int SD, int NF>
 __global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a,
                                                          const float *mx, const float *my, const float *mz,
-                                                         Spacing sp, Grid g, int dx, int dy, int dz)
+                                                         Spacing sp, Grid g, int dx, int dy, int dz, int fused)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK_WINDOW(1 + dx, nbi - 2, 1 + dy, nbj - 2, 1 + dz, g.nkg + dz - 2)
+    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    // FL_OPT_FUSED_HOUSEKEEPING.  Bit 2: init <- the uncompensated field, on EVERY node of the buffer (stage 2 of
+    // gpu_compensate_*, GPU_kernel.cu:656-658).  A thread reads init only at its own node, before it stores there,
+    // and no thread reads init anywhere else or writes src, so doing it here is race-free.  Bit 1: err = 0 outside
+    // the window (the caller's clear).
+    float init_own[NF];
+    if (i < nbi && j < nbj) {
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            init_own[f] = a.init[f][id];
+            if (fused & 2) a.init[f][id] = a.src[f][id];
+            if ((fused & 1) && !active) a.err[f][id] = 0.f;
+        }
+    }
+    if (block_out) return;
     const float h = sp.h;
     Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
     Nine n = nine_setup(h, dx, dy, dz);
@@ -362,7 +395,6 @@ __global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a
     const bool ge1 = NF == 1 && wave_all_ge<PT>(mp, h);   // (two fields: both code paths together need too many registers)
 #pragma unroll
     for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3_ordered(mp[a9], lo, hi);
-    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     Field src[NF];
     float sum[NF], value[NF];
 #pragma unroll
@@ -371,7 +403,7 @@ __global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a
     else                blend9_gather<P2, PT, NF, false>(src, sp, n.org, mp, sum, value);
 #pragma unroll
     for (int f = 0; f < NF; f++)
-        a.err[f][id] = (float)(0.5 * (double)sum[f] + 0.5 * (double)value[f]) - a.init[f][id];
+        a.err[f][id] = (float)(0.5 * (double)sum[f] + 0.5 * (double)value[f]) - init_own[f];
 }
 
 // ---- A6: clampExtrema_kernel (GPU_kernel.cu:146-167) --------------------------------------
@@ -551,7 +583,7 @@ static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, con
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
     hipStream_t st = rt().compute;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
-        advect_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz);
+        advect_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
     });
     BQ_LAUNCH_CHECK("advect_kernel");
 }
@@ -580,7 +612,7 @@ static void compensate_multi(CompensateArgs<NF> a, const float *mx, const float 
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
     hipStream_t st = rt().compute;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
-        compensate_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz);
+        compensate_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
     });
     BQ_LAUNCH_CHECK("compensate_kernel");
 }
@@ -595,7 +627,7 @@ static void cumulate_comp(const float *src, float *dst, const float *mx, const f
 {
     cumulate_multi<1>(CumulateArgs<1>{{src}, {dst}, {coeff}}, mx, my, mz, sp, g, dx, dy, dz, pt, identity);
 }
-static void compensate_comp(const float *src, const float *init, float *err, const float *mx, const float *my, const float *mz,
+static void compensate_comp(const float *src, float *init, float *err, const float *mx, const float *my, const float *mz,
                             Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
     compensate_multi<1>(CompensateArgs<1>{{src}, {init}, {err}}, mx, my, mz, sp, g, dx, dy, dz, pt);
@@ -742,7 +774,8 @@ BQ_ENTRY(gpu_solve_backwardDMC, (float *u, float *v, float *w, float *x_in, floa
     BQ_ENTER("gpu_solve_backwardDMC", u, v, w, x_in, y_in, z_in, x_out, y_out, z_out)
     BQ_REQUIRE(x_in != x_out && y_in != y_out && z_in != z_out, "gpu_solve_backwardDMC");
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
-    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep);
+    const int border = (rt().opt_fused_housekeeping & 8) ? 2 : (rt().opt_fused_housekeeping & 4) ? 1 : 0;
+    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep, border);
 }
 
 BQ_ENTRY(gpu_advect_velocity, (float *u, float *v, float *w, float *u_init, float *v_init, float *w_init,
@@ -907,9 +940,11 @@ BQ_ENTRY(gpu_compensate_velocity, (float *u, float *v, float *w, float *du, floa
     compensate_comp(v, dv, v_src, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point);
     compensate_comp(w, dw, w_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point);
     // d* <- uncompensated field (:656-658; clobbers the caller's `init`)
-    fl_memcpy_d2d(du, u, nu * sizeof(float));
-    fl_memcpy_d2d(dv, v, nv * sizeof(float));
-    fl_memcpy_d2d(dw, w, nw * sizeof(float));
+    if (!(rt().opt_fused_housekeeping & 2)) {        // (with that bit the error kernels have stored it already)
+        fl_memcpy_d2d(du, u, nu * sizeof(float));
+        fl_memcpy_d2d(dv, v, nv * sizeof(float));
+        fl_memcpy_d2d(dw, w, nw * sizeof(float));
+    }
     // subtract half the back-mapped error (:659-661)
     cumulate_comp(u_src, u, backward_x, backward_y, backward_z, sp, g, 1, 0, 0, is_point, -0.5f);
     cumulate_comp(v_src, v, backward_x, backward_y, backward_z, sp, g, 0, 1, 0, is_point, -0.5f);
@@ -928,7 +963,7 @@ BQ_ENTRY(gpu_compensate_field, (float *u, float *du, float *u_src,
     BQ_ENTER("gpu_compensate_field", u, du, u_src, forward_x, forward_y, forward_z, backward_x, backward_y, backward_z)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 0, is_point);
-    fl_memcpy_d2d(du, u, (size_t)ni * nj * nk * sizeof(float));
+    if (!(rt().opt_fused_housekeeping & 2)) fl_memcpy_d2d(du, u, (size_t)ni * nj * nk * sizeof(float));
     cumulate_comp(u_src, u, backward_x, backward_y, backward_z, sp, g, 0, 0, 0, is_point, -0.5f);
     clamp_box(du, u, ni, nj, nk, 0);
 }

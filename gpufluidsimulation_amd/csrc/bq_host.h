@@ -23,6 +23,7 @@ struct Runtime {
     int         opt_jacobi_fuse = 1;        // 0 never, 1 inside gpu_projection_jacobi, 2 also in gpu_jacobi_sweeps
     int         opt_jacobi_kchunk2 = 0;     // planes per block of the fused kernel (0 = auto)    // structured (compile-time taps) map look-up on power-of-two spacing
     int         opt_jacobi_kchunk = 0;      // 0 = auto
+    int         opt_fused_housekeeping = 0; // FL_OPT_FUSED_HOUSEKEEPING bit mask
     int         opt_fast_lerp = 0;          // gather kernels: one fp32 fma per lerp instead of the double-evaluated one
     int         opt_mgcg_graph = 1;         // replay the multigrid V-cycle from a captured hipGraph
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)

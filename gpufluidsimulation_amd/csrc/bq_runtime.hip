@@ -247,6 +247,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_JACOBI_KCHUNK2:  g_rt.opt_jacobi_kchunk2 = value < 0 ? 0 : value; break;
     case FL_OPT_MGCG_GRAPH:      g_rt.opt_mgcg_graph = value != 0; break;
     case FL_OPT_FAST_LERP:       g_rt.opt_fast_lerp = value != 0; break;
+    case FL_OPT_FUSED_HOUSEKEEPING: g_rt.opt_fused_housekeeping = value & 15; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -265,6 +266,7 @@ int fl_get_option(int option)
     case FL_OPT_JACOBI_KCHUNK2:  return g_rt.opt_jacobi_kchunk2;
     case FL_OPT_MGCG_GRAPH:      return g_rt.opt_mgcg_graph;
     case FL_OPT_FAST_LERP:       return g_rt.opt_fast_lerp;
+    case FL_OPT_FUSED_HOUSEKEEPING: return g_rt.opt_fused_housekeeping;
     default: return -1;
     }
 }

@@ -457,8 +457,17 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     // snapshot and that accumulation are not executed (BQ_OPT_FULL_STATE = 1 executes them; every field a caller
     // can observe is the same either way, tests/test_gpu_solver.py).
     const bool prev_dead = !keep_full_state && reinit_policy == 0 && VelocityAdvector.BlendCoeff == 1.f;
-    // :157-159
-    if (!prev_dead) { VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW); }
+    // Buoyancy acts on v only: unless a source imposes its velocity ring this frame or viscosity smooths all three
+    // components, u and w stay what they are until the projection.
+    bool forces_touch_uw = Viscosity != 0.f;
+    for (const Emitter &e : sim_emitter) forces_touch_uw = forces_touch_uw || framenum < e.emitFrame;
+    // :157-159 snapshots for the force delta (:175-177).  The u and w snapshots are only ever read by that delta
+    // (with the Jacobi projection the gradient pass hands out d*Proj, :179-193 needs no snapshot) and by the
+    // viscous diffusion, which uses them as work arrays: not taken when nothing will touch u and w.
+    if (!prev_dead) {
+        if (forces_touch_uw || projection_kind != BQ_PROJECTION_JACOBI) { VelocityUTemp.copy_from(VelocityU); VelocityWTemp.copy_from(VelocityW); }
+        VelocityVTemp.copy_from(VelocityV);
+    }
     // policy 1 follows the CPU solver (BimocqSolver.cpp:129-133): scalar snapshots BEFORE the sources act
     if (policy1) { DensityTemp.copy_from(Density); TemperatureTemp.copy_from(Temperature); }
 
@@ -477,12 +486,9 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
         }
     }
 
-    // :175-177 velocity change due to external forces.  Buoyancy acts on v only: unless a source imposed its
-    // velocity ring this frame or viscosity smoothed all three components, u and w still equal their snapshots,
-    // U - UTemp is identically +0, and accumulating blend9 of a zero field (:213) changes no value -- neither the
-    // difference nor its look-up is executed for u and w then.
-    bool forces_touch_uw = Viscosity != 0.f;
-    for (const Emitter &e : sim_emitter) forces_touch_uw = forces_touch_uw || framenum < e.emitFrame;
+    // :175-177 velocity change due to external forces.  When nothing touched u and w they still equal their
+    // snapshots, U - UTemp is identically +0, and accumulating blend9 of a zero field (:213) changes no value --
+    // neither the difference nor its look-up is executed for u and w then.
     if (prev_dead) {
         // nothing: d*Extern only feeds the accumulation that is dead
     } else if (forces_touch_uw) {

@@ -66,9 +66,12 @@ float gpuMapper::endEventRecord()
 void gpuMapper::advectVelocity(float *u, float *v, float *w, float *ui, float *vi, float *wi,
                                float *bx, float *by, float *bz, bool is_point) const
 {
-    fl_memset(u, 0, g.nu() * sizeof(float));
-    fl_memset(v, 0, g.nv() * sizeof(float));
-    fl_memset(w, 0, g.nw() * sizeof(float));
+    FusedScope fused(fuse_housekeeping, 1);             // the kernels write the zeros outside their window themselves
+    if (!fused.on) {
+        fl_memset(u, 0, g.nu() * sizeof(float));
+        fl_memset(v, 0, g.nv() * sizeof(float));
+        fl_memset(w, 0, g.nw() * sizeof(float));
+    }
     gpu_advect_velocity(u, v, w, ui, vi, wi, bx, by, bz, g.h, g.ni, g.nj, g.nk, is_point);
 }
 
@@ -85,7 +88,8 @@ void gpuMapper::compensateVelocity(float *u, float *v, float *w, float *du, floa
 // GPU_Advection.h:505-511 (sized ni*nj*nk, not the reference's (ni+1)*nj*nk overrun)
 void gpuMapper::advectField(float *f, float *fi, float *bx, float *by, float *bz, bool is_point) const
 {
-    fl_memset(f, 0, g.n() * sizeof(float));
+    FusedScope fused(fuse_housekeeping, 1);
+    if (!fused.on) fl_memset(f, 0, g.n() * sizeof(float));
     gpu_advect_field(f, fi, bx, by, bz, g.h, g.ni, g.nj, g.nk, is_point);
 }
 

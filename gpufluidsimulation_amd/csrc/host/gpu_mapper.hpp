@@ -91,6 +91,24 @@ private:
     size_t n_ = 0;
 };
 
+// FL_OPT_FUSED_HOUSEKEEPING bits for the duration of a scope.  `on` is false when the caller does not want it or
+// the operator library underneath does not implement the option (fl_get_option < 0: the CPU stand-in of the tests);
+// the caller then issues the clears and copies itself.
+struct FusedScope {
+    int prev = -1;
+    bool on = false;
+    FusedScope(bool wanted, int bits)
+    {
+        if (!wanted) return;
+        prev = fl_get_option(FL_OPT_FUSED_HOUSEKEEPING);
+        on = prev >= 0;
+        if (on) fl_set_option(FL_OPT_FUSED_HOUSEKEEPING, bits);
+    }
+    ~FusedScope() { if (on) fl_set_option(FL_OPT_FUSED_HOUSEKEEPING, prev); }
+    FusedScope(const FusedScope &) = delete;
+    FusedScope &operator=(const FusedScope &) = delete;
+};
+
 // z-slab decomposition of the global grid.  Rank `rank` of `nranks` owns the global cell
 // planes [own0, own1) and stores [own0 - G, own1 + G); off = single GPU.
 struct SlabCtx {
@@ -142,6 +160,7 @@ public:
     }
     // scratch owned by the mapper (GPU_Advection.h:122-136)
     DeviceField u_src, v_src, w_src;
+    bool fuse_housekeeping = true;          // BQ_OPT_FUSED_HOUSEKEEPING (see FusedScope)
     DeviceField x_out, y_out, z_out;        // DMC ping buffers (border nodes stay 0, as in the reference)
     DeviceField x_out2, y_out2, z_out2;     // second ping set so sub-steps never copy
 

@@ -61,11 +61,16 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
     DeviceField *in[3] = { &m.BackwardX, &m.BackwardY, &m.BackwardZ };
     DeviceField *ping[2][3] = { { &gs.x_out, &gs.y_out, &gs.z_out }, { &gs.x_out2, &gs.y_out2, &gs.z_out2 } };
     int which = 0;
-    bool any = false;
+    bool any = false, swap_result = false;
     while (T < dt) {
         if (T + substep > dt) substep = dt - T;
         DeviceField **out = ping[which];
-        if (keepDmcBorder) { out[0]->copy_from(*in[0]); out[1]->copy_from(*in[1]); out[2]->copy_from(*in[2]); }
+        // border nodes of the output: zeros (the reference's cleared scratch) or, with keepDmcBorder, the input's
+        // values -- written by the kernel itself when the operator library can do that, else prepared here (the
+        // scratch sets then have to keep their zero border, so the result is copied out rather than swapped)
+        FusedScope fused(gs.fuse_housekeeping, keepDmcBorder ? 8 : 4);
+        swap_result = fused.on;
+        if (keepDmcBorder && !fused.on) { out[0]->copy_from(*in[0]); out[1]->copy_from(*in[1]); out[2]->copy_from(*in[2]); }
         gs.require({ &U, &V, &W, in[0], in[1], in[2] }, kReachDMC);
         gs.solveBackwardDMC(U, V, W, *in[0], *in[1], *in[2], *out[0], *out[1], *out[2], substep);
         const int v = gpuMapper::minValid({ &U, &V, &W, in[0], in[1], in[2] }) - kReachDMC;
@@ -75,7 +80,11 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
         any = true;
         T += substep;
     }
-    if (any) {
+    if (any && swap_result) {
+        // every node of the newest scratch set was written by the last sub-step: it becomes the map, the old map's
+        // buffers become scratch (their content is dead: a sub-step writes all of its output)
+        m.BackwardX.swap(*in[0]); m.BackwardY.swap(*in[1]); m.BackwardZ.swap(*in[2]);
+    } else if (any) {
         m.BackwardX.copy_from(*in[0]); m.BackwardY.copy_from(*in[1]); m.BackwardZ.copy_from(*in[2]);
     }
     m.Dback += dcells;
@@ -119,16 +128,23 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     // stage 1: error at time 0, u_src = blend9(U(psi_fwd(x))) - Ui(x)      (GPU_Advection.h:499-501 zeroes u_src)
     gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
     gs.require({ &U, &V, &W }, reachField(m.Dfwd));
-    gs.u_src.zero(); gs.v_src.zero(); gs.w_src.zero();
-    gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
-                                  m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    bool stage2_done;
+    {
+        // fused: the kernels zero the error outside their window and store U into Ui after reading it (stage 2)
+        FusedScope fused(gs.fuse_housekeeping, 1 | 2);
+        stage2_done = fused.on;
+        if (!fused.on) { gs.u_src.zero(); gs.v_src.zero(); gs.w_src.zero(); }
+        gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
+                                      m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    }
     gs.producedAll({ &gs.u_src, &gs.v_src, &gs.w_src },
                    std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                               gpuMapper::minValid({ &U, &V, &W }) - reachField(m.Dfwd),
                               gpuMapper::minValid({ &Ui, &Vi, &Wi }) }));
     trace_point("v.stage1");
     // stage 2: Ui <- uncompensated U (clobbers the caller's init)
-    Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W);
+    if (stage2_done) { Ui.valid = U.valid; Vi.valid = V.valid; Wi.valid = W.valid; }
+    else { Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W); }
     // stage 3: U += blend9(-0.5 * u_src(psi_back(x)))
     gs.require({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback));
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
@@ -175,14 +191,20 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
 
     gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
     gs.require({ &f }, reachField(m.Dfwd));
-    fl_memset(gs.u_src, 0, g.n() * sizeof(float));            // GPU_Advection.h:526 (u_src doubles as scalar scratch)
-    gpu_compensate_error_field(f, fInit, gs.u_src, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    const int fInit_valid = fInit.valid;
+    bool stage2_done;
+    {
+        FusedScope fused(gs.fuse_housekeeping, 1 | 2);
+        stage2_done = fused.on;
+        if (!fused.on) fl_memset(gs.u_src, 0, g.n() * sizeof(float));     // GPU_Advection.h:526 (u_src doubles as scalar scratch)
+        gpu_compensate_error_field(f, fInit, gs.u_src, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    }
     // u_src is the u-sized scratch: as a scalar field its planes are ni*nj wide
     const size_t saved_plane = gs.u_src.plane;
     gs.u_src.plane = (size_t)ni * nj;
     gs.produced(gs.u_src, std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
-                                     f.valid - reachField(m.Dfwd), fInit.valid }));
-    fInit.copy_from(f);
+                                     f.valid - reachField(m.Dfwd), fInit_valid }));
+    if (stage2_done) fInit.valid = f.valid; else fInit.copy_from(f);
     gs.require({ &gs.u_src }, reachField(m.Dback));
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
     gs.accumulateField(gs.u_src, f, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
@@ -221,21 +243,31 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
 
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
     gs.require({ &f1Init, &f2Init }, reachField(m.Dback));
-    f1.zero(); f2.zero();                                                   // GPU_Advection.h:507
-    gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+    {
+        FusedScope fused(gs.fuse_housekeeping, 1);
+        if (!fused.on) { f1.zero(); f2.zero(); }                            // GPU_Advection.h:507
+        gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+    }
     gs.produced(f1, std::min(back() - kReachMap, f1Init.valid - reachField(m.Dback)));
     gs.produced(f2, std::min(back() - kReachMap, f2Init.valid - reachField(m.Dback)));
 
     gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
     gs.require({ &f1, &f2 }, reachField(m.Dfwd));
     DeviceField &e1 = gs.u_src, &e2 = gs.v_src;                             // scalar-sized use of the scratches
-    fl_memset(e1, 0, g.n() * sizeof(float)); fl_memset(e2, 0, g.n() * sizeof(float));
-    gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    const int f1Init_valid = f1Init.valid, f2Init_valid = f2Init.valid;
+    bool stage2_done;
+    {
+        FusedScope fused(gs.fuse_housekeeping, 1 | 2);
+        stage2_done = fused.on;
+        if (!fused.on) { fl_memset(e1, 0, g.n() * sizeof(float)); fl_memset(e2, 0, g.n() * sizeof(float)); }
+        gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+    }
     const size_t plane1 = e1.plane, plane2 = e2.plane;
     e1.plane = e2.plane = (size_t)ni * nj;
-    gs.produced(e1, std::min({ fwd() - kReachMap, f1.valid - reachField(m.Dfwd), f1Init.valid }));
-    gs.produced(e2, std::min({ fwd() - kReachMap, f2.valid - reachField(m.Dfwd), f2Init.valid }));
-    f1Init.copy_from(f1); f2Init.copy_from(f2);
+    gs.produced(e1, std::min({ fwd() - kReachMap, f1.valid - reachField(m.Dfwd), f1Init_valid }));
+    gs.produced(e2, std::min({ fwd() - kReachMap, f2.valid - reachField(m.Dfwd), f2Init_valid }));
+    if (stage2_done) { f1Init.valid = f1.valid; f2Init.valid = f2.valid; }
+    else { f1Init.copy_from(f1); f2Init.copy_from(f2); }
     gs.require({ &e1, &e2 }, reachField(m.Dback));
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
     gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);

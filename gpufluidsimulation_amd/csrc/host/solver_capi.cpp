@@ -90,6 +90,12 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         s->solver->ScalarAdvector.keepDmcBorder = value != 0;
     } else if (option == BQ_OPT_FULL_STATE) {
         s->solver->keep_full_state = value != 0;
+    } else if (option == BQ_OPT_FUSED_HOUSEKEEPING) {
+        bqhost::gpuMapper &gm = *s->solver->GpuSolver;
+        gm.fuse_housekeeping = value != 0;
+        if (!value) {   // the unfused DMC update relies on scratch sets whose border nodes are zero; swaps may have left map data there
+            gm.x_out.zero(); gm.y_out.zero(); gm.z_out.zero(); gm.x_out2.zero(); gm.y_out2.zero(); gm.z_out2.zero();
+        }
     } else if (option == BQ_OPT_REINIT_POLICY) {
         s->solver->setReinitPolicy(value);
         s->solver->ScalarAdvector.keepDmcBorder = s->solver->VelocityAdvector.keepDmcBorder;

@@ -114,7 +114,8 @@ class BimocqGPUSolver:
         return out
 
     def setOption(self, option, value):
-        """option 1 = BQ_OPT_KEEP_DMC_BORDER, 2 = BQ_OPT_REINIT_POLICY (0 every frame, 1 distortion-driven)"""
+        """option 1 = BQ_OPT_KEEP_DMC_BORDER, 2 = BQ_OPT_REINIT_POLICY (0 every frame, 1 distortion-driven),
+        3 = BQ_OPT_FULL_STATE, 4 = BQ_OPT_FUSED_HOUSEKEEPING (include/bimocq_solver.h)"""
         self.lib.bq_solver_set_option(self.s, option, value)
         self._check()
 

@@ -254,6 +254,15 @@ enum {
     FL_OPT_JACOBI_KCHUNK2  = 9, /* planes marched per block in the fused kernel (0 = auto)           */
     FL_OPT_MGCG_GRAPH      = 10,/* 1 (default): the multigrid V-cycle is captured into a hipGraph once and
                                  * replayed in every outer iteration; 0: plain launches                */
+    FL_OPT_FUSED_HOUSEKEEPING = 12, /* bit mask, default 0 (the reference's operator semantics).  Lets a caller drop the clears
+                                 * and copies it issues around the map operators; what each bit makes the kernels do:
+                                 *   1: gpu_advect_velocity/_field/_field2 and gpu_compensate_error_* write zeros outside their
+                                 *      index window -- the outputs need not be cleared first (GPU_Advection.h:472-526);
+                                 *   2: gpu_compensate_error_* store the uncompensated field into `init` (du/dv/dw) after
+                                 *      reading it -- stage 2 of gpu_compensate_* (GPU_kernel.cu:656-658) needs no copy;
+                                 *   4: gpu_solve_backwardDMC writes zeros to the border nodes of x/y/z_out (what the
+                                 *      reference's cleared scratch holds there, GPU_Advection.h:464-468);
+                                 *   8: gpu_solve_backwardDMC copies the border nodes of x/y/z_in to x/y/z_out instead.  */
     FL_OPT_FAST_LERP       = 11 /* 0 (default): the reference's double-evaluated lerp, results bit-identical to the
                                  * oracle.  1: every lerp of the gather kernels is one fp32 fma, fmaf(c, b-a, a) --
                                  * ~3 orders of magnitude inside the 1e-5 RMS tolerance after 200 steps, the gather

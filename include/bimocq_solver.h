@@ -68,7 +68,11 @@ enum {
      * frame the *Prev fields are never sampled, so the pre-reinit accumulation into *Init (which only survives as
      * *Prev) and the force delta feeding it are skipped.  1: execute the reference's full sequence.  Every field
      * reachable through this API, and every dump, is identical either way. */
-    BQ_OPT_FULL_STATE = 3
+    BQ_OPT_FULL_STATE = 3,
+    /* 1 (default): the clears and copies the reference issues around the map operators (GPU_Advection.h:464-526,
+     * GPU_kernel.cu:656-658) are done by the kernels themselves (FL_OPT_FUSED_HOUSEKEEPING of the operator ABI):
+     * same values in every buffer, ~25 fewer memset/memcpy launches per step.  0: separate launches. */
+    BQ_OPT_FUSED_HOUSEKEEPING = 4
 };
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
  * last step measured (policy 1; 0 otherwise) */

@@ -501,3 +501,72 @@ def test_gather_ops_on_wild_maps(gm, ni, nj, nk, h):
     for r, g in zip(ref, out2):
         assert F.same(r, g.numpy())
     bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_fused_housekeeping_bits(gm, ni, nj, nk, h):
+    """FL_OPT_FUSED_HOUSEKEEPING, bit by bit, against the plain operator sequence it replaces: outputs that were NOT
+    cleared come out with zero borders (1), the error kernels leave the uncompensated field in `init` (2), the DMC
+    update writes zero (4) or copied (8) border nodes into an uncleared output."""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    OPT = bq._lib.FL_OPT_FUSED_HOUSEKEEPING
+    h, vel, fwd, back, _ = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    gm(ni, nj, nk, h)
+    dvel, dfwd, dback = dev(*vel), dev(*fwd), dev(*back)
+    junk = lambda c: np.full(c, 7.5, np.float32)
+    # bit 1: advect
+    ref = dev(*[np.zeros(c, np.float32) for c in (nu, nv, nw)])
+    hip.gpu_advect_velocity(*[x.ptr for x in ref], *[x.ptr for x in dvel], *[x.ptr for x in dback], h, ni, nj, nk, False)
+    out = dev(junk(nu), junk(nv), junk(nw))
+    hip.fl_set_option(OPT, 1)
+    hip.gpu_advect_velocity(*[x.ptr for x in out], *[x.ptr for x in dvel], *[x.ptr for x in dback], h, ni, nj, nk, False)
+    hip.fl_set_option(OPT, 0)
+    for r, g in zip(ref, out):
+        assert F.same(r.numpy(), g.numpy())
+    # bits 1 | 2: error stage, velocity and two scalars at once
+    cur = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    dcur = dev(*cur)
+    init_ref, err_ref = dev(*vel), dev(*[np.zeros(c, np.float32) for c in (nu, nv, nw)])
+    hip.gpu_compensate_error_velocity(*[x.ptr for x in dcur], *[x.ptr for x in init_ref], *[x.ptr for x in err_ref],
+                                      *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+    init_f, err_f = dev(*vel), dev(junk(nu), junk(nv), junk(nw))
+    hip.fl_set_option(OPT, 3)
+    hip.gpu_compensate_error_velocity(*[x.ptr for x in dcur], *[x.ptr for x in init_f], *[x.ptr for x in err_f],
+                                      *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+    hip.fl_set_option(OPT, 0)
+    for r, g in zip(err_ref, err_f):
+        assert F.same(r.numpy(), g.numpy())
+    for c, v0, r, g in zip(cur, vel, init_ref, init_f):
+        assert F.same(v0, r.numpy())                             # the plain operator leaves init alone
+        assert F.same(c, g.numpy())                              # fused: init now holds the uncompensated field
+    a, b = F.scalar(ni, nj, nk, 0.4), F.scalar(ni, nj, nk, 1.9, amp=2.0)
+    ai, bi = F.scalar(ni, nj, nk, 2.4), F.scalar(ni, nj, nk, 0.7)
+    da, db = dev(a, b)
+    r_ai, r_bi, r_ea, r_eb = dev(ai, bi, np.zeros(n, np.float32), np.zeros(n, np.float32))
+    hip.gpu_compensate_error_field2(da.ptr, r_ai.ptr, r_ea.ptr, db.ptr, r_bi.ptr, r_eb.ptr, *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+    f_ai, f_bi, f_ea, f_eb = dev(ai, bi, junk(n), junk(n))
+    hip.fl_set_option(OPT, 3)
+    hip.gpu_compensate_error_field2(da.ptr, f_ai.ptr, f_ea.ptr, db.ptr, f_bi.ptr, f_eb.ptr, *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+    hip.fl_set_option(OPT, 0)
+    assert F.same(r_ea.numpy(), f_ea.numpy()) and F.same(r_eb.numpy(), f_eb.numpy())
+    assert F.same(a, f_ai.numpy()) and F.same(b, f_bi.numpy())
+    # bits 4 / 8: DMC border
+    xin = dev(*back)
+    plain = dev(*[np.zeros(n, np.float32) for _ in range(3)])
+    hip.gpu_solve_backwardDMC(*[x.ptr for x in dvel], *[x.ptr for x in xin], *[x.ptr for x in plain], h, ni, nj, nk, 0.4 * h)
+    for bits, start in ((4, None), (8, back)):
+        out = dev(junk(n), junk(n), junk(n))
+        hip.fl_set_option(OPT, bits)
+        hip.gpu_solve_backwardDMC(*[x.ptr for x in dvel], *[x.ptr for x in xin], *[x.ptr for x in out], h, ni, nj, nk, 0.4 * h)
+        hip.fl_set_option(OPT, 0)
+        for c in range(3):
+            want = plain[c].numpy().copy()
+            if start is not None:                       # what a copy of the input before the update would have left
+                idx = np.arange(n); k, j, i = idx // (ni * nj), (idx // ni) % nj, idx % ni
+                border = (i <= 1) | (i >= ni - 2) | (j <= 1) | (j >= nj - 2) | (k <= 1) | (k >= nk - 2)
+                want[border] = start[c][border]
+            assert F.same(want, out[c].numpy()), (bits, c)
+    assert hip.fl_get_option(OPT) == 0
+    bq.check()

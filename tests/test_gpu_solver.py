@@ -297,3 +297,43 @@ def test_fast_lerp_variant():
         hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
         oracle().orc_set_fast_lerp(0)
     s.close(); exact.close(); fast.close()
+
+
+@pytest.mark.parametrize("keep_border", [0, 1])
+def test_fused_housekeeping_equals_separate_launches(keep_border):
+    """BQ_OPT_FUSED_HOUSEKEEPING (default 1: the kernels write the zero borders, store the uncompensated field and
+    fill the DMC border themselves; the backward map is swapped in, not copied) against the separate memset/memcpy
+    launches of the reference, and both against the oracle: every field bit-identical after every step.  Two DMC
+    sub-steps per frame in the later frames, blend < 1, with and without BQ_OPT_KEEP_DMC_BORDER."""
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    dims, L = (32, 24, 40), 1.0
+    em = [(0.5, 0.25, 0.6, 0.14, 1.0, 1.5, 0.0, 2)]
+    o = OracleSolver(*dims, L, 0.0, 0.8); o.set_smoke(0.0, 1.0, em); o.set_projection(30, 0.5)
+    if keep_border:
+        o.set_option(1, 1)
+    sol = []
+    for fused in (1, 0):
+        s = BimocqGPUSolver(*dims, L, 0.0, 0.8); s.setSmoke(0.0, 1.0, em); s.setProjection(30, 0.5)
+        s.setOption(3, 1)                       # full state: the *Prev fields are computed and compared too
+        if keep_border:
+            s.setOption(1, 1)
+        s.setOption(4, fused)
+        sol.append(s)
+    dt = 3.0 * L / dims[0]
+    for f in range(7):
+        o.advance(f, dt)
+        for s in sol:
+            s.advance(f, dt)
+        for name in FIELDS:
+            a = o.field(name)
+            for s in sol:
+                assert F.same(a, s.field(name)), (f, name)
+    # switching a running solver from fused to separate launches re-establishes the scratch borders
+    sol[0].setOption(4, 0)
+    for f in range(7, 9):
+        o.advance(f, dt); sol[0].advance(f, dt); sol[1].advance(f, dt)
+    for name in FIELDS:
+        assert F.same(o.field(name), sol[0].field(name)) and F.same(o.field(name), sol[1].field(name)), name
+    for s in sol:
+        s.close()
+    o.close()
