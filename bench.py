@@ -104,10 +104,10 @@ def cpu_baseline(args):
                       + f"), OpenMP C oracle (-O2 -march=native), {el:.1f} s"}
 
 
-def pmc_traffic(n, sweeps_per_launch=1.0):
+def pmc_traffic(n, sweeps_per_launch=1.0, kernel=""):
     """HBM bytes per Jacobi launch from the committed rocprofv3 PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "jacobi_pmc_traffic.json")
-    key = str(n) if sweeps_per_launch < 1.5 else f"{n}_fused2"
+    key = str(n) if sweeps_per_launch < 1.5 else (f"{n}_fused2r" if kernel == "jacobi_march2r_kernel" else f"{n}_fused2")
     try:
         with open(path) as f:
             return json.load(f).get(key, {}).get("bytes_per_launch")
@@ -302,9 +302,10 @@ def main():
         cells = n ** 3 if world == 1 else n * n * (nz_global // world + 2 * args.ghost)
         alg = JACOBI_BYTES_PER_VOXEL * cells * spl
         achieved = alg / (us * 1e-6) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "jacobi_march2_kernel" if spl > 1.5 else "jacobi_march_kernel",
+        kname = (lib.fl_jacobi_kernel_name() or b"").decode() or "jacobi_march2_kernel"
+        line["roofline"] = {"bound": "hbm", "kernel": kname if spl > 1.5 else "jacobi_march_kernel",
                             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl) if world == 1 else None,
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl, kname) if world == 1 else None,
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
                             "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3),
                             "algorithmic_bytes_per_launch": int(alg)}

@@ -64,6 +64,7 @@ HIP_SIGS = {
     "fl_set_option": (None, [c_i, c_i]),
     "fl_get_option": (c_i, [c_i]),
     "fl_jacobi_profile": (None, [C.POINTER(c_d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "fl_jacobi_kernel_name": (C.c_char_p, []),
     # 3. additive
     "gpu_init_maps": (None, [VP, VP, VP] + _G),
     "gpu_max_abs3": (c_f, [VP, VP, VP, c_i, c_i, c_i]),

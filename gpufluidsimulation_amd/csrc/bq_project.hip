@@ -466,6 +466,113 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     }
 }
 
+// ---- the same fusion with TWO rows per thread ----------------------------------------------------
+// jacobi_march2_kernel evaluates L1 on three rows to produce L2 on one: the two outer rows are what the
+// neighbouring waves compute as their own centre.  Here a thread owns the float4 columns of rows j and j + 1: L0
+// of the rows j-1 .. j+2 on three planes in registers, L1 on those four rows, L2 on the two inner ones -- four L1
+// evaluations for two outputs instead of three for one, and 10 float4 loads (rows j-2 .. j+3 of p, j-1 .. j+2 of
+// div) for two outputs instead of 8 for one.  Same expression per value, so bit-identical to the other sweep
+// kernels.  One wave per row (nx <= 256).  Preconditions as for jacobi_march2_kernel.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                                    float *__restrict__ out, int nx, int ny, int nz,
+                                                                    int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
+{
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
+    const int by = b % nby, bz = b / nby;
+    const int rows = (WAVES * 64) / cw;
+    const int c = threadIdx.x % cw, r = threadIdx.x / cw;
+    const int xraw = 4 * c, j = 2 * (by * rows + r);
+    const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;
+    const bool xok = xraw < nx;
+    const bool active0 = xok && j >= 1 && j <= ny - 2, active1 = xok && j + 1 >= 1 && j + 1 <= ny - 2;
+    // out-of-range rows, planes and lanes are clamped into the array (see jacobi_march2_kernel)
+    const int x = xok ? xraw : nx - 4;
+    const size_t sj = nx, sk = (size_t)nx * ny;
+    const bool xlo = x == 0, xhi = x + 3 == nx - 1;
+    auto rowoff = [&](int row) -> size_t { return (size_t)x + sj * (size_t)min(max(row, 0), ny - 1); };
+    const size_t o_m2 = rowoff(j - 2), o_p3 = rowoff(j + 3);
+    size_t o[4];
+    bool rowb[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) { o[a] = rowoff(j - 1 + a); rowb[a] = j - 1 + a <= 0 || j - 1 + a >= ny - 1; }
+    auto plane = [&](int pl) -> size_t { return sk * (size_t)min(max(pl, 0), nz - 1); };
+    auto ld4 = [&](const float *ptr, size_t off) -> float4 { return *reinterpret_cast<const float4 *>(ptr + off); };
+    auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, bool boundary) -> float4 {
+        const float left = lane_up(ce.w), right = lane_down(ce.x);
+        float4 v;
+        v.x = (left + ce.y + fr.x + bk.x + dn.x + up.x + alpha * dv.x) * beta;
+        v.y = (ce.x + ce.z + fr.y + bk.y + dn.y + up.y + alpha * dv.y) * beta;
+        v.z = (ce.y + ce.w + fr.z + bk.z + dn.z + up.z + alpha * dv.z) * beta;
+        v.w = (ce.z + right + fr.w + bk.w + dn.w + up.w + alpha * dv.w) * beta;
+        if (boundary) return ce;
+        if (xlo) v.x = ce.x;
+        if (xhi) v.w = ce.w;
+        return v;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 A[4], B[4], C[4], Dv[4], Hf, Hb;
+    int q = kbeg - 1;
+    {
+        const size_t pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
+#pragma unroll
+        for (int a = 0; a < 4; a++) { A[a] = ld4(p, pm + o[a]); B[a] = ld4(p, pc + o[a]); C[a] = ld4(p, pn + o[a]); Dv[a] = ld4(div, pc + o[a]); }
+        Hf = ld4(p, pc + o_m2); Hb = ld4(p, pc + o_p3);
+    }
+    float4 Mc[4] = { zero4, zero4, zero4, zero4 };      // L1 on plane q-1, rows j-1 .. j+2
+    float4 Mm[2] = { zero4, zero4 };                    // L1 of rows j, j+1 on plane q-2
+    float4 Dprev[2] = { zero4, zero4 };                 // div of rows j, j+1 on plane q-1
+    auto phase = [&](float4 (&Lm)[4], float4 (&Lc)[4], float4 (&Ln)[4]) {
+        const size_t pa = plane(q + 2), pb = plane(q + 1);
+        float4 La[4], Da[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { La[a] = ld4(p, pa + o[a]); Da[a] = ld4(div, pb + o[a]); }
+        const float4 Hfa = ld4(p, pb + o_m2), Hba = ld4(p, pb + o_p3);
+        const bool qb = q < kA || q >= kB;
+        float4 M[4];
+        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], qb || rowb[0]);
+        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], qb || rowb[1]);
+        M[2] = jac(Lc[2], Lc[1], Lc[3], Lm[2], Ln[2], Dv[2], qb || rowb[2]);
+        M[3] = jac(Lc[3], Lc[2], Hb, Lm[3], Ln[3], Dv[3], qb || rowb[3]);
+        const int k = q - 1;
+        const float4 o0 = jac(Mc[1], Mc[0], Mc[2], Mm[0], M[1], Dprev[0], false);
+        const float4 o1 = jac(Mc[2], Mc[1], Mc[3], Mm[1], M[2], Dprev[1], false);
+        if (k >= kbeg && k < kend) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                if (!(rr ? active1 : active0)) continue;
+                const float4 v = rr ? o1 : o0;
+                float *dst = out + (size_t)x + sj * (j + rr) + sk * k;
+                if (x >= 4 && x + 4 < nx) {
+                    *reinterpret_cast<float4 *>(dst) = v;
+                } else {
+                    if (x >= 1) dst[0] = v.x;
+                    dst[1] = v.y;
+                    dst[2] = v.z;
+                    if (x + 3 < nx - 1) dst[3] = v.w;
+                }
+            }
+        }
+        Mm[0] = Mc[1]; Mm[1] = Mc[2];
+        Dprev[0] = Dv[1]; Dprev[1] = Dv[2];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { Mc[a] = M[a]; Lm[a] = La[a]; Dv[a] = Da[a]; }
+        Hf = Hfa; Hb = Hba;
+        q++;
+    };
+    while (q <= kend) {
+        phase(A, B, C);
+        if (q > kend) break;
+        phase(B, C, A);
+        if (q > kend) break;
+        phase(C, A, B);
+    }
+}
+
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
 // update_residual_kernel / calc_poisson_value arithmetic (GPU_kernel.cu:1048-1060,1239-1249);
 // the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
@@ -618,6 +725,8 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
     BQ_LAUNCH_CHECK("jacobi_tile_kernel");
 }
 
+static const char *g_last_pair_kernel = "";     // name of the fused sweep kernel launched last (fl_jacobi_kernel_name)
+
 // Two sweeps in one launch (in -> out holds iterate +2) when the fused kernel applies; returns false
 // (nothing launched) otherwise.  The caller guarantees that both buffers carry the same boundary layer.
 static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
@@ -636,6 +745,31 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     // (chunks of 32) run 19.1 us per sweep, 576 or 448 blocks (chunks of 28 or 40) 22.7; a z-slab rank with 272
     // planes runs 25.4 us with chunks of 32 (9 of them) and 20.0 with chunks of 34 (8).  So: the number of chunks is
     // the multiple of 512 / gcd(row blocks, 512) closest to planes / target.
+    // Two rows per thread (jacobi_march2r_kernel; rows of one wave only).  It has half as many row blocks, runs one
+    // 4-wave block per CU best, and like the one-row kernel only pays when the blocks fill the 256 CUs in whole
+    // rounds: 256^3 17.1 us per sweep with 8 chunks of 32 planes (256 blocks) against 19.0-19.7 for the one-row
+    // kernel, but 21-23 us with chunks of 24-28 and 28 us with chunks of 64; 272 planes 18.0 (8 chunks of 34) against
+    // 20.0; 128^3 is slower with it (5.5 vs 4.6: the chunks get too short).  FL_OPT_JACOBI_ROWS: 0 = this rule,
+    // 1 = one row, 2 = two rows whenever the kernel applies.
+    if (!wide && nj >= 4 && rt().opt_jacobi_rows != 1) {
+        const int nby2 = (nj + 2 * rows - 1) / (2 * rows);
+        int gcd = nby2, rem = 256;
+        while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+        const int quantum = 256 / gcd;                              // chunk counts that make nby2 * nbz a multiple of 256
+        int nchunks = ((2 * nk + 32) / 64 + quantum / 2) / quantum * quantum;   // ~32 planes per chunk
+        if (nchunks < quantum) nchunks = quantum;
+        int kc = (nk + nchunks - 1) / nchunks;
+        const bool pays = kc >= 16;
+        if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
+        if (kc < 4) kc = 4;
+        if (pays || rt().opt_jacobi_rows == 2) {
+            const int nbz2 = (nk + kc - 1) / kc;
+            jacobi_march2r_kernel<4><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk));
+            BQ_LAUNCH_CHECK("jacobi_march2r_kernel");
+            g_last_pair_kernel = "jacobi_march2r_kernel";
+            return true;
+        }
+    }
     int kchunk = rt().opt_jacobi_kchunk2;
     if (kchunk <= 0) {
         const int target = wide ? 64 : 32;
@@ -653,6 +787,7 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     if (wide) jacobi_march2_kernel<4, true><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
     else      jacobi_march2_kernel<4, false><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
+    g_last_pair_kernel = "jacobi_march2_kernel";
     return true;
 }
 
@@ -845,6 +980,8 @@ void fl_jacobi_profile(double *total_ms, long long *launches, long long *sweeps)
     if (launches) *launches = n;
     if (sweeps) *sweeps = sw;
 }
+
+const char *fl_jacobi_kernel_name(void) { return g_last_pair_kernel; }
 
 // GPU_kernel.cu:855-876
 void gpu_diffuse_field(float *field, float *fieldTemp0, float *filedTemp1, int ni, int nj, int nk, int iter, float coef)

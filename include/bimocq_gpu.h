@@ -247,7 +247,7 @@ enum {
     FL_OPT_JACOBI_VARIANT  = 3, /* 0 = auto, 1 = generic scalar kernel, 2 = LDS-tiled kernel      */
     FL_OPT_PROFILE_JACOBI  = 4, /* record a hipEvent pair around each projection's sweep loop      */
     FL_OPT_JACOBI_KCHUNK   = 5, /* planes marched per block in the tiled kernel (0 = auto)         */
-    FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread in the tiled kernel: 1, 2, 4 (0 = auto)  */
+    FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread: tiled kernel 1, 2, 4; fused kernel 1, 2 (0 = auto) */
     FL_OPT_STRUCTURED_MAPS = 7, /* 9-point kernels: compile-time taps when h is a power of two (1)  */
     FL_OPT_JACOBI_FUSE     = 8, /* two sweeps per launch: 0 never, 1 in gpu_projection_jacobi (default),
                                    2 also in gpu_jacobi_sweeps (caller vouches for equal boundary layers) */
@@ -273,6 +273,8 @@ int  fl_get_option(int option);
 /* FL_OPT_PROFILE_JACOBI: total milliseconds, sweep-kernel launches and Jacobi sweeps (a fused launch
  * performs two) of the sweep loops recorded since the previous call (blocking; resets the record) */
 void fl_jacobi_profile(double *total_ms, long long *launches, long long *sweeps);
+/* name of the two-sweep kernel the projection launched last ("" before the first; for reports) */
+const char *fl_jacobi_kernel_name(void);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Additive entry points (no reference counterpart)

@@ -157,9 +157,11 @@ def test_projection_quarter_strength(hip):
 @pytest.mark.parametrize("ni,nj,nk", [(32, 32, 32), (64, 48, 40), (128, 37, 19), (256, 32, 24), (200, 20, 12), (36, 5, 3),
                                       (512, 9, 7), (260, 20, 12), (516, 6, 5), (1024, 5, 4), (384, 10, 40)])   # rows of 2-4 waves
 @pytest.mark.parametrize("sweeps", [2, 3, 4, 9])
-def test_fused_two_sweep_kernel(hip, ni, nj, nk, sweeps):
-    """jacobi_march2_kernel (two sweeps per launch) against single oracle sweeps; both ping-pong buffers
-    carry the same boundary layer (the kernel's precondition), which is otherwise arbitrary."""
+@pytest.mark.parametrize("rows", [1, 2])
+def test_fused_two_sweep_kernel(hip, ni, nj, nk, sweeps, rows):
+    """jacobi_march2_kernel (two sweeps per launch; rows = 2: jacobi_march2r_kernel, two rows per thread, where a row
+    is one wave) against single oracle sweeps; both ping-pong buffers carry the same boundary layer (the kernel's
+    precondition), which is otherwise arbitrary."""
     import gpufluidsimulation_amd as bq
     p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
     a, b = p0.copy(), p0.copy()             # same boundary layer in both buffers
@@ -168,9 +170,11 @@ def test_fused_two_sweep_kernel(hip, ni, nj, nk, sweeps):
         a, b = b, a
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, rows)
     dp, dd, dt = dev(p0, div, p0)
     where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, sweeps, ALPHA, BETA)
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
     newest = dt if where else dp
     assert F.same(a, newest.numpy()), (ni, nj, nk, sweeps)
     bq.check()
