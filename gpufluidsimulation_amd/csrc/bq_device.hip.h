@@ -13,9 +13,10 @@
 // Two arithmetic variants of everything in this file exist side by side in the library (inline namespaces
 // bq::exact / bq::fast, selected per translation unit by BQ_FAST_LERP): `exact` is the contract above; `fast`
 // evaluates a lerp as ONE fp32 fma, fmaf(c, b - a, a), and changes nothing else (oracle: orc_set_fast_lerp).
-// The gather kernels are bound by the issue rate of the double-evaluated lerp (4 conversions and 2 fp64
-// operations each), so `fast` is the variant SURVEY 8(d) calls for next to the exact one; it stays 3 orders
-// of magnitude inside the 1e-5 RMS tolerance over 200 steps (tests/test_gpu_solver.py).
+// The single-field gather kernels are bound by VALU instruction issue (~3.8 cycles per wave64 instruction whatever its
+// type), so `fast` -- the variant SURVEY 8(d) calls for next to the exact one -- wins what its shorter lerps save in
+// instruction count (~10 % of such a kernel); it stays 3 orders of magnitude inside the 1e-5 RMS tolerance over
+// 200 steps (tests/test_gpu_solver.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
