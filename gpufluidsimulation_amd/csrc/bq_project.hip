@@ -8,6 +8,7 @@
 // Summation order is the reference's (GPU_kernel.cu:1834), so results are bit-identical.
 #include "bq_device.hip.h"
 #include "bq_host.h"
+#include <algorithm>
 #include <vector>
 
 namespace bq {
@@ -16,6 +17,10 @@ namespace bq {
 // [klo, khi): optional restriction of a stencil launch to a range of LOCAL planes (used to sweep the
 // slab interior while the ghost planes are still in flight).
 struct Slab { int koff, nkg, klo, khi; };
+// Output planes of a fused two-sweep launch: chunks bz < nchA march [k0a, k1a), the others [k0b, k1b) (used to
+// split a launch into the part that needs no ghost planes and the two parts next to them); L1 is evaluated
+// wherever those outputs need it.  Whole array: {0, nz, 0, 0, nbz}.
+struct PairRanges { int k0a, k1a, k0b, k1b, nchA; };
 
 // ---- divergence_kernel (GPU_kernel.cu:967-985) --------------------------------------------
 __global__ __launch_bounds__(256) void divergence_kernel(const float *__restrict__ u, const float *__restrict__ v,
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march_kernel(const float *_
 template <int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                    float *__restrict__ out, int nx, int ny, int nz,
-                                                                   int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
+                                                                   int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
     const int nblk = gridDim.x;
     int b = blockIdx.x;
@@ -338,7 +343,8 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
     // local planes a sweep may update: inside the array AND inside the global domain (z-slab ranks);
     // everything else counts as boundary and keeps its input value in L1
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
-    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    const int r0 = bz < rg.nchA ? rg.k0a + bz * kchunk : rg.k0b + (bz - rg.nchA) * kchunk, r1 = bz < rg.nchA ? rg.k1a : rg.k1b;
+    const int kbeg = max(kA, r0), kend = min(min(kB, r1), r0 + kchunk);
     if (kbeg >= kend) return;
     const bool xok = xraw < nx;
     const bool active = xok && j >= 1 && j <= ny - 2;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                     float *__restrict__ out, int nx, int ny, int nz,
-                                                                    int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
+                                                                    int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
     const int nblk = gridDim.x;
     int b = blockIdx.x;
@@ -486,7 +492,8 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
     const int xraw = 4 * c, j = 2 * (by * rows + r);
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
-    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    const int r0 = bz < rg.nchA ? rg.k0a + bz * kchunk : rg.k0b + (bz - rg.nchA) * kchunk, r1 = bz < rg.nchA ? rg.k1a : rg.k1b;
+    const int kbeg = max(kA, r0), kend = min(min(kB, r1), r0 + kchunk);
     if (kbeg >= kend) return;
     const bool xok = xraw < nx;
     const bool active0 = xok && j >= 1 && j <= ny - 2, active1 = xok && j + 1 >= 1 && j + 1 <= ny - 2;
@@ -729,63 +736,76 @@ static const char *g_last_pair_kernel = "";     // name of the fused sweep kerne
 
 // Two sweeps in one launch (in -> out holds iterate +2) when the fused kernel applies; returns false
 // (nothing launched) otherwise.  The caller guarantees that both buffers carry the same boundary layer.
-static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
+// k0a..k1b: output plane ranges (see PairRanges); the default is the whole array
+static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta,
+                              int k0a = 0, int k1a = 1 << 30, int k0b = 0, int k1b = 0)
 {
     if (ni < 3 || nj < 3 || nk < 3) return false;
     const int variant = rt().opt_jacobi_variant;
     if (variant != 0 && variant != 3) return false;
     if (!((ni % 4 == 0) && ni >= 32 && ni <= 1024 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
+    k0a = std::max(k0a, 0); k1a = std::min(k1a, nk); k0b = std::max(k0b, 0); k1b = std::min(k1b, nk);
+    const int lenA = std::max(k1a - k0a, 0), lenB = std::max(k1b - k0b, 0);
+    if (lenA + lenB == 0) return true;
+    const bool whole = lenB == 0 && lenA == nk;
+    const int nkr = lenA + lenB;                         // planes this launch produces
+    auto chunks_of = [](int len, int kc) { return len > 0 ? (len + kc - 1) / kc : 0; };
     int cw = 16;
     while (cw * 4 < ni) cw *= 2;                         // float4 lanes per row: <= 64 one wave, 128/256 = 2/4 waves
     const bool wide = cw > 64;
     const int rows = 256 / cw;
     const int nby = (nj + rows - 1) / rows;
-    // planes per block: ~32 measured best at 256^3 (one wave per row), ~64 at 512^3 (248 vs 254 us per sweep).  What
-    // matters more is that the blocks fill the 256 CUs in whole rounds of two blocks per CU: at 256^3, 512 blocks
-    // (chunks of 32) run 19.1 us per sweep, 576 or 448 blocks (chunks of 28 or 40) 22.7; a z-slab rank with 272
-    // planes runs 25.4 us with chunks of 32 (9 of them) and 20.0 with chunks of 34 (8).  So: the number of chunks is
-    // the multiple of 512 / gcd(row blocks, 512) closest to planes / target.
     // Two rows per thread (jacobi_march2r_kernel; rows of one wave only).  It has half as many row blocks, runs one
     // 4-wave block per CU best, and like the one-row kernel only pays when the blocks fill the 256 CUs in whole
     // rounds: 256^3 17.1 us per sweep with 8 chunks of 32 planes (256 blocks) against 19.0-19.7 for the one-row
     // kernel, but 21-23 us with chunks of 24-28 and 28 us with chunks of 64; 272 planes 18.0 (8 chunks of 34) against
     // 20.0; 128^3 is slower with it (5.5 vs 4.6: the chunks get too short).  FL_OPT_JACOBI_ROWS: 0 = this rule,
-    // 1 = one row, 2 = two rows whenever the kernel applies.
+    // 1 = one row, 2 = two rows whenever the kernel applies.  Short plane ranges (the parts of a split launch next to
+    // the ghost planes): one chunk per range.
     if (!wide && nj >= 4 && rt().opt_jacobi_rows != 1) {
         const int nby2 = (nj + 2 * rows - 1) / (2 * rows);
         int gcd = nby2, rem = 256;
         while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
         const int quantum = 256 / gcd;                              // chunk counts that make nby2 * nbz a multiple of 256
-        int nchunks = ((2 * nk + 32) / 64 + quantum / 2) / quantum * quantum;   // ~32 planes per chunk
+        int nchunks = ((2 * nkr + 32) / 64 + quantum / 2) / quantum * quantum;   // ~32 planes per chunk
         if (nchunks < quantum) nchunks = quantum;
-        int kc = (nk + nchunks - 1) / nchunks;
-        const bool pays = kc >= 16;
+        int kc = (nkr + nchunks - 1) / nchunks;
+        bool pays = kc >= 16;
+        if (!whole && std::max(lenA, lenB) <= 48) { kc = std::max(lenA, lenB); pays = true; }
         if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
         if (kc < 4) kc = 4;
         if (pays || rt().opt_jacobi_rows == 2) {
-            const int nbz2 = (nk + kc - 1) / kc;
-            jacobi_march2r_kernel<4><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk));
+            const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kc)};
+            const int nbz2 = rg.nchA + chunks_of(lenB, kc);
+            jacobi_march2r_kernel<4><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
             BQ_LAUNCH_CHECK("jacobi_march2r_kernel");
             g_last_pair_kernel = "jacobi_march2r_kernel";
             return true;
         }
     }
+    // planes per block: ~32 measured best at 256^3 (one wave per row), ~64 at 512^3 (248 vs 254 us per sweep).  What
+    // matters more is that the blocks fill the 256 CUs in whole rounds of two blocks per CU: at 256^3, 512 blocks
+    // (chunks of 32) run 19.1 us per sweep, 576 or 448 blocks (chunks of 28 or 40) 22.7; a z-slab rank with 272
+    // planes runs 25.4 us with chunks of 32 (9 of them) and 20.0 with chunks of 34 (8).  So: the number of chunks is
+    // the multiple of 512 / gcd(row blocks, 512) closest to planes / target.
     int kchunk = rt().opt_jacobi_kchunk2;
     if (kchunk <= 0) {
         const int target = wide ? 64 : 32;
         int gcd = nby, rem = 512;
         while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
         const int quantum = 512 / gcd;                          // chunk counts that make nby * nbz a multiple of 512
-        int nchunks = ((2 * nk + target) / (2 * target) + quantum / 2) / quantum * quantum;
+        int nchunks = ((2 * nkr + target) / (2 * target) + quantum / 2) / quantum * quantum;
         if (nchunks < quantum) nchunks = quantum;
-        kchunk = (nk + nchunks - 1) / nchunks;
+        kchunk = (nkr + nchunks - 1) / nchunks;
         if (kchunk < 16) kchunk = target;                       // small grids: no whole round to fill anyway
+        if (!whole && std::max(lenA, lenB) <= 48) kchunk = std::max(lenA, lenB);
     }
-    while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
-    const int nbz = (nk + kchunk - 1) / kchunk;
+    while (whole && kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 512) kchunk /= 2;
+    const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kchunk)};
+    const int nbz = rg.nchA + chunks_of(lenB, kchunk);
     // (loads two planes ahead instead of one measured no better at 256^3: 19.4 vs 19.1 us per sweep)
-    if (wide) jacobi_march2_kernel<4, true><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
-    else      jacobi_march2_kernel<4, false><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk));
+    if (wide) jacobi_march2_kernel<4, true><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk), rg);
+    else      jacobi_march2_kernel<4, false><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk), rg);
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
     g_last_pair_kernel = "jacobi_march2_kernel";
     return true;
@@ -891,6 +911,19 @@ void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int n
     g_klo = k_begin; g_khi = k_end;
     jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta);
     g_klo = 0; g_khi = 1 << 30;
+}
+
+// Two sweeps in one launch, `out` written on the planes [k0a, k1a) and [k0b, k1b) only (either may be empty): the
+// pieces of a chunk's first two sweeps on a z-slab rank -- planes whose two-sweep stencil stays inside the owned
+// planes while the ghost planes are in flight, then the rest.  Returns 1 when the fused kernel ran, 0 when it does
+// not apply to this grid (nothing launched: the caller sweeps plane ranges one sweep at a time instead).
+int gpu_jacobi_sweep_pair_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                                 int k0a, int k1a, int k0b, int k1b, float alpha, float beta)
+{
+    if (!ensure_ready("gpu_jacobi_sweep_pair_ranges") || !dims_ok(ni, nj, nk, "gpu_jacobi_sweep_pair_ranges")) return 0;
+    if (!in || !div || !out || in == out) { latch(FL_ERR_BAD_ARGUMENT, "gpu_jacobi_sweep_pair_ranges", "null or aliased buffers"); return 0; }
+    if (rt().opt_jacobi_fuse == 0) return 0;
+    return jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta, k0a, k1a, k0b, k1b) ? 1 : 0;
 }
 
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float halfrdx)

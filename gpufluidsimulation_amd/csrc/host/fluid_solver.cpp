@@ -364,26 +364,47 @@ bool BimocqGPUSolver::projection(bool with_delta)
     const int fuse_was = fl_get_option(FL_OPT_JACOBI_FUSE);
     if (fuse_was == 1) fl_set_option(FL_OPT_JACOBI_FUSE, 2);
     int left = jacobi_iters - 1;                                         // iterate iter-1 is applied
-    // an odd chunk = the overlapped first sweep + an even number of sweeps, which all run as fused pairs
-    const int chunk_max = (G % 2 == 0 && G > 1) ? G - 1 : G;
+    const int own0 = G, own1 = g.nk - G;                                 // local owned planes [own0, own1)
+    bool pair_split = G >= 2 && own1 - own0 >= 5;                        // until the operator library says it cannot
     while (left > 0) {
-        const int chunk = std::min(left, chunk_max);
         int where;
-        if (cur->valid < chunk) {
-            // exchange the ghost planes of `cur` on the halo stream and meanwhile sweep the planes whose
-            // stencil stays inside the owned planes; the rest of the first sweep follows the exchange
-            const int own0 = G, own1 = g.nk - G;                 // local owned planes [own0, own1)
+        int chunk;
+        if (cur->valid >= std::min(left, G)) {
+            chunk = std::min(left, G);
+            where = gpu_jacobi_sweeps(*cur, div, *oth, g.ni, g.nj, g.nk, chunk, alpha, beta);
+        } else {
+            // The ghost planes of `cur` travel on the halo stream while the compute stream sweeps what does not
+            // depend on them; the planes next to them follow the exchange.
             float *ptr = cur->get(); size_t pe = cur->plane; int ex = 0;
             fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0);
-            gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own0 + 1, own1 - 1, alpha, beta);
-            fl_halo_wait();
-            gs.produced(*cur, G);
-            gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, 0, own0 + 1, alpha, beta);
-            gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own1 - 1, g.nk, alpha, beta);
-            // remaining sweeps of the chunk start from `oth`
-            where = 1 - (chunk > 1 ? gpu_jacobi_sweeps(*oth, div, *cur, g.ni, g.nj, g.nk, chunk - 1, alpha, beta) : 0);
-        } else {
-            where = gpu_jacobi_sweeps(*cur, div, *oth, g.ni, g.nj, g.nk, chunk, alpha, beta);
+            int done = 0;
+            chunk = std::min(left, G);
+            if (pair_split && chunk >= 2) {
+                // first TWO sweeps of the chunk as one fused launch per piece: output planes whose two-sweep stencil
+                // stays inside the owned planes now, the two ends after the exchange (one launch for both)
+                if (gpu_jacobi_sweep_pair_ranges(*cur, div, *oth, g.ni, g.nj, g.nk, own0 + 2, own1 - 2, 0, 0, alpha, beta)) {
+                    fl_halo_wait();
+                    gs.produced(*cur, G);
+                    gpu_jacobi_sweep_pair_ranges(*cur, div, *oth, g.ni, g.nj, g.nk, 0, own0 + 2, own1 - 2, g.nk, alpha, beta);
+                    done = 2;
+                } else {
+                    pair_split = false;                                  // fused kernel does not apply to this grid
+                }
+            }
+            if (!done) {
+                // one sweep in three plane ranges; an odd chunk so that everything after it runs as fused pairs
+                chunk = std::min(left, (G % 2 == 0 && G > 1) ? G - 1 : G);
+                gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own0 + 1, own1 - 1, alpha, beta);
+                fl_halo_wait();
+                gs.produced(*cur, G);
+                gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, 0, own0 + 1, alpha, beta);
+                gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own1 - 1, g.nk, alpha, beta);
+                done = 1;
+            }
+            // the remaining sweeps of the chunk start from `oth`
+            const int rest = chunk - done;
+            const int w2 = rest > 0 ? gpu_jacobi_sweeps(*oth, div, *cur, g.ni, g.nj, g.nk, rest, alpha, beta) : 0;
+            where = w2 ? 0 : 1;                                          // w2 = 1: newest back in `cur`
         }
         int v = cur->valid;
         for (int s = 0; s < chunk; s++) v = std::min(v - 1, div.valid);     // each sweep reaches one plane

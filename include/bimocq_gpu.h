@@ -300,6 +300,13 @@ void gpu_gradient_delta(float *u, float *v, float *w, const float *p, float *du,
  * planes that do not depend on ghost planes while those are still being exchanged */
 void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,
                             int k_begin, int k_end, float alpha, float beta);
+/* TWO Jacobi sweeps in -> out in one launch, `out` written on the local planes [k0a, k1a) and [k0b, k1b) only (either
+ * range may be empty): a z-slab host issues the first two sweeps after an exchange as the planes whose two-sweep stencil
+ * stays inside the owned planes (while the ghost planes are in flight) and then the rest.  Both buffers must carry the
+ * same boundary layer (as for FL_OPT_JACOBI_FUSE = 2).  Returns 1 when the fused kernel ran, 0 when it does not apply
+ * to this grid -- nothing was launched and the caller falls back to gpu_jacobi_sweep_range. */
+int gpu_jacobi_sweep_pair_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                                 int k0a, int k1a, int k0b, int k1b, float alpha, float beta);
 /* exact sum r^2 (double) and max|r| of r = div - (sum6 p - 6p) over interior cells; blocking */
 void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk,
                         double *sum_sq, float *max_abs);

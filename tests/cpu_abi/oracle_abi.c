@@ -231,6 +231,29 @@ void gpu_gradient_delta(float *u, float *v, float *w, const float *p, float *du,
 void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int ni, int nj, int nk,
                             int k_begin, int k_end, float alpha, float beta)
 { orc_jacobi_sweep_range(in, div, out, ni, nj, nk, k_begin, k_end, alpha, beta); }
+/* two sweeps, output on two plane ranges: L1 on the planes those outputs read (into a scratch copy of `in`, which
+ * also gives it the same boundary layer), then L2 on the ranges themselves */
+int gpu_jacobi_sweep_pair_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                                 int k0a, int k1a, int k0b, int k1b, float alpha, float beta)
+{
+    size_t n = (size_t)ni * nj * nk;
+    float *l1 = (float *)malloc(n * sizeof(float));
+    if (!l1) return 0;
+    memcpy(l1, in, n * sizeof(float));
+    const int r[2][2] = { { k0a, k1a }, { k0b, k1b } };
+    for (int a = 0; a < 2; a++) {
+        int k0 = r[a][0] < 0 ? 0 : r[a][0], k1 = r[a][1] > nk ? nk : r[a][1];
+        if (k0 >= k1) continue;
+        orc_jacobi_sweep_range(in, div, l1, ni, nj, nk, k0 - 1 < 0 ? 0 : k0 - 1, k1 + 1 > nk ? nk : k1 + 1, alpha, beta);
+    }
+    for (int a = 0; a < 2; a++) {
+        int k0 = r[a][0] < 0 ? 0 : r[a][0], k1 = r[a][1] > nk ? nk : r[a][1];
+        if (k0 >= k1) continue;
+        orc_jacobi_sweep_range(l1, div, out, ni, nj, nk, k0, k1, alpha, beta);
+    }
+    free(l1);
+    return 1;
+}
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float hr)
 {
     orc_gradient(u, p, ni + 1, nj, nk, 1, 0, 0, hr);

@@ -202,3 +202,45 @@ def test_jacobi_sweep_range(hip, ni, nj, nk, variant):
     hip.gpu_jacobi_sweep_range(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 5, 5, ALPHA, BETA)      # empty range
     assert F.same(full, dt.numpy())
     bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk", [(64, 48, 40), (256, 32, 30), (128, 37, 19), (512, 9, 24), (32, 6, 12)])
+@pytest.mark.parametrize("rows", [0, 1, 2])
+def test_fused_pair_on_plane_ranges(hip, ni, nj, nk, rows):
+    """gpu_jacobi_sweep_pair_ranges: two sweeps in one launch, output restricted to two plane ranges.  The interior
+    piece leaves every other plane of `out` untouched; interior + the two ends together equal two oracle sweeps
+    (the split a z-slab rank uses around its ghost-plane exchange)."""
+    import gpufluidsimulation_amd as bq
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    a, b = p0.copy(), p0.copy()
+    for _ in range(2):
+        oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+        a, b = b, a
+    want = a                                             # after two sweeps the newest iterate is back in `a`
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, rows)
+    G = 4
+    lo, hi = G + 2, nk - G - 2
+    dp, dd = dev(p0, div)
+    (dout,) = dev(p0)                                    # same boundary layer; interior values are overwritten
+    assert hip.gpu_jacobi_sweep_pair_ranges(dp.ptr, dd.ptr, dout.ptr, ni, nj, nk, lo, hi, 0, 0, ALPHA, BETA) == 1
+    part = dout.numpy().reshape(nk, nj, ni)
+    w3, p3 = want.reshape(nk, nj, ni), p0.reshape(nk, nj, ni)
+    assert F.same(part[lo:hi], w3[lo:hi])
+    assert F.same(part[:lo], p3[:lo]) and F.same(part[hi:], p3[hi:])
+    assert hip.gpu_jacobi_sweep_pair_ranges(dp.ptr, dd.ptr, dout.ptr, ni, nj, nk, 0, lo, hi, nk, ALPHA, BETA) == 1
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
+    assert F.same(dout.numpy(), want)
+    assert F.same(dp.numpy(), p0)                        # the input is only read
+    bq.check()
+
+
+def test_fused_pair_ranges_reports_when_it_does_not_apply(hip):
+    """rows that are not a multiple of 4 floats cannot take the fused kernel: 0 is returned and nothing is written"""
+    import gpufluidsimulation_amd as bq
+    ni, nj, nk = 30, 9, 12
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    dp, dd, dout = dev(p0, div, p0)
+    assert hip.gpu_jacobi_sweep_pair_ranges(dp.ptr, dd.ptr, dout.ptr, ni, nj, nk, 3, 9, 0, 0, ALPHA, BETA) == 0
+    assert F.same(dout.numpy(), p0)
+    bq.check()
