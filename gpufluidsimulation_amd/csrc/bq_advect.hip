@@ -107,10 +107,12 @@ __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v
     const float h = sp.h;
     Vel3 vel{make_field(u, g.ni + 1, g.nj, g.nk, g.koff), make_field(v, g.ni, g.nj + 1, g.nk, g.koff), make_field(w, g.ni, g.nj, g.nk + 1, g.koff)};
     Map3 in{make_field(xi, g.ni, g.nj, g.nk, g.koff), make_field(yi, g.ni, g.nj, g.nk, g.koff), make_field(zi, g.ni, g.nj, g.nk, g.koff)};
+    // the node (indices >= 2 inside the window) and its upwind neighbour are at least h away from the origin on every
+    // axis: q >= 1 for both velocity look-ups (sample's GE1 form); the DMC departure point below is not bounded
     f3 pt = mk3(h * (float)i, h * (float)j, h * (float)kg);
-    f3 vl = get_velocity<P2>(vel, sp, pt);
+    f3 vl = get_velocity<P2, true>(vel, sp, pt);
     f3 tp = mk3((vl.x > 0) ? pt.x - h : pt.x + h, (vl.y > 0) ? pt.y - h : pt.y + h, (vl.z > 0) ? pt.z - h : pt.z + h);
-    f3 tv = get_velocity<P2>(vel, sp, tp);
+    f3 tv = get_velocity<P2, true>(vel, sp, tp);
     float ax = (vl.x - tv.x) / (pt.x - tp.x);
     float ay = (vl.y - tv.y) / (pt.y - tp.y);
     float az = (vl.z - tv.z) / (pt.z - tp.z);

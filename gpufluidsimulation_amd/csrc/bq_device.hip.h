@@ -251,10 +251,11 @@ __device__ __forceinline__ float gather(const Field &f, const Cell &c)
 }
 
 // GPU_kernel.cu:43-62 sample_buffer
-template <bool P2>
+// GE1: the caller vouches that pos - off >= h on every axis (q >= 1): locate's NONNEG form and the one-fma lerps apply
+template <bool P2, bool GE1 = false>
 __device__ __forceinline__ float sample(const Field &f, const Spacing &sp, f3 off, f3 pos)
 {
-    return gather(f, locate<P2>(f, sp, off, pos));
+    return gather<GE1>(f, locate<P2, GE1>(f, sp, off, pos));
 }
 
 // three co-located fields (the x/y/z maps share cell and weights: GPU_kernel.cu:350-352 etc.)
@@ -412,13 +413,13 @@ __device__ __forceinline__ void map9(const Map3 &m, int i, int j, int kl, f3 out
 // MAC velocity (GPU_kernel.cu:64-72)
 struct Vel3 { Field u, v, w; };
 
-template <bool P2>
+template <bool P2, bool GE1 = false>
 __device__ __forceinline__ f3 get_velocity(const Vel3 &vel, const Spacing &sp, f3 pos)
 {
     float mh = (float)(-0.5 * (double)sp.h);
-    return mk3(sample<P2>(vel.u, sp, mk3(mh, 0.f, 0.f), pos),
-               sample<P2>(vel.v, sp, mk3(0.f, mh, 0.f), pos),
-               sample<P2>(vel.w, sp, mk3(0.f, 0.f, mh), pos));
+    return mk3(sample<P2, GE1>(vel.u, sp, mk3(mh, 0.f, 0.f), pos),
+               sample<P2, GE1>(vel.v, sp, mk3(0.f, mh, 0.f), pos),
+               sample<P2, GE1>(vel.w, sp, mk3(0.f, 0.f, mh), pos));
 }
 
 // GPU_kernel.cu:74-90 traceRK3
