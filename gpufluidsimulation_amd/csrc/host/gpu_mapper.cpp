@@ -1,5 +1,6 @@
 // gpu_mapper.cpp -- see gpu_mapper.hpp.  Reference: src/bimocq3D/GPU_Advection.h:110-627.
 #include "gpu_mapper.hpp"
+#include <cstdio>
 
 #include <cstdlib>
 
@@ -44,6 +45,16 @@ void gpuMapper::require(std::initializer_list<DeviceField *> fields, int depth)
     for (DeviceField *f : fields)
         if ((always || f->valid < depth) && n < 16) { ptrs[n] = f->get(); planes[n] = f->plane; extras[n] = f->extra; n++; }
     if (!n) return;
+    // BQ_TRACE_REQUIRE=1 (debug): what triggered the exchange -- requested depth and the shallowest valid depth found
+    static const bool trace = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0;
+    if (trace && slab.rank == 0) {
+        int vmin = 1 << 20;
+        for (DeviceField *f : fields) if (f->valid < vmin) vmin = f->valid;
+        fprintf(stderr, "[require] %d of %d fields, depth %d requested, valid %d\n", n, (int)fields.size(), depth, vmin);
+    }
+    // All G planes move, whatever depth was asked for: moving only `depth` planes was measured on two ranks
+    // (tests/slab_worker.py, 32x32x64, G = 8): 26 % fewer planes outside the Jacobi loop but 4 more exchanges per step
+    // (the deeper validity is what spares later operators their own exchange) -- no gain.
     fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, slab.G, 1);
     for (DeviceField *f : fields)
         if (always || f->valid < depth) f->valid = slab.G;

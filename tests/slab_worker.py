@@ -116,7 +116,7 @@ def main():
                 print(f"[rank {rank}] step {f}: {name} differs, max|diff| {d.max():.3e} in global planes {planes[:12]}{'...' if len(planes) > 12 else ''}", flush=True)
                 bad += 1
     moved = np.abs(o.field("v")).max()
-    print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} "
+    print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} planes={tr.planes_moved} "
           f"max|v|={moved:.4f} mismatches={bad}", flush=True)
     if tr.trace is not None and rank == 0:
         print(f"[rank 0] exchange trace (fields, depth, bytes per neighbour): {[t for t in tr.trace if not (t[0] == 1 and t[1] == a.ghost)]}", flush=True)
