@@ -92,6 +92,7 @@ HIP_SIGS = {
     "fl_report_error": (None, [c_i, C.c_char_p]),
     # 4. multi-GPU
     "fl_set_slab": (None, [c_i, c_i, c_i, c_i, c_i]),
+    "fl_set_plane_window": (c_i, [c_i, c_i]),
     "fl_comm_unique_id": (c_i, [VP]),
     "fl_comm_init": (c_i, [VP, c_i, c_i]),
     "fl_comm_destroy": (None, []),

@@ -7,6 +7,7 @@
 #include "bq_device.hip.h"
 #include "bq_host.h"
 
+#include <algorithm>
 #include <cstdint>
 #include <type_traits>
 
@@ -16,7 +17,7 @@ inline namespace BQ_VARIANT {
 #define BQ_IJK(nbi, nbj, nbk)                                   \
     const int i = blockIdx.x * 64 + threadIdx.x;                \
     const int j = blockIdx.y * 4 + threadIdx.y;                 \
-    const int k = blockIdx.z;                                   \
+    const int k = blockIdx.z + g.kw0;                           \
     if (i >= (nbi) || j >= (nbj) || k >= (nbk)) return;         \
     const int kg = k + g.koff;                                  \
     (void)kg;
@@ -30,7 +31,7 @@ static const dim3 kBlock(64, 4, 1);
 // block_out: no thread of the block is inside the window (block-uniform, so leaving on it skips no barrier).
 #define BQ_IJK_WINDOW(ilo, ihi, jlo, jhi, klo, khi)                                           \
     const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 4;                                      \
-    const int i = i0 + threadIdx.x, j = j0 + threadIdx.y, k = blockIdx.z;                     \
+    const int i = i0 + threadIdx.x, j = j0 + threadIdx.y, k = blockIdx.z + g.kw0;             \
     const int kg = k + g.koff;                                                                \
     const bool block_out = !((klo) < kg && kg < (khi)) || i0 + 63 <= (ilo) || i0 >= (ihi) || j0 + 3 <= (jlo) || j0 >= (jhi); \
     const bool active = !block_out && (ilo) < i && i < (ihi) && (jlo) < j && j < (jhi);
@@ -39,7 +40,7 @@ template <bool P2, bool PT, int SD> constexpr bool kStaged = P2 && !PT && SD >= 
 // CELL dims of the LOCAL buffers plus the z-slab context: local plane k is global plane k + koff of a
 // grid with nkg cell planes (single GPU: koff = 0, nkg = nk).  Index windows, positions and clamps
 // are evaluated in GLOBAL coordinates so that a slab rank computes exactly what one GPU would.
-struct Grid { int ni, nj, nk, koff, nkg; };
+struct Grid { int ni, nj, nk, koff, nkg, kw0; };      // kw0: first local plane of this launch (plane window, else 0)
 
 // ---- 9-point stencil of sub-voxel sample positions (GPU_kernel.cu:317-348) ---------------
 struct Nine {
@@ -514,8 +515,23 @@ __global__ __launch_bounds__(256) void clamp_extrema_kernel(const float *field, 
 static inline Grid mk_grid(int ni, int nj, int nk)
 {
     const Runtime &r = rt();
-    if (r.slab_on) return Grid{ni, nj, nk, r.slab_koff, r.slab_nkg};
-    return Grid{ni, nj, nk, 0, nk};
+    if (r.slab_on) return Grid{ni, nj, nk, r.slab_koff, r.slab_nkg, 0};
+    return Grid{ni, nj, nk, 0, nk, 0};
+}
+// the same with the plane window (fl_set_plane_window) applied: g.kw0 = first plane, *planes = how many planes of a
+// buffer with nk + dz planes this launch covers (0: nothing to do)
+static inline Grid mk_grid_win(int ni, int nj, int nk, int dz, int *planes)
+{
+    Grid g = mk_grid(ni, nj, nk);
+    const Runtime &r = rt();
+    int k0 = 0, k1 = nk + dz;
+    if (r.win_on) {
+        k0 = std::min(r.win_k0, nk + dz);
+        k1 = r.win_k1 >= nk ? nk + dz : std::max(r.win_k1, k0);
+    }
+    g.kw0 = k0;
+    *planes = k1 - k0;
+    return g;
 }
 
 static bool dims_ok(int ni, int nj, int nk, const char *op)
@@ -582,7 +598,10 @@ template <int NF>
 static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, const float *bz,
                          Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
-    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
+    int planes;
+    g = mk_grid_win(g.ni, g.nj, g.nk, dz, &planes);      // plane window (fl_set_plane_window)
+    if (planes <= 0) return;
+    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         advect_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
@@ -595,7 +614,10 @@ template <int NF>
 static void cumulate_multi(CumulateArgs<NF> a, const float *mx, const float *my, const float *mz,
                            Spacing sp, Grid g, int dx, int dy, int dz, bool pt, bool identity)
 {
-    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
+    int planes;
+    g = mk_grid_win(g.ni, g.nj, g.nk, dz, &planes);
+    if (planes <= 0) return;
+    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
@@ -611,7 +633,10 @@ template <int NF>
 static void compensate_multi(CompensateArgs<NF> a, const float *mx, const float *my, const float *mz,
                              Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
 {
-    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, g.nk + dz);
+    int planes;
+    g = mk_grid_win(g.ni, g.nj, g.nk, dz, &planes);
+    if (planes <= 0) return;
+    const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         compensate_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
@@ -765,8 +790,10 @@ BQ_ENTRY(gpu_solve_forward, (float *u, float *v, float *w, float *x_fwd, float *
 {
     BQ_ENTER("gpu_solve_forward", u, v, w, x_fwd, y_fwd, z_fwd)
     BQ_REQUIRE(cfldt > 0.f || dt == 0.f, "gpu_solve_forward");     // cfldt <= 0 would never terminate
-    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
-    BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt);
+    int planes;
+    Spacing sp = make_spacing(h); Grid g = mk_grid_win(ni, nj, nk, 0, &planes);
+    if (planes <= 0) return;
+    BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, planes), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt);
 }
 
 BQ_ENTRY(gpu_solve_backwardDMC, (float *u, float *v, float *w, float *x_in, float *y_in, float *z_in,
@@ -775,9 +802,11 @@ BQ_ENTRY(gpu_solve_backwardDMC, (float *u, float *v, float *w, float *x_in, floa
 {
     BQ_ENTER("gpu_solve_backwardDMC", u, v, w, x_in, y_in, z_in, x_out, y_out, z_out)
     BQ_REQUIRE(x_in != x_out && y_in != y_out && z_in != z_out, "gpu_solve_backwardDMC");
-    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    int planes;
+    Spacing sp = make_spacing(h); Grid g = mk_grid_win(ni, nj, nk, 0, &planes);
+    if (planes <= 0) return;
     const int border = (rt().opt_fused_housekeeping & 8) ? 2 : (rt().opt_fused_housekeeping & 4) ? 1 : 0;
-    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, nk), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep, border);
+    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, planes), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep, border);
 }
 
 BQ_ENTRY(gpu_advect_velocity, (float *u, float *v, float *w, float *u_init, float *v_init, float *w_init,

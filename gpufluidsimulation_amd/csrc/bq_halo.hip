@@ -107,6 +107,19 @@ void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
     r.slab_koff = koff; r.slab_nkg = nk_global; r.slab_own0 = own0; r.slab_own1 = own1; r.slab_nkl = nk_local;
 }
 
+// Restrict the map operators (gpu_solve_forward/_backwardDMC, gpu_advect_*, gpu_compensate_error_*, gpu_accumulate_*) to
+// the local CELL planes [k0, k1): they produce exactly the nodes of those planes (a buffer with one plane more than
+// cells -- the w component -- gets its extra plane with the window that reaches the last cell plane).  k0 < 0: off.
+// Lets a z-slab host run an operator on the planes that need no ghost data while those are in flight.  Returns 1
+// (supported).
+int fl_set_plane_window(int k0, int k1)
+{
+    Runtime &r = rt();
+    if (k0 < 0) { r.win_on = false; return 1; }
+    r.win_on = true; r.win_k0 = k0; r.win_k1 = k1 < k0 ? k0 : k1;
+    return 1;
+}
+
 int fl_comm_rank(void) { return g_rank; }
 int fl_comm_size(void) { return g_nranks; }
 

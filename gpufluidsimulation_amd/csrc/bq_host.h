@@ -29,6 +29,9 @@ struct Runtime {
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;
     // this rank owns global planes [slab_own0, slab_own1) (reductions count only those)
+    // plane window (fl_set_plane_window): the map operators that honour it produce the local planes [win_k0, win_k1) only
+    bool        win_on = false;
+    int         win_k0 = 0, win_k1 = 0;
     bool        slab_on = false;
     int         slab_koff = 0, slab_nkg = 0, slab_own0 = 0, slab_own1 = 0, slab_nkl = 0;  // nkl: local cell planes
     // persistent workspace (replaces the cudaMalloc/cudaFree pair inside the reference's

@@ -8,6 +8,8 @@
 //   * buffers are released in the destructor (the reference never frees anything);
 //   * the DMC sub-step ping-pongs between buffers instead of copying out -> in three times.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <initializer_list>
 #include <vector>
@@ -149,6 +151,52 @@ public:
     // make sure the listed fields have at least `depth` valid ghost planes: those that do not are
     // refreshed from the z-neighbours (all G planes, one RCCL group).  No-op on a single GPU.
     void require(std::initializer_list<DeviceField *> fields, int depth);
+    // The same requirement for one or more (fields, depth) pairs followed by the operator `op` that consumes them, with
+    // the exchange OVERLAPPED: the ghost planes travel on the halo stream while `op` runs on the planes that cannot
+    // reach them (fl_set_plane_window: [G + reach, nk - G - reach)); after fl_halo_wait it runs on the two ends.
+    // `op` is called up to three times and must consist of window-honouring operator calls only (no clears, no
+    // copies: that is the case with the fused housekeeping) and must not write a field that is being exchanged.
+    // Falls back to require() + op() when the operator library has no plane windows (CPU stand-in), the housekeeping
+    // is not fused, or the slab is too thin.
+    struct GhostNeed { std::initializer_list<DeviceField *> fields; int depth; };
+    template <class Op>
+    void withGhosts(std::initializer_list<GhostNeed> needs, Op &&op)
+    {
+        if (!slab.on || slab.nranks <= 1) { op(); return; }
+        float *ptrs[16]; size_t planes[16]; int extras[16]; DeviceField *moved[16];
+        int n = 0, reach = 0;
+        for (const GhostNeed &nd : needs) {
+            if (nd.depth > slab.G) { require(nd.fields, nd.depth); return; }     // latches the "ghost zone too shallow" error
+            for (DeviceField *f : nd.fields) {
+                if (f->valid >= nd.depth) continue;
+                bool seen = false;
+                for (int a = 0; a < n; a++) seen = seen || moved[a] == f;
+                if (seen || n >= 16) continue;
+                moved[n] = f; ptrs[n] = f->get(); planes[n] = f->plane; extras[n] = f->extra; n++;
+                if (nd.depth > reach) reach = nd.depth;
+            }
+        }
+        if (!n) { op(); return; }
+        const int k0 = slab.G + reach, k1 = g.nk - slab.G - reach;
+        const bool split = overlap_exchanges && fuse_housekeeping && k1 - k0 >= 8 &&
+                           fl_get_option(FL_OPT_FUSED_HOUSEKEEPING) >= 0 && fl_set_plane_window(k0, k1) == 1;
+        if (!split) {
+            for (const GhostNeed &nd : needs) require(nd.fields, nd.depth);
+            op();
+            return;
+        }
+        if (trace_require() && slab.rank == 0)
+            fprintf(stderr, "[require] %d fields, reach %d: exchange overlapped with planes [%d, %d) of %d\n", n, reach, k0, k1, g.nk);
+        fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, slab.G, /*wait=*/0);
+        op();                                       // planes [k0, k1): no ghost plane within reach
+        fl_halo_wait();
+        for (int a = 0; a < n; a++) moved[a]->valid = slab.G;
+        fl_set_plane_window(0, k0); op();
+        fl_set_plane_window(k1, g.nk); op();
+        fl_set_plane_window(-1, -1);
+    }
+    bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
+    static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes
     void produced(DeviceField &f, int valid) const { if (slab.on) f.valid = valid < 0 ? 0 : valid; }
     void producedAll(std::initializer_list<DeviceField *> fields, int valid) const { for (DeviceField *f : fields) produced(*f, valid); }

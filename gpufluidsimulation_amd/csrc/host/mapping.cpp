@@ -71,8 +71,9 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
         FusedScope fused(gs.fuse_housekeeping, keepDmcBorder ? 8 : 4);
         swap_result = fused.on;
         if (keepDmcBorder && !fused.on) { out[0]->copy_from(*in[0]); out[1]->copy_from(*in[1]); out[2]->copy_from(*in[2]); }
-        gs.require({ &U, &V, &W, in[0], in[1], in[2] }, kReachDMC);
-        gs.solveBackwardDMC(U, V, W, *in[0], *in[1], *in[2], *out[0], *out[1], *out[2], substep);
+        gs.withGhosts({ { { &U, &V, &W, in[0], in[1], in[2] }, kReachDMC } }, [&] {
+            gs.solveBackwardDMC(U, V, W, *in[0], *in[1], *in[2], *out[0], *out[1], *out[2], substep);
+        });
         const int v = gpuMapper::minValid({ &U, &V, &W, in[0], in[1], in[2] }) - kReachDMC;
         gs.producedAll({ out[0], out[1], out[2] }, v);
         in[0] = out[0]; in[1] = out[1]; in[2] = out[2];
@@ -97,8 +98,9 @@ void MapperBaseGPU::updateForward(DeviceField &U, DeviceField &V, DeviceField &W
     MapSet &m = *maps;
     gpuMapper &gs = *gpuSolver;
     const int reach = reachField(m.Dfwd + dcells);
-    gs.require({ &U, &V, &W }, reach);
-    gs.solveForward(U, V, W, m.ForwardX, m.ForwardY, m.ForwardZ, cfldt, dt);
+    gs.withGhosts({ { { &U, &V, &W }, reach } }, [&] {
+        gs.solveForward(U, V, W, m.ForwardX, m.ForwardY, m.ForwardZ, cfldt, dt);
+    });
     const int v = std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }),
                            gpuMapper::minValid({ &U, &V, &W }) - reach);
     gs.producedAll({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, v);
@@ -118,24 +120,24 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     const int ni = g.ni, nj = g.nj, nk = g.nk;
 
     // advect: U(x) = blend9(Ui(psi_back(x)))
-    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
-    gs.require({ &Ui, &Vi, &Wi }, reachField(m.Dback));
-    gs.advectVelocity(U, V, W, Ui, Vi, Wi, m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    gs.withGhosts({ { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap }, { { &Ui, &Vi, &Wi }, reachField(m.Dback) } }, [&] {
+        gs.advectVelocity(U, V, W, Ui, Vi, Wi, m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    });
     gs.producedAll({ &U, &V, &W }, std::min(gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                             gpuMapper::minValid({ &Ui, &Vi, &Wi }) - reachField(m.Dback)));
 
     trace_point("v.advect");
     // stage 1: error at time 0, u_src = blend9(U(psi_fwd(x))) - Ui(x)      (GPU_Advection.h:499-501 zeroes u_src)
-    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
-    gs.require({ &U, &V, &W }, reachField(m.Dfwd));
     bool stage2_done;
     {
         // fused: the kernels zero the error outside their window and store U into Ui after reading it (stage 2)
         FusedScope fused(gs.fuse_housekeeping, 1 | 2);
         stage2_done = fused.on;
         if (!fused.on) { gs.u_src.zero(); gs.v_src.zero(); gs.w_src.zero(); }
-        gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
-                                      m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+        gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &U, &V, &W }, reachField(m.Dfwd) } }, [&] {
+            gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
+                                          m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+        });
     }
     gs.producedAll({ &gs.u_src, &gs.v_src, &gs.w_src },
                    std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
@@ -146,9 +148,9 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     if (stage2_done) { Ui.valid = U.valid; Vi.valid = V.valid; Wi.valid = W.valid; }
     else { Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W); }
     // stage 3: U += blend9(-0.5 * u_src(psi_back(x)))
-    gs.require({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback));
-    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
-    gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
+    gs.withGhosts({ { { &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
+        gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
+    });
     gs.producedAll({ &U, &V, &W }, std::min({ gpuMapper::minValid({ &U, &V, &W }),
                                               gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                               gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) }));
@@ -241,18 +243,16 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
     const auto back = [&] { return gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }); };
     const auto fwd = [&] { return gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }); };
 
-    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
-    gs.require({ &f1Init, &f2Init }, reachField(m.Dback));
     {
         FusedScope fused(gs.fuse_housekeeping, 1);
         if (!fused.on) { f1.zero(); f2.zero(); }                            // GPU_Advection.h:507
-        gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+        gs.withGhosts({ { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap }, { { &f1Init, &f2Init }, reachField(m.Dback) } }, [&] {
+            gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+        });
     }
     gs.produced(f1, std::min(back() - kReachMap, f1Init.valid - reachField(m.Dback)));
     gs.produced(f2, std::min(back() - kReachMap, f2Init.valid - reachField(m.Dback)));
 
-    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
-    gs.require({ &f1, &f2 }, reachField(m.Dfwd));
     DeviceField &e1 = gs.u_src, &e2 = gs.v_src;                             // scalar-sized use of the scratches
     const int f1Init_valid = f1Init.valid, f2Init_valid = f2Init.valid;
     bool stage2_done;
@@ -260,7 +260,9 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
         FusedScope fused(gs.fuse_housekeeping, 1 | 2);
         stage2_done = fused.on;
         if (!fused.on) { fl_memset(e1, 0, g.n() * sizeof(float)); fl_memset(e2, 0, g.n() * sizeof(float)); }
-        gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+        gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &f1, &f2 }, reachField(m.Dfwd) } }, [&] {
+            gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
+        });
     }
     const size_t plane1 = e1.plane, plane2 = e2.plane;
     e1.plane = e2.plane = (size_t)ni * nj;
@@ -268,9 +270,9 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
     gs.produced(e2, std::min({ fwd() - kReachMap, f2.valid - reachField(m.Dfwd), f2Init_valid }));
     if (stage2_done) { f1Init.valid = f1.valid; f2Init.valid = f2.valid; }
     else { f1Init.copy_from(f1); f2Init.copy_from(f2); }
-    gs.require({ &e1, &e2 }, reachField(m.Dback));
-    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
-    gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+    gs.withGhosts({ { { &e1, &e2 }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
+        gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
+    });
     gs.produced(f1, std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) }));
     gs.produced(f2, std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) }));
     e1.plane = plane1; e2.plane = plane2;
@@ -304,12 +306,12 @@ void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, Devic
 {
     MapSet &m = *maps;
     gpuMapper &gs = *gpuSolver;
-    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
-    gs.require({ &Uc, &Vc, &Wc }, reachField(m.Dfwd));
-    if (m.fwdIdentity)
-        gpu_accumulate_velocity_identity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false, coeff);
-    else
-        gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
+    gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Uc, &Vc, &Wc }, reachField(m.Dfwd) } }, [&] {
+        if (m.fwdIdentity)
+            gpu_accumulate_velocity_identity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false, coeff);
+        else
+            gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
+    });
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc, &Vc, &Wc }) - reachField(m.Dfwd) }));
@@ -321,20 +323,21 @@ void MapperBaseGPU::accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, Devi
 {
     MapSet &m = *maps;
     gpuMapper &gs = *gpuSolver;
-    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
     if (first_uw_zero) {
-        gs.require({ &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd));
-        gpu_accumulate_component(Uc2, coeff2, nullptr, 0.f, dUi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 0, false);
-        gpu_accumulate_component(Vc1, coeff1, Vc2, coeff2, dVi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 1, false);
-        gpu_accumulate_component(Wc2, coeff2, nullptr, 0.f, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 2, false);
+        gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd) } }, [&] {
+            gpu_accumulate_component(Uc2, coeff2, nullptr, 0.f, dUi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 0, false);
+            gpu_accumulate_component(Vc1, coeff1, Vc2, coeff2, dVi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 1, false);
+            gpu_accumulate_component(Wc2, coeff2, nullptr, 0.f, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 2, false);
+        });
         gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                         gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                         gpuMapper::minValid({ &Vc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
         return;
     }
-    gs.require({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd));
-    gpu_accumulate_velocity2(Uc1, Vc1, Wc1, coeff1, Uc2, Vc2, Wc2, coeff2, dUi, dVi, dWi,
-                             m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false);
+    gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd) } }, [&] {
+        gpu_accumulate_velocity2(Uc1, Vc1, Wc1, coeff1, Uc2, Vc2, Wc2, coeff2, dUi, dVi, dWi,
+                                 m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false);
+    });
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));

@@ -96,6 +96,8 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         if (!value) {   // the unfused DMC update relies on scratch sets whose border nodes are zero; swaps may have left map data there
             gm.x_out.zero(); gm.y_out.zero(); gm.z_out.zero(); gm.x_out2.zero(); gm.y_out2.zero(); gm.z_out2.zero();
         }
+    } else if (option == BQ_OPT_OVERLAP_EXCHANGES) {
+        s->solver->GpuSolver->overlap_exchanges = value != 0;
     } else if (option == BQ_OPT_REINIT_POLICY) {
         s->solver->setReinitPolicy(value);
         s->solver->ScalarAdvector.keepDmcBorder = s->solver->VelocityAdvector.keepDmcBorder;

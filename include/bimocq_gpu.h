@@ -383,6 +383,12 @@ void gpu_clamp_extrema_box(const float *before, float *after, int ni, int nj, in
  * Index windows, positions and clamps are then evaluated in global coordinates; reductions
  * (gpu_max_abs3, residual norms) count owned planes and are all-reduced.  nk_global <= 0 resets. */
 void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local);
+/* Restrict the map operators (gpu_solve_forward, gpu_solve_backwardDMC, gpu_advect_velocity/_field/_field2,
+ * gpu_compensate_error_*, gpu_accumulate_*) to the local cell planes [k0, k1): they produce exactly the nodes of those
+ * planes (the w component's extra plane belongs to the window that reaches the last cell plane).  k0 < 0 switches it
+ * off.  A z-slab host runs an operator on the planes that need no ghost data while the ghost planes are in flight
+ * (fl_halo_exchange with wait = 0), then on the rest after fl_halo_wait.  Returns 1 if supported, 0 if not. */
+int fl_set_plane_window(int k0, int k1);
 /* rank 0 obtains a 128-byte ncclUniqueId, the host program distributes it, every rank calls init */
 int  fl_comm_unique_id(void *id128);
 int  fl_comm_init(const void *id128, int rank, int nranks);

@@ -72,7 +72,11 @@ enum {
     /* 1 (default): the clears and copies the reference issues around the map operators (GPU_Advection.h:464-526,
      * GPU_kernel.cu:656-658) are done by the kernels themselves (FL_OPT_FUSED_HOUSEKEEPING of the operator ABI):
      * same values in every buffer, ~25 fewer memset/memcpy launches per step.  0: separate launches. */
-    BQ_OPT_FUSED_HOUSEKEEPING = 4
+    BQ_OPT_FUSED_HOUSEKEEPING = 4,
+    /* z-slab ranks, 1 (default): the ghost-plane exchange in front of a map operator runs on the halo stream while the
+     * operator works on the planes that cannot reach a ghost plane; the planes at both ends follow the exchange.
+     * 0: exchange, then the whole operator.  Same values either way. */
+    BQ_OPT_OVERLAP_EXCHANGES = 5
 };
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
  * last step measured (policy 1; 0 otherwise) */

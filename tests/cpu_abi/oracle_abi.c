@@ -119,6 +119,7 @@ static fl_exchange_cb c_exchange;
 static fl_allreduce_cb c_allreduce;
 
 void fl_report_error(int code, const char *text) { latch(code, text ? text : ""); }
+int fl_set_plane_window(int k0, int k1) { (void)k0; (void)k1; return 0; }   /* not implemented here: the host keeps the blocking exchange */
 void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
 {
     s_on = nk_global > 0; s_koff = koff; s_nkg = nk_global;

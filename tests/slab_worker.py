@@ -36,6 +36,7 @@ def main():
                     help="1: bit-exact mode (see csrc/host/mapping.hpp); 0: reference-faithful mode, compared by RMS")
     ap.add_argument("--rms-tol", type=float, default=1e-5)
     ap.add_argument("--viscosity", type=float, default=0.0)
+    ap.add_argument("--overlap", type=int, default=1, help="BQ_OPT_OVERLAP_EXCHANGES")
     a = ap.parse_args()
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -74,6 +75,7 @@ def main():
     s.setSmoke(0.05, 1.0, em)
     s.setProjection(a.iters, 0.5)
     s.setOption(1, a.keep_dmc_border)
+    s.setOption(5, a.overlap)
     if a.backend == "cpu":
         # the oracle library inside the CPU stand-in carries the slab context; the reference run below
         # uses the separately loaded liboracle.so, which stays single-domain

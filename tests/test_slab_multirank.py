@@ -93,6 +93,24 @@ def test_two_ranks_bit_exact_gpu():
 
 
 @pytest.mark.gpu
+def test_two_ranks_without_exchange_overlap_gpu():
+    """BQ_OPT_OVERLAP_EXCHANGES = 0: exchange first, then the whole operator (the default splits every map operator
+    that needs ghost planes into the part that cannot reach them, run during the exchange, and the two ends)"""
+    rc, out = launch(2, "--backend", "gpu", "--steps", 4, "--overlap", 0, threads=4)
+    assert rc == 0, out
+    assert "mismatches=0" in out
+
+
+@pytest.mark.gpu
+def test_three_ranks_gpu():
+    """a middle rank exchanges with two neighbours; 36 planes -> 12 owned each, 6 ghost planes: too thin for the
+    operator split at the larger reaches, so both forms occur in one run"""
+    rc, out = launch(3, "--backend", "gpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
+@pytest.mark.gpu
 def test_two_ranks_viscous_gpu():
     rc, out = launch(2, "--backend", "gpu", "--steps", 3, "--viscosity", 2e-3, threads=4)
     assert rc == 0, out
