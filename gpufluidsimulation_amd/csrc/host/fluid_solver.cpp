@@ -354,10 +354,15 @@ bool BimocqGPUSolver::projection(bool with_delta)
     // sweep shrinks the correct ghost depth by one plane (the ghost planes are swept redundantly,
     // which yields the very values the neighbour computes).
     const int G = gs.slab.G;
-    gs.require({ &VelocityU, &VelocityV, &VelocityW }, G);
+    // The redundant ghost sweeps need div on all G ghost planes.  Rather than refreshing three velocity components to
+    // depth G and evaluating div there, div is evaluated where the velocities are valid (the owned planes need one ghost
+    // plane of w) and its own ghost planes are fetched: one field instead of three, the same values (a neighbour's
+    // owned-plane divergence is the very expression this rank would evaluate).
+    gs.require({ &VelocityU, &VelocityV, &VelocityW }, 1);
     div.zero(); p.zero(); p_temp.zero();                                 // GPU_Advection.h:604-606
     gpu_divergence(VelocityU, VelocityV, VelocityW, div, g.ni, g.nj, g.nk, halfrdx);
     gs.produced(div, std::min({ VelocityU.valid, VelocityV.valid, VelocityW.valid - 1 }));
+    gs.require({ &div }, G);
     DeviceField *cur = &p, *oth = &p_temp;
     gs.produced(*cur, G);                                                // zeros everywhere
     // p and p_temp carry the same (zero) boundary layer: gpu_jacobi_sweeps may fuse sweeps pairwise
