@@ -422,6 +422,16 @@ __device__ __forceinline__ f3 get_velocity(const Vel3 &vel, const Spacing &sp, f
                sample<P2, GE1>(vel.w, sp, mk3(0.f, 0.f, mh), pos));
 }
 
+// The same look-up at a position that is not known to be inside the grid: one test per wave decides between the short
+// form (every lane at least h from the origin on every axis: q >= 1) and the general one.  A NaN fails the test.
+template <bool P2>
+__device__ __forceinline__ f3 get_velocity_auto(const Vel3 &vel, const Spacing &sp, f3 pos)
+{
+    if (__all(fminf(pos.x, fminf(pos.y, pos.z)) >= sp.h && pos.x == pos.x && pos.y == pos.y && pos.z == pos.z))
+        return get_velocity<P2, true>(vel, sp, pos);
+    return get_velocity<P2, false>(vel, sp, pos);
+}
+
 // GPU_kernel.cu:74-90 traceRK3
 template <bool P2>
 __device__ __forceinline__ f3 trace_rk3(const Vel3 &vel, const Spacing &sp, f3 hi, float dt, f3 pos)
@@ -429,17 +439,17 @@ __device__ __forceinline__ f3 trace_rk3(const Vel3 &vel, const Spacing &sp, f3 h
     float c1 = (float)(2.0 / 9.0 * (double)dt);
     float c2 = (float)(3.0 / 9.0 * (double)dt);
     float c3 = (float)(4.0 / 9.0 * (double)dt);
-    f3 v1 = get_velocity<P2>(vel, sp, pos);
+    f3 v1 = get_velocity_auto<P2>(vel, sp, pos);
     double hdt = 0.5 * (double)dt;
     f3 m1 = mk3((float)((double)pos.x + hdt * (double)v1.x),
                 (float)((double)pos.y + hdt * (double)v1.y),
                 (float)((double)pos.z + hdt * (double)v1.z));
-    f3 v2 = get_velocity<P2>(vel, sp, m1);
+    f3 v2 = get_velocity_auto<P2>(vel, sp, m1);
     double qdt = 0.75 * (double)dt;
     f3 m2 = mk3((float)((double)pos.x + qdt * (double)v2.x),
                 (float)((double)pos.y + qdt * (double)v2.y),
                 (float)((double)pos.z + qdt * (double)v2.z));
-    f3 v3 = get_velocity<P2>(vel, sp, m2);
+    f3 v3 = get_velocity_auto<P2>(vel, sp, m2);
     f3 out = mk3(pos.x + c1 * v1.x + c2 * v2.x + c3 * v3.x,
                  pos.y + c1 * v1.y + c2 * v2.y + c3 * v3.y,
                  pos.z + c1 * v1.z + c2 * v2.z + c3 * v3.z);
