@@ -35,8 +35,18 @@ void orc_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 /* local plane range [KLO, KHI) of a buffer with nkloc planes whose GLOBAL index lies in [glo, ghi) */
-#define KLO(glo) imax(0, (glo) - KOFF)
-#define KHI(ghi, nkloc) imin((nkloc), (ghi) - KOFF)
+/* plane window (orc_set_plane_window; mirrors fl_set_plane_window of the operator ABI): while it is set, the operators
+ * touch the local planes [W_k0, W_k1) only; a buffer with one plane more than cells gets its extra plane from the window
+ * that reaches the last cell plane.  W_cells: local cell planes (needed for that rule), given with the window. */
+static int W_on = 0, W_k0 = 0, W_k1 = 0, W_cells = 0;
+void orc_set_plane_window(int k0, int k1, int nk_cells)
+{
+    W_on = k0 >= 0; W_k0 = k0 < 0 ? 0 : k0; W_k1 = k1 < W_k0 ? W_k0 : k1; W_cells = nk_cells;
+}
+#define WLO (W_on ? W_k0 : 0)
+#define WHI(nkloc) (W_on ? (W_k1 >= W_cells ? (nkloc) : W_k1) : (nkloc))
+#define KLO(glo) imax(imax(0, (glo) - KOFF), WLO)
+#define KHI(ghi, nkloc) imin(imin((nkloc), (ghi) - KOFF), WHI(nkloc))
 
 /* GPU_kernel.cu:9-12 */
 static inline float clampf(float a, float lo, float hi) { return fminf(fmaxf(lo, a), hi); }

@@ -121,6 +121,8 @@ void orc_mad(float *out, const float *f1, const float *f2, float c1, float c2, i
 void orc_clamp_extrema_box(const float *before, float *after, int ni, int nj, int nk);
 void orc_divergence(const float *u, const float *v, const float *w, float *div,
                     int ni, int nj, int nk, float halfrdx);
+/* restrict every operator to the local planes [k0, k1) (k0 < 0: off); nk_cells = local cell planes */
+void orc_set_plane_window(int k0, int k1, int nk_cells);
 void orc_jacobi_sweep(const float *p, const float *div, float *out,
                       int ni, int nj, int nk, float alpha, float beta);
 /* ---- fp64 multigrid-CG projection (mgcg_oracle.c; GPU_kernel.cu:1420-1815) ---- */

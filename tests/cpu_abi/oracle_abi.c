@@ -48,8 +48,31 @@ int fl_last_error(void) { return g_err; }
 const char *fl_last_error_string(void) { return g_err == FL_OK ? "" : g_text; }
 void fl_clear_error(void) { g_err = FL_OK; g_text[0] = 0; }
 void *fl_compute_stream(void) { return NULL; }
-void fl_set_option(int option, int value) { if (option >= 0 && option < 8) g_opt[option] = value; }
-int fl_get_option(int option) { return (option >= 0 && option < 8) ? g_opt[option] : -1; }
+/* options 0..7 are stored; FL_OPT_FUSED_HOUSEKEEPING (12) is implemented below; everything else is unknown (-1) */
+static int g_fused = 0;
+static int g_nk_local = 0;          /* local cell planes, from fl_set_slab */
+void fl_set_option(int option, int value)
+{
+    if (option >= 0 && option < 8) g_opt[option] = value;
+    if (option == FL_OPT_FUSED_HOUSEKEEPING) g_fused = value & 15;
+}
+int fl_get_option(int option)
+{
+    if (option == FL_OPT_FUSED_HOUSEKEEPING) return g_fused;
+    return (option >= 0 && option < 8) ? g_opt[option] : -1;
+}
+/* plane window of the map operators (fl_set_plane_window): handed to the oracle's loops; the clears and copies of the
+ * fused housekeeping below are restricted to the same planes */
+static int g_win_on = 0, g_win_k0 = 0, g_win_k1 = 0, g_win_cells = 0;
+static void win_planes(int nk_cells, int nbk, int *p0, int *p1)
+{
+    *p0 = 0; *p1 = nbk;
+    if (g_win_on) { *p0 = g_win_k0 < nbk ? g_win_k0 : nbk; *p1 = g_win_k1 >= nk_cells ? nbk : (g_win_k1 < *p0 ? *p0 : g_win_k1); }
+}
+static void win_zero(float *f, size_t plane, int nk_cells, int nbk)
+{ int a, b; win_planes(nk_cells, nbk, &a, &b); if (b > a) memset(f + plane * (size_t)a, 0, plane * (size_t)(b - a) * sizeof(float)); }
+static void win_copy(float *dst, const float *src, size_t plane, int nk_cells, int nbk)
+{ int a, b; win_planes(nk_cells, nbk, &a, &b); if (b > a) memcpy(dst + plane * (size_t)a, src + plane * (size_t)a, plane * (size_t)(b - a) * sizeof(float)); }
 void fl_jacobi_profile(double *total_ms, long long *launches, long long *sweeps)
 { if (total_ms) *total_ms = 0; if (launches) *launches = 0; if (sweeps) *sweeps = 0; }
 
@@ -58,16 +81,27 @@ void gpu_solve_forward(float *u, float *v, float *w, float *x, float *y, float *
 { orc_solve_forward(u, v, w, x, y, z, h, ni, nj, nk, cfldt, dt); }
 void gpu_solve_backwardDMC(float *u, float *v, float *w, float *xi, float *yi, float *zi,
                            float *xo, float *yo, float *zo, float h, int ni, int nj, int nk, float substep)
-{ orc_solve_backwardDMC(u, v, w, xi, yi, zi, xo, yo, zo, h, ni, nj, nk, substep); }
+{
+    const size_t pl = (size_t)ni * nj;
+    if (g_fused & 8) { win_copy(xo, xi, pl, nk, nk); win_copy(yo, yi, pl, nk, nk); win_copy(zo, zi, pl, nk, nk); }
+    else if (g_fused & 4) { win_zero(xo, pl, nk, nk); win_zero(yo, pl, nk, nk); win_zero(zo, pl, nk, nk); }
+    orc_solve_backwardDMC(u, v, w, xi, yi, zi, xo, yo, zo, h, ni, nj, nk, substep);
+}
 void gpu_advect_velocity(float *u, float *v, float *w, float *ui, float *vi, float *wi,
                          float *bx, float *by, float *bz, float h, int ni, int nj, int nk, bool pt)
-{ orc_advect_velocity(u, v, w, ui, vi, wi, bx, by, bz, h, ni, nj, nk, pt); }
+{
+    if (g_fused & 1) { win_zero(u, (size_t)(ni + 1) * nj, nk, nk); win_zero(v, (size_t)ni * (nj + 1), nk, nk); win_zero(w, (size_t)ni * nj, nk, nk + 1); }
+    orc_advect_velocity(u, v, w, ui, vi, wi, bx, by, bz, h, ni, nj, nk, pt);
+}
 void gpu_advect_vel_double(float *u, float *v, float *w, float *ut, float *vt, float *wt,
                            float *bx, float *by, float *bz, float *px, float *py, float *pz,
                            float h, int ni, int nj, int nk, bool pt, float blend)
 { orc_advect_vel_double(u, v, w, ut, vt, wt, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
 void gpu_advect_field(float *f, float *fi, float *bx, float *by, float *bz, float h, int ni, int nj, int nk, bool pt)
-{ orc_advect_field(f, fi, bx, by, bz, h, ni, nj, nk, pt); }
+{
+    if (g_fused & 1) win_zero(f, (size_t)ni * nj, nk, nk);
+    orc_advect_field(f, fi, bx, by, bz, h, ni, nj, nk, pt);
+}
 void gpu_advect_field_double(float *f, float *fp, float *bx, float *by, float *bz, float *px, float *py, float *pz,
                              float h, int ni, int nj, int nk, bool pt, float blend)
 { orc_advect_field_double(f, fp, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
@@ -119,10 +153,17 @@ static fl_exchange_cb c_exchange;
 static fl_allreduce_cb c_allreduce;
 
 void fl_report_error(int code, const char *text) { latch(code, text ? text : ""); }
-int fl_set_plane_window(int k0, int k1) { (void)k0; (void)k1; return 0; }   /* not implemented here: the host keeps the blocking exchange */
+int fl_set_plane_window(int k0, int k1)
+{
+    if (g_nk_local <= 0) return 0;  /* only meaningful on a slab rank */
+    g_win_on = k0 >= 0; g_win_k0 = k0 < 0 ? 0 : k0; g_win_k1 = k1; g_win_cells = g_nk_local;
+    orc_set_plane_window(k0, k1, g_nk_local);
+    return 1;
+}
 void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
 {
     s_on = nk_global > 0; s_koff = koff; s_nkg = nk_global;
+    g_nk_local = nk_global > 0 ? nk_local : 0;
     orc_set_slab(koff, nk_global, own0, own1, nk_local);
 }
 int fl_comm_unique_id(void *id128) { memset(id128, 0, 128); return FL_OK; }
@@ -162,17 +203,26 @@ float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int n
 void gpu_compensate_error_velocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
                                    float *us, float *vs, float *ws, float *fx, float *fy, float *fz,
                                    float h, int ni, int nj, int nk, bool pt)
-{ orc_compensate_error_velocity(u, v, w, du, dv, dw, us, vs, ws, fx, fy, fz, h, ni, nj, nk, pt); }
+{
+    const size_t pu = (size_t)(ni + 1) * nj, pv = (size_t)ni * (nj + 1), pw = (size_t)ni * nj;
+    if (g_fused & 1) { win_zero(us, pu, nk, nk); win_zero(vs, pv, nk, nk); win_zero(ws, pw, nk, nk + 1); }
+    orc_compensate_error_velocity(u, v, w, du, dv, dw, us, vs, ws, fx, fy, fz, h, ni, nj, nk, pt);
+    if (g_fused & 2) { win_copy(du, u, pu, nk, nk); win_copy(dv, v, pv, nk, nk); win_copy(dw, w, pw, nk, nk + 1); }
+}
 void gpu_compensate_error_field(float *u, float *du, float *us, float *fx, float *fy, float *fz,
                                 float h, int ni, int nj, int nk, bool pt)
-{ orc_compensate_error_field(u, du, us, fx, fy, fz, h, ni, nj, nk, pt); }
+{
+    if (g_fused & 1) win_zero(us, (size_t)ni * nj, nk, nk);
+    orc_compensate_error_field(u, du, us, fx, fy, fz, h, ni, nj, nk, pt);
+    if (g_fused & 2) win_copy(du, u, (size_t)ni * nj, nk, nk);
+}
 /* batched / shortcut forms: by definition the single operators in order */
 void gpu_advect_field2(float *f1, float *f1i, float *f2, float *f2i, float *bx, float *by, float *bz,
                        float h, int ni, int nj, int nk, bool pt)
-{ orc_advect_field(f1, f1i, bx, by, bz, h, ni, nj, nk, pt); orc_advect_field(f2, f2i, bx, by, bz, h, ni, nj, nk, pt); }
+{ gpu_advect_field(f1, f1i, bx, by, bz, h, ni, nj, nk, pt); gpu_advect_field(f2, f2i, bx, by, bz, h, ni, nj, nk, pt); }
 void gpu_compensate_error_field2(float *u1, float *du1, float *us1, float *u2, float *du2, float *us2,
                                  float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt)
-{ orc_compensate_error_field(u1, du1, us1, fx, fy, fz, h, ni, nj, nk, pt); orc_compensate_error_field(u2, du2, us2, fx, fy, fz, h, ni, nj, nk, pt); }
+{ gpu_compensate_error_field(u1, du1, us1, fx, fy, fz, h, ni, nj, nk, pt); gpu_compensate_error_field(u2, du2, us2, fx, fy, fz, h, ni, nj, nk, pt); }
 void gpu_accumulate_field2(float *c1, float *d1, float k1, float *c2, float *d2, float k2,
                            float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt)
 { orc_accumulate_field(c1, d1, fx, fy, fz, h, ni, nj, nk, pt, k1); orc_accumulate_field(c2, d2, fx, fy, fz, h, ni, nj, nk, pt, k2); }

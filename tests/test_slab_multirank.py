@@ -52,6 +52,15 @@ def test_two_ranks_bit_exact_cpu():
     assert "mismatches=0" in out and "exchanges=" in out
 
 
+def test_two_ranks_without_exchange_overlap_cpu():
+    """BQ_OPT_OVERLAP_EXCHANGES = 0 (exchange, then the whole operator) against the default, in which the map operators
+    run on the planes out of reach of the ghost planes first and on the two ends after the exchange (the stand-in
+    implements fl_set_plane_window and the fused housekeeping like the HIP library)"""
+    rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--overlap", 0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+
+
 def test_three_ranks_middle_rank_cpu():
     """a middle rank has two neighbours; 36 planes -> 12 owned each, 6 ghost planes"""
     rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0)
