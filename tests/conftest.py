@@ -8,6 +8,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# before anything loads an OpenMP runtime (torch, the oracle): keep it within the job's CPU share
+from oracle_lib import limit_openmp_threads  # noqa: E402
+limit_openmp_threads()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 

@@ -15,6 +15,38 @@ FP = C.POINTER(C.c_float)
 c_f, c_i = C.c_float, C.c_int
 
 
+def usable_cores():
+    """CPU threads this job may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job 16 cores of a much bigger host)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read().split()[0])
+            if quota not in ("max", "-1"):
+                cores = min(cores, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, cores)
+
+
+def limit_openmp_threads():
+    """libgomp starts one thread per visible core; beyond the job's CPU share every barrier of the oracle's small
+    parallel loops crawls (measured on a GPU box: 35 s instead of 0.3 s per 32^3 step).  Must run before the first
+    OpenMP library is loaded; an explicit OMP_NUM_THREADS wins."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, usable_cores())))
+
+
 def build(march="x86-64", out="_build"):
     """(re)build liboracle.so with gcc; returns its path."""
     so = os.path.join(ORACLE_DIR, out, "liboracle.so")
@@ -118,6 +150,7 @@ _lib = None
 def lib(march="x86-64", out="_build"):
     global _lib
     if _lib is None:
+        limit_openmp_threads()
         _lib = C.CDLL(build(march, out))
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)

@@ -16,8 +16,8 @@ import numpy as np
 def main():
     # the OpenMP oracle must not start more threads than the job's CPU share (a GPU box hands out 16 cores of a big
     # host: the default of one thread per visible core makes every barrier crawl)
-    import bench
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, bench.usable_cores())))
+    import oracle_lib
+    oracle_lib.limit_openmp_threads()
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, nargs="+", default=[32, 48])
     ap.add_argument("--steps", type=int, default=200)
