@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void clamp_box_march_kernel(const float *__res
     const int kA = max(1, 1 - koff), kB = min(nk - 1, nkg - 1 - koff);          // local planes the limiter updates
     const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
     if (kbeg >= kend) return;
-    const bool xok = xraw < ni;
+    const bool xok = xraw + 4 <= ni;        // whole float4 inside the row (a row of 4m + 1 floats: its last column is the tail)
     const bool active = xok && j >= 1 && j <= nj - 2;
     const int x = xok ? xraw : ni - 4;
     const size_t sj = ni, sk = (size_t)ni * nj;
@@ -700,12 +700,18 @@ __global__ __launch_bounds__(256) void clamp_box_march_kernel(const float *__res
     auto mn3 = [](float a, float b, float c2) { return fminf(fminf(a, b), c2); };
     auto mx3 = [](float a, float b, float c2) { return fmaxf(fmaxf(a, b), c2); };
     // min/max over the 3x3 (x, y) neighbourhood of every cell of this float4 on plane pl
+    // rows of 4*cw + 1 floats (the u component: 257): the last lane of a row fetches the one extra column itself
+    const bool tail = ni % 4 == 1 && xraw + 4 == ni - 1;
     auto plane_box = [&](int pl) -> MinMax4 {
         const size_t p0 = sk * (size_t)min(max(pl, 0), nk - 1);
         const float4 a = ld4(p0 + o_m), b = ld4(p0 + o_0), d = ld4(p0 + o_p);
         float4 lo = make_float4(mn3(a.x, b.x, d.x), mn3(a.y, b.y, d.y), mn3(a.z, b.z, d.z), mn3(a.w, b.w, d.w));
         float4 hi = make_float4(mx3(a.x, b.x, d.x), mx3(a.y, b.y, d.y), mx3(a.z, b.z, d.z), mx3(a.w, b.w, d.w));
-        const float llo = lane_up(lo.w), rlo = lane_down(lo.x), lhi = lane_up(hi.w), rhi = lane_down(hi.x);
+        float llo = lane_up(lo.w), rlo = lane_down(lo.x), lhi = lane_up(hi.w), rhi = lane_down(hi.x);
+        if (tail) {
+            const float ta = before[p0 + o_m + 4], tb = before[p0 + o_0 + 4], td = before[p0 + o_p + 4];
+            rlo = mn3(ta, tb, td); rhi = mx3(ta, tb, td);
+        }
         MinMax4 m;
         m.lo = make_float4(mn3(llo, lo.x, lo.y), mn3(lo.x, lo.y, lo.z), mn3(lo.y, lo.z, lo.w), mn3(lo.z, lo.w, rlo));
         m.hi = make_float4(mx3(lhi, hi.x, hi.y), mx3(hi.x, hi.y, hi.z), mx3(hi.y, hi.z, hi.w), mx3(hi.z, hi.w, rhi));
@@ -739,11 +745,16 @@ __global__ __launch_bounds__(256) void clamp_box_march_kernel(const float *__res
 static void clamp_box(const float *before, float *after, int ni, int nj, int nk, int dz)
 {
     Grid g = mk_grid(1, 1, nk - dz);
-    const bool vec_ok = ni % 4 == 0 && ni >= 32 && ni <= 256 && nj >= 3 && nk >= 3 &&
-                        (((uintptr_t)before | (uintptr_t)after) & 15u) == 0 && rt().opt_jacobi_variant != 1;
+    // float4 columns; rows of 4m + 1 floats (u: 257) go through the same kernel with unaligned 16-byte accesses and one
+    // extra column fetched by the last lane (102 -> 48 us at 257 x 256 x 256)
+    const int nv = ni % 4 == 1 ? ni - 1 : ni;            // floats per row handled as float4
+    const bool pow2row = nv >= 32 && nv <= 256 && (nv & (nv - 1)) == 0;
+    const bool vec_ok = nj >= 3 && nk >= 3 && rt().opt_jacobi_variant != 1 &&
+                        ((ni % 4 == 0 && ni >= 32 && ni <= 256 && (((uintptr_t)before | (uintptr_t)after) & 15u) == 0) ||
+                         (ni % 4 == 1 && pow2row && (((uintptr_t)before | (uintptr_t)after) & 3u) == 0));
     if (vec_ok) {
         int cw = 16;
-        while (cw * 4 < ni) cw *= 2;
+        while (cw * 4 < nv) cw *= 2;
         const int rows = 256 / cw, nby = (nj + rows - 1) / rows;
         int kchunk = 32;
         while (kchunk > 8 && (long)nby * ((nk + kchunk - 1) / kchunk) < 1024) kchunk /= 2;

@@ -570,3 +570,19 @@ def test_fused_housekeeping_bits(gm, ni, nj, nk, h):
             assert F.same(want, out[c].numpy()), (bits, c)
     assert hip.fl_get_option(OPT) == 0
     bq.check()
+
+
+@pytest.mark.parametrize("nx", [32, 33, 64, 65, 129, 256, 257, 36, 37])
+def test_clamp_extrema_box_row_widths(nx):
+    """the limiter's marching kernel on rows of 4m floats and of 4m + 1 floats (the u component: unaligned float4
+    accesses, the last column fetched by the row's last lane), and the plain kernel on everything else"""
+    import gpufluidsimulation_amd as bq
+    ny, nz = 11, 9
+    before, after = F.scalar(nx, ny, nz, 0.2), F.scalar(nx, ny, nz, 0.45, amp=1.4)
+    ref = after.copy()
+    oracle().orc_clamp_extrema_box(fp(before), fp(ref), nx, ny, nz)
+    db, da = dev(before, after)
+    bq.hip_lib().gpu_clamp_extrema_box(db.ptr, da.ptr, nx, ny, nz)
+    assert F.same(ref, da.numpy())
+    assert not F.same(ref, after)
+    bq.check()
