@@ -586,3 +586,64 @@ def test_clamp_extrema_box_row_widths(nx):
     assert F.same(ref, da.numpy())
     assert not F.same(ref, after)
     bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
+def test_plane_windows_partition_the_operators(gm, ni, nj, nk, h):
+    """fl_set_plane_window: a map operator run on three plane windows that partition the grid (with the fused
+    housekeeping, so that it is nothing but window-honouring launches) produces what one unrestricted call does --
+    the split a z-slab host uses to overlap its ghost-plane exchange with the operator's interior planes."""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    OPT = bq._lib.FL_OPT_FUSED_HOUSEKEEPING
+    h, vel, fwd, back, _ = setup(ni, nj, nk, h)
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    gm(ni, nj, nk, h)
+    dvel, dfwd, dback = dev(*vel), dev(*fwd), dev(*back)
+    cur = [F.scalar(ni + 1, nj, nk, 0.1), F.scalar(ni, nj + 1, nk, 0.2), F.scalar(ni, nj, nk + 1, 0.3)]
+    windows = [(5, nk - 4), (0, 5), (nk - 4, nk)]            # interior first, then the two ends
+
+    def both(run, make_outputs):
+        """run(outputs) once unrestricted and once per window; returns the two sets of output arrays"""
+        full = make_outputs(); run(full)
+        split = make_outputs()
+        for k0, k1 in windows:
+            assert hip.fl_set_plane_window(k0, k1) == 1
+            run(split)
+        hip.fl_set_plane_window(-1, -1)
+        return [x.numpy() for x in full], [x.numpy() for x in split]
+
+    junk = lambda c: np.full(c, 3.25, np.float32)
+    hip.fl_set_option(OPT, 1 | 2 | 4)
+    try:
+        # advect (outputs start as junk: the kernels write the zero border themselves)
+        a, b = both(lambda o: hip.gpu_advect_velocity(*[x.ptr for x in o], *[x.ptr for x in dvel], *[x.ptr for x in dback], h, ni, nj, nk, False),
+                    lambda: dev(junk(nu), junk(nv), junk(nw)))
+        assert all(F.same(x, y) for x, y in zip(a, b))
+        # compensate-error: error outputs and the init <- field store
+        dcur = dev(*cur)
+        a, b = both(lambda o: hip.gpu_compensate_error_velocity(*[x.ptr for x in dcur], *[x.ptr for x in o[:3]], *[x.ptr for x in o[3:]],
+                                                                *[x.ptr for x in dfwd], h, ni, nj, nk, False),
+                    lambda: dev(*vel) + dev(junk(nu), junk(nv), junk(nw)))
+        assert all(F.same(x, y) for x, y in zip(a, b))
+        # accumulate (dst += ...): every node exactly once
+        a, b = both(lambda o: hip.gpu_accumulate_velocity(*[x.ptr for x in dvel], *[x.ptr for x in o], *[x.ptr for x in dfwd], h, ni, nj, nk, False, -0.5),
+                    lambda: dev(*cur))
+        assert all(F.same(x, y) for x, y in zip(a, b))
+        # DMC sub-step with its border nodes, forward map update in place
+        a, b = both(lambda o: hip.gpu_solve_backwardDMC(*[x.ptr for x in dvel], *[x.ptr for x in dback], *[x.ptr for x in o], h, ni, nj, nk, 0.4 * h),
+                    lambda: dev(junk(n), junk(n), junk(n)))
+        assert all(F.same(x, y) for x, y in zip(a, b))
+        a, b = both(lambda o: hip.gpu_solve_forward(*[x.ptr for x in dvel], *[x.ptr for x in o], h, ni, nj, nk, 0.3 * h, 0.9 * h),
+                    lambda: dev(*fwd))
+        assert all(F.same(x, y) for x, y in zip(a, b))
+        # two scalar fields at once
+        fa, fb = F.scalar(ni, nj, nk, 0.4), F.scalar(ni, nj, nk, 1.9, amp=2.0)
+        dfa, dfb = dev(fa, fb)
+        a, b = both(lambda o: hip.gpu_advect_field2(o[0].ptr, dfa.ptr, o[1].ptr, dfb.ptr, *[x.ptr for x in dback], h, ni, nj, nk, False),
+                    lambda: dev(junk(n), junk(n)))
+        assert all(F.same(x, y) for x, y in zip(a, b))
+    finally:
+        hip.fl_set_option(OPT, 0)
+        hip.fl_set_plane_window(-1, -1)
+    bq.check()
