@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 // ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
 // ID: the map is the identity map of gpu_init_maps (mx/my/mz are not read).
 template <bool P2, bool PT, int SD, int NF, bool ID>
-__global__ __launch_bounds__(256, 6) void cumulate_kernel(CumulateArgs<NF> a,
+__global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void cumulate_kernel(CumulateArgs<NF> a,
                                                        const float *mx, const float *my, const float *mz,
                                                        Spacing sp, Grid g, int dx, int dy, int dz)
 {
