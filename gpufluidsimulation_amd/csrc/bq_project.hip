@@ -479,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2_kernel(const float *
 // evaluations for two outputs instead of three for one, and 10 float4 loads (rows j-2 .. j+3 of p, j-1 .. j+2 of
 // div) for two outputs instead of 8 for one.  Same expression per value, so bit-identical to the other sweep
 // kernels.  One wave per row (nx <= 256).  Preconditions as for jacobi_march2_kernel.
-template <int WAVES>
+template <int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                     float *__restrict__ out, int nx, int ny, int nz,
                                                                     int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
@@ -501,16 +501,31 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
     const int x = xok ? xraw : nx - 4;
     const size_t sj = nx, sk = (size_t)nx * ny;
     const bool xlo = x == 0, xhi = x + 3 == nx - 1;
-    auto rowoff = [&](int row) -> size_t { return (size_t)x + sj * (size_t)min(max(row, 0), ny - 1); };
-    const size_t o_m2 = rowoff(j - 2), o_p3 = rowoff(j + 3);
+    auto rowat = [&](int col, int row) -> size_t { return (size_t)min(max(col, 0), nx - 1) + sj * (size_t)min(max(row, 0), ny - 1); };
+    const size_t o_m2 = rowat(x, j - 2), o_p3 = rowat(x, j + 3);
     size_t o[4];
     bool rowb[4];
 #pragma unroll
-    for (int a = 0; a < 4; a++) { o[a] = rowoff(j - 1 + a); rowb[a] = j - 1 + a <= 0 || j - 1 + a >= ny - 1; }
+    for (int a = 0; a < 4; a++) { o[a] = rowat(x, j - 1 + a); rowb[a] = j - 1 + a <= 0 || j - 1 + a >= ny - 1; }
+    // WIDE (a row spans several waves): the edge lanes look after the cell just outside their wave, on both rows --
+    // the scheme of jacobi_march2_kernel, twice
+    const int lane = threadIdx.x & 63;
+    const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 4 < nx;
+    const bool edge = edgeL || edgeR;
+    const int xe = edgeL ? xraw - 1 : xraw + 4, xo = edgeL ? xe - 1 : xe + 1;
+    size_t e[4], eo[2];
+#pragma unroll
+    for (int a = 0; a < 4; a++) e[a] = rowat(xe, j - 1 + a);
+    eo[0] = rowat(xo, j); eo[1] = rowat(xo, j + 1);
+    const bool xe_boundary = xe <= 0 || xe >= nx - 1;
     auto plane = [&](int pl) -> size_t { return sk * (size_t)min(max(pl, 0), nz - 1); };
     auto ld4 = [&](const float *ptr, size_t off) -> float4 { return *reinterpret_cast<const float4 *>(ptr + off); };
-    auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, bool boundary) -> float4 {
-        const float left = lane_up(ce.w), right = lane_down(ce.x);
+    auto jac = [&](float4 ce, float4 fr, float4 bk, float4 dn, float4 up, float4 dv, float outside, bool boundary) -> float4 {
+        float left = lane_up(ce.w), right = lane_down(ce.x);
+        if (WIDE) {
+            if (lane == 0) left = outside;
+            if (lane == 63) right = outside;
+        }
         float4 v;
         v.x = (left + ce.y + fr.x + bk.x + dn.x + up.x + alpha * dv.x) * beta;
         v.y = (ce.x + ce.z + fr.y + bk.y + dn.y + up.y + alpha * dv.y) * beta;
@@ -524,11 +539,20 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 A[4], B[4], C[4], Dv[4], Hf, Hb;
     int q = kbeg - 1;
+    // the outside cell: L0 on rows j-1 .. j+2 at plane q (Ec), on rows j, j+1 at planes q-1 / q+1 (Em / En), its outer
+    // x-neighbour (Eo) and its div (Eb) on rows j, j+1 at plane q; Xp: its L1 on rows j, j+1 at plane q-1
+    float Ec[4] = { 0.f, 0.f, 0.f, 0.f }, Em[2] = { 0.f, 0.f }, En[2] = { 0.f, 0.f }, Eo[2] = { 0.f, 0.f }, Eb[2] = { 0.f, 0.f }, Xp[2] = { 0.f, 0.f };
     {
         const size_t pm = plane(q - 1), pc = plane(q), pn = plane(q + 1);
 #pragma unroll
         for (int a = 0; a < 4; a++) { A[a] = ld4(p, pm + o[a]); B[a] = ld4(p, pc + o[a]); C[a] = ld4(p, pn + o[a]); Dv[a] = ld4(div, pc + o[a]); }
         Hf = ld4(p, pc + o_m2); Hb = ld4(p, pc + o_p3);
+        if (edge) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) Ec[a] = p[pc + e[a]];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) { Em[rr] = p[pm + e[rr + 1]]; En[rr] = p[pn + e[rr + 1]]; Eo[rr] = p[pc + eo[rr]]; Eb[rr] = div[pc + e[rr + 1]]; }
+        }
     }
     float4 Mc[4] = { zero4, zero4, zero4, zero4 };      // L1 on plane q-1, rows j-1 .. j+2
     float4 Mm[2] = { zero4, zero4 };                    // L1 of rows j, j+1 on plane q-2
@@ -539,15 +563,31 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
 #pragma unroll
         for (int a = 0; a < 4; a++) { La[a] = ld4(p, pa + o[a]); Da[a] = ld4(div, pb + o[a]); }
         const float4 Hfa = ld4(p, pb + o_m2), Hba = ld4(p, pb + o_p3);
+        float E2[4] = { 0.f, En[0], En[1], 0.f }, En2[2] = { 0.f, 0.f }, Eo2[2] = { 0.f, 0.f }, Eb2[2] = { 0.f, 0.f };
+        if (edge) {
+            E2[0] = p[pb + e[0]]; E2[3] = p[pb + e[3]];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) { En2[rr] = p[pa + e[rr + 1]]; Eo2[rr] = p[pb + eo[rr]]; Eb2[rr] = div[pb + e[rr + 1]]; }
+        }
         const bool qb = q < kA || q >= kB;
         float4 M[4];
-        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], qb || rowb[0]);
-        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], qb || rowb[1]);
-        M[2] = jac(Lc[2], Lc[1], Lc[3], Lm[2], Ln[2], Dv[2], qb || rowb[2]);
-        M[3] = jac(Lc[3], Lc[2], Hb, Lm[3], Ln[3], Dv[3], qb || rowb[3]);
+        M[0] = jac(Lc[0], Hf, Lc[1], Lm[0], Ln[0], Dv[0], Ec[0], qb || rowb[0]);
+        M[1] = jac(Lc[1], Lc[0], Lc[2], Lm[1], Ln[1], Dv[1], Ec[1], qb || rowb[1]);
+        M[2] = jac(Lc[2], Lc[1], Lc[3], Lm[2], Ln[2], Dv[2], Ec[2], qb || rowb[2]);
+        M[3] = jac(Lc[3], Lc[2], Hb, Lm[3], Ln[3], Dv[3], Ec[3], qb || rowb[3]);
+        // L1 of the outside cell on rows j, j+1 at plane q (edge lanes; a boundary cell keeps L0)
+        float X[2] = { Ec[1], Ec[2] };
+        if (edge) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                if (qb || rowb[rr + 1] || xe_boundary) continue;
+                const float l = edgeL ? Eo[rr] : Lc[rr + 1].w, rg2 = edgeL ? Lc[rr + 1].x : Eo[rr];
+                X[rr] = (l + rg2 + Ec[rr] + Ec[rr + 2] + Em[rr] + En[rr] + alpha * Eb[rr]) * beta;
+            }
+        }
         const int k = q - 1;
-        const float4 o0 = jac(Mc[1], Mc[0], Mc[2], Mm[0], M[1], Dprev[0], false);
-        const float4 o1 = jac(Mc[2], Mc[1], Mc[3], Mm[1], M[2], Dprev[1], false);
+        const float4 o0 = jac(Mc[1], Mc[0], Mc[2], Mm[0], M[1], Dprev[0], Xp[0], false);
+        const float4 o1 = jac(Mc[2], Mc[1], Mc[3], Mm[1], M[2], Dprev[1], Xp[1], false);
         if (k >= kbeg && k < kend) {
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
@@ -567,7 +607,9 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
         Mm[0] = Mc[1]; Mm[1] = Mc[2];
         Dprev[0] = Dv[1]; Dprev[1] = Dv[2];
 #pragma unroll
-        for (int a = 0; a < 4; a++) { Mc[a] = M[a]; Lm[a] = La[a]; Dv[a] = Da[a]; }
+        for (int rr = 0; rr < 2; rr++) { Xp[rr] = X[rr]; Em[rr] = Ec[rr + 1]; En[rr] = En2[rr]; Eo[rr] = Eo2[rr]; Eb[rr] = Eb2[rr]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++) { Mc[a] = M[a]; Lm[a] = La[a]; Dv[a] = Da[a]; Ec[a] = E2[a]; }
         Hf = Hfa; Hb = Hba;
         q++;
     };
@@ -762,12 +804,15 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     // 20.0; 128^3 is slower with it (5.5 vs 4.6: the chunks get too short).  FL_OPT_JACOBI_ROWS: 0 = this rule,
     // 1 = one row, 2 = two rows whenever the kernel applies.  Short plane ranges (the parts of a split launch next to
     // the ghost planes): one chunk per range.
-    if (!wide && nj >= 4 && rt().opt_jacobi_rows != 1) {
+    if (nj >= 4 && rt().opt_jacobi_rows != 1) {
         const int nby2 = (nj + 2 * rows - 1) / (2 * rows);
         int gcd = nby2, rem = 256;
         while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
         const int quantum = 256 / gcd;                              // chunk counts that make nby2 * nbz a multiple of 256
-        int nchunks = ((2 * nkr + 32) / 64 + quantum / 2) / quantum * quantum;   // ~32 planes per chunk
+        // ~32 planes per chunk for rows of one wave; rows of 2-4 waves (WIDE) like longer marches: 512^3 runs 201 us per
+        // sweep with 6 chunks of 86 planes, 203-214 with 8 of 64, 226 with 48, 211 with 128 (one-row kernel: 228-238)
+        const int target2 = wide ? 80 : 32;
+        int nchunks = ((2 * nkr + target2) / (2 * target2) + quantum / 2) / quantum * quantum;
         if (nchunks < quantum) nchunks = quantum;
         int kc = (nkr + nchunks - 1) / nchunks;
         bool pays = kc >= 16;
@@ -777,7 +822,8 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
         if (pays || rt().opt_jacobi_rows == 2) {
             const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kc)};
             const int nbz2 = rg.nchA + chunks_of(lenB, kc);
-            jacobi_march2r_kernel<4><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+            if (wide) jacobi_march2r_kernel<4, true><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+            else      jacobi_march2r_kernel<4, false><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
             BQ_LAUNCH_CHECK("jacobi_march2r_kernel");
             g_last_pair_kernel = "jacobi_march2r_kernel";
             return true;
