@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
+    ap.add_argument("--emulate-slab", action="store_true",
+                    help="debug, one GPU: run the z-slab code path of rank 0 of 2 (size^3 owned planes + ghost planes, chunked "
+                         "Jacobi, split operators) with exchanges that move nothing -- the compute-side cost of the slab path; "
+                         "the line is labelled and is not a benchmark result")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="N > 1: ghost planes over RCCL/xGMI (default) or staged through the host over gloo (debug)")
     return ap.parse_args()
@@ -186,6 +190,10 @@ def main():
             sys.exit("--strong needs size divisible by the number of ranks")
         nz_global = n if args.strong else n * world
         s = BimocqGPUSolver(n, n, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
+    elif args.emulate_slab:
+        keep = transport.NullTransport(lib, 0, 2)
+        nz_global = n
+        s = BimocqGPUSolver(n, n, 2 * n, 1.0, 0.0, 1.0, device=local_rank, rank=0, nranks=2, ghost=args.ghost)
     else:
         nz_global = n
         s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
@@ -270,6 +278,9 @@ def main():
                    f"{world} z-slabs of {nz_global // world} planes, {args.ghost} ghost planes, neighbour exchange over "
                    + getattr(args, "transport_note", args.transport)},
     }
+    if args.emulate_slab:
+        line["metric"] += " [EMULATED z-slab rank 0 of 2 on one GPU, exchanges move nothing: compute-side cost only]"
+        line["config"]["parallelism"] = f"emulated slab: {n} owned + 2 x {args.ghost} ghost planes, no data exchanged"
     line["extra"] = {"dead_state_elision": {"value": round(voxels * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
                                             "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
                                             "note": "library default: with blend == 1 and a re-initialisation every frame the "
@@ -299,13 +310,13 @@ def main():
         spl = sweeps.value / launches.value
         # a z-slab rank sweeps its ghost planes too (communication-avoiding chunks): n x n x (n + 2G) cells per sweep;
         # the overlapped first sweep of a chunk (three range launches) is not inside the timed spans
-        cells = n ** 3 if world == 1 else n * n * (nz_global // world + 2 * args.ghost)
+        cells = n ** 3 if (world == 1 and not args.emulate_slab) else n * n * (nz_global // world + 2 * args.ghost)
         alg = JACOBI_BYTES_PER_VOXEL * cells * spl
         achieved = alg / (us * 1e-6) / 1e9
         kname = (lib.fl_jacobi_kernel_name() or b"").decode() or "jacobi_march2_kernel"
         line["roofline"] = {"bound": "hbm", "kernel": kname if spl > 1.5 else "jacobi_march_kernel",
                             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl, kname) if world == 1 else None,
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl, kname) if (world == 1 and not args.emulate_slab) else None,
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
                             "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3),
                             "algorithmic_bytes_per_launch": int(alg)}

@@ -98,3 +98,15 @@ class HostStagedTransport:
         t = torch.from_numpy(view.copy())
         dist.all_reduce(t, op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM, group=self.group)
         view[:] = t.numpy()
+
+
+class NullTransport:
+    """Timing aid, not a transport: registers callbacks that move nothing, so that ONE process can run the z-slab code
+    path of rank `rank` of `nranks` (ghost planes, chunked Jacobi, split operators) and its compute-side cost can be
+    measured on a single GPU.  The fields it produces are meaningless near the slab boundary."""
+
+    def __init__(self, lib, rank=0, nranks=2):
+        self._ex = EXCHANGE_CB(lambda *a: None)
+        self._ar = ALLREDUCE_CB(lambda *a: None)
+        lib.fl_comm_set_custom.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.fl_comm_set_custom(rank, nranks, C.cast(self._ex, C.c_void_p), C.cast(self._ar, C.c_void_p))
