@@ -93,6 +93,7 @@ HIP_SIGS = {
     # 4. multi-GPU
     "fl_set_slab": (None, [c_i, c_i, c_i, c_i, c_i]),
     "fl_set_plane_window": (c_i, [c_i, c_i]),
+    "fl_comm_set_null": (None, [c_i, c_i]),
     "fl_comm_unique_id": (c_i, [VP]),
     "fl_comm_init": (c_i, [VP, c_i, c_i]),
     "fl_comm_destroy": (None, []),

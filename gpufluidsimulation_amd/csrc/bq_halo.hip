@@ -44,6 +44,7 @@ static int g_rank = 0, g_nranks = 1;
 static fl_exchange_cb g_custom_exchange = nullptr;
 static fl_allreduce_cb g_custom_allreduce = nullptr;
 static hipEvent_t g_ev_ready = nullptr, g_ev_done = nullptr;
+static bool g_null_transport = false;       // fl_comm_set_null: exchanges and all-reduces are skipped (timing aid)
 
 static bool load_rccl()
 {
@@ -79,7 +80,7 @@ static bool nccl_ok(int rc, const char *what)
 // residual norms when a communicator exists).  No-op on a single rank.
 bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStream_t st)
 {
-    if (g_nranks <= 1) return true;
+    if (g_nranks <= 1 || g_null_transport) return true;
     if (g_custom_allreduce) {
         const size_t bytes = count * (is_double ? 8 : 4);
         void *host = pinned(bytes < 64 ? 64 : bytes);
@@ -151,7 +152,18 @@ void fl_comm_destroy(void)
 {
     if (g_comm) { fl_sync(); g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
     g_custom_exchange = nullptr; g_custom_allreduce = nullptr;
+    g_null_transport = false;
     g_rank = 0; g_nranks = 1;
+}
+
+// Timing aid: this process plays rank `rank` of `nranks` with a transport that moves nothing and never waits, so
+// that the compute-side cost of the z-slab path can be measured on one GPU (bench.py --emulate-slab).  The ghost
+// planes keep whatever they held: results near the slab boundary are meaningless.
+void fl_comm_set_null(int rank, int nranks)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) { latch(FL_ERR_BAD_ARGUMENT, "fl_comm_set_null", "bad rank/size"); return; }
+    g_rank = rank; g_nranks = nranks; g_null_transport = nranks > 1;
+    g_custom_exchange = nullptr; g_custom_allreduce = nullptr;
 }
 
 void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb exchange, fl_allreduce_cb allreduce)
@@ -179,6 +191,7 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
     if (n <= 0 || !fields || !plane_elems || !extra || depth < 1 || depth > G || own < depth + 1) {
         latch(FL_ERR_BAD_ARGUMENT, "fl_halo_exchange", "bad depth/ghost/owned plane counts"); return;
     }
+    if (g_null_transport) return;               // timing aid: nothing moves, nothing waits
     if (g_custom_exchange) {                    // host-side transport: everything queued so far must be done
         BQ_HIP(hipStreamSynchronize(r.compute));
         g_custom_exchange(n, fields, plane_elems, extra, nk_local, G, depth);

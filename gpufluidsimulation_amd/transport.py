@@ -101,12 +101,9 @@ class HostStagedTransport:
 
 
 class NullTransport:
-    """Timing aid, not a transport: registers callbacks that move nothing, so that ONE process can run the z-slab code
-    path of rank `rank` of `nranks` (ghost planes, chunked Jacobi, split operators) and its compute-side cost can be
-    measured on a single GPU.  The fields it produces are meaningless near the slab boundary."""
+    """Timing aid, not a transport (fl_comm_set_null): ONE process runs the z-slab code path of rank `rank` of `nranks`
+    (ghost planes, chunked Jacobi, split operators) with exchanges that move nothing and never wait, so that its
+    compute-side cost can be measured on a single GPU.  The fields it produces are meaningless near the slab boundary."""
 
     def __init__(self, lib, rank=0, nranks=2):
-        self._ex = EXCHANGE_CB(lambda *a: None)
-        self._ar = ALLREDUCE_CB(lambda *a: None)
-        lib.fl_comm_set_custom.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        lib.fl_comm_set_custom(rank, nranks, C.cast(self._ex, C.c_void_p), C.cast(self._ar, C.c_void_p))
+        lib.fl_comm_set_null(rank, nranks)

@@ -413,6 +413,9 @@ typedef void (*fl_exchange_cb)(int n, float *const *fields, const size_t *plane_
                                int nk_local, int G, int depth);
 typedef void (*fl_allreduce_cb)(void *host_values, int count, int is_double, int is_max);
 void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb exchange, fl_allreduce_cb allreduce);
+/* timing aid: play rank `rank` of `nranks` with a transport that moves nothing and never waits (the compute-side cost
+ * of the z-slab path on one GPU; results near the slab boundary are meaningless) */
+void fl_comm_set_null(int rank, int nranks);
 
 #ifdef __cplusplus
 }
