@@ -816,7 +816,14 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
         if (nchunks < quantum) nchunks = quantum;
         int kc = (nkr + nchunks - 1) / nchunks;
         bool pays = kc >= 16;
-        if (!whole && std::max(lenA, lenB) <= 48) { kc = std::max(lenA, lenB); pays = true; }
+        if (!whole && std::max(lenA, lenB) <= 48) {
+            // short ranges (the ends of a split launch): as many chunks as fill the 256 CUs once -- a block marches its
+            // chunk plus two warm-up planes, so 2 ranges x 32 row blocks x 4 chunks of 3 planes beat 2 x 32 x 1 of 10
+            const int nranges = (lenA > 0) + (lenB > 0);
+            const int per_range = std::max(1, 256 / std::max(1, nby2 * nranges));
+            kc = std::max(2, (std::max(lenA, lenB) + per_range - 1) / per_range);
+            pays = true;
+        }
         if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
         if (kc < 4) kc = 4;
         if (pays || rt().opt_jacobi_rows == 2) {
