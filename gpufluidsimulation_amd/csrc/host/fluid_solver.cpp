@@ -406,10 +406,19 @@ bool BimocqGPUSolver::projection(bool with_delta)
                 gpu_jacobi_sweep_range(*cur, div, *oth, g.ni, g.nj, g.nk, own1 - 1, g.nk, alpha, beta);
                 done = 1;
             }
-            // the remaining sweeps of the chunk start from `oth`
-            const int rest = chunk - done;
-            const int w2 = rest > 0 ? gpu_jacobi_sweeps(*oth, div, *cur, g.ni, g.nj, g.nk, rest, alpha, beta) : 0;
-            where = w2 ? 0 : 1;                                          // w2 = 1: newest back in `cur`
+            // The remaining sweeps of the chunk start from `oth`.  A sweep leaves one ghost plane less correct on each
+            // side, and nothing reads the planes beyond: every further fused pair is restricted to the planes that will
+            // still be correct after it (done = 2 of G = 8: 264, 260, 256 of 272 planes).
+            int rest = chunk - done;
+            DeviceField *in = oth, *out = cur;
+            int depth = G - done;                                        // correct ghost planes of `in`
+            while (pair_split && rest >= 2 &&
+                   gpu_jacobi_sweep_pair_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - (depth - 2), own1 + (depth - 2), 0, 0, alpha, beta)) {
+                std::swap(in, out); rest -= 2; depth -= 2;
+            }
+            const int w2 = rest > 0 ? gpu_jacobi_sweeps(*in, div, *out, g.ni, g.nj, g.nk, rest, alpha, beta) : 0;
+            DeviceField *newest = w2 ? out : in;
+            where = newest == cur ? 0 : 1;
         }
         int v = cur->valid;
         for (int s = 0; s < chunk; s++) v = std::min(v - 1, div.valid);     // each sweep reaches one plane
