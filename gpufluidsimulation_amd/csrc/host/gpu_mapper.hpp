@@ -158,11 +158,19 @@ public:
     // copies: that is the case with the fused housekeeping) and must not write a field that is being exchanged.
     // Falls back to require() + op() when the operator library has no plane windows (CPU stand-in), the housekeeping
     // is not fused, or the slab is too thin.
+    // out_valid (optional): how many ghost planes of the operator's outputs will be correct afterwards (what the caller
+    // passes to produced()).  Nothing may read an output beyond that, so the operator is not run there at all: with
+    // G = 8 and a typical out_valid of 4 it covers 264 instead of 272 planes.
     struct GhostNeed { std::initializer_list<DeviceField *> fields; int depth; };
     template <class Op>
-    void withGhosts(std::initializer_list<GhostNeed> needs, Op &&op)
+    void withGhosts(std::initializer_list<GhostNeed> needs, Op &&op, int out_valid = DeviceField::kAlwaysValid)
     {
         if (!slab.on || slab.nranks <= 1) { op(); return; }
+        // planes worth computing: the owned ones and out_valid ghost planes per side
+        const bool can_window = overlap_exchanges && fuse_housekeeping && fl_get_option(FL_OPT_FUSED_HOUSEKEEPING) >= 0;
+        const int ov = out_valid < 0 ? 0 : (out_valid > slab.G ? slab.G : out_valid);
+        // (at least one plane on the high side: the last rank owns the w face on top of its last cell plane)
+        const int w0 = can_window ? slab.G - ov : 0, w1 = can_window ? g.nk - slab.G + (ov > 1 ? ov : 1) : g.nk;
         float *ptrs[16]; size_t planes[16]; int extras[16]; DeviceField *moved[16];
         int n = 0, reach = 0;
         for (const GhostNeed &nd : needs) {
@@ -176,13 +184,18 @@ public:
                 if (nd.depth > reach) reach = nd.depth;
             }
         }
-        if (!n) { op(); return; }
+        const bool trimmed = can_window && (w0 > 0 || w1 < g.nk);
+        if (!n) {
+            if (trimmed && fl_set_plane_window(w0, w1) == 1) { op(); fl_set_plane_window(-1, -1); }
+            else op();
+            return;
+        }
         const int k0 = slab.G + reach, k1 = g.nk - slab.G - reach;
-        const bool split = overlap_exchanges && fuse_housekeeping && k1 - k0 >= 8 &&
-                           fl_get_option(FL_OPT_FUSED_HOUSEKEEPING) >= 0 && fl_set_plane_window(k0, k1) == 1;
+        const bool split = can_window && k1 - k0 >= 8 && fl_set_plane_window(k0, k1) == 1;
         if (!split) {
             for (const GhostNeed &nd : needs) require(nd.fields, nd.depth);
-            op();
+            if (trimmed && fl_set_plane_window(w0, w1) == 1) { op(); fl_set_plane_window(-1, -1); }
+            else op();
             return;
         }
         if (trace_require() && slab.rank == 0)
@@ -191,8 +204,8 @@ public:
         op();                                       // planes [k0, k1): no ghost plane within reach
         fl_halo_wait();
         for (int a = 0; a < n; a++) moved[a]->valid = slab.G;
-        fl_set_plane_window(0, k0); op();
-        fl_set_plane_window(k1, g.nk); op();
+        fl_set_plane_window(w0, k0); op();
+        fl_set_plane_window(k1, w1); op();
         fl_set_plane_window(-1, -1);
     }
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
@@ -200,6 +213,14 @@ public:
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes
     void produced(DeviceField &f, int valid) const { if (slab.on) f.valid = valid < 0 ? 0 : valid; }
     void producedAll(std::initializer_list<DeviceField *> fields, int valid) const { for (DeviceField *f : fields) produced(*f, valid); }
+    // the smallest ghost validity among `fields` once require(fields, depth) has been met (what an exchange refreshes
+    // comes back with all G planes)
+    int validAfter(std::initializer_list<const DeviceField *> fields, int depth) const
+    {
+        int v = DeviceField::kAlwaysValid;
+        for (const DeviceField *f : fields) { const int a = (slab.on && slab.nranks > 1 && f->valid < depth) ? slab.G : f->valid; if (a < v) v = a; }
+        return v;
+    }
     static int minValid(std::initializer_list<const DeviceField *> fields)
     {
         int v = DeviceField::kAlwaysValid;

@@ -73,7 +73,7 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
         if (keepDmcBorder && !fused.on) { out[0]->copy_from(*in[0]); out[1]->copy_from(*in[1]); out[2]->copy_from(*in[2]); }
         gs.withGhosts({ { { &U, &V, &W, in[0], in[1], in[2] }, kReachDMC } }, [&] {
             gs.solveBackwardDMC(U, V, W, *in[0], *in[1], *in[2], *out[0], *out[1], *out[2], substep);
-        });
+        }, gs.validAfter({ &U, &V, &W, in[0], in[1], in[2] }, kReachDMC) - kReachDMC);
         const int v = gpuMapper::minValid({ &U, &V, &W, in[0], in[1], in[2] }) - kReachDMC;
         gs.producedAll({ out[0], out[1], out[2] }, v);
         in[0] = out[0]; in[1] = out[1]; in[2] = out[2];
@@ -100,7 +100,7 @@ void MapperBaseGPU::updateForward(DeviceField &U, DeviceField &V, DeviceField &W
     const int reach = reachField(m.Dfwd + dcells);
     gs.withGhosts({ { { &U, &V, &W }, reach } }, [&] {
         gs.solveForward(U, V, W, m.ForwardX, m.ForwardY, m.ForwardZ, cfldt, dt);
-    });
+    }, std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }), gs.validAfter({ &U, &V, &W }, reach) - reach));
     const int v = std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }),
                            gpuMapper::minValid({ &U, &V, &W }) - reach);
     gs.producedAll({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, v);
@@ -122,13 +122,17 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     // advect: U(x) = blend9(Ui(psi_back(x)))
     gs.withGhosts({ { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap }, { { &Ui, &Vi, &Wi }, reachField(m.Dback) } }, [&] {
         gs.advectVelocity(U, V, W, Ui, Vi, Wi, m.BackwardX, m.BackwardY, m.BackwardZ, false);
-    });
+    }, std::min(gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
+                gs.validAfter({ &Ui, &Vi, &Wi }, reachField(m.Dback)) - reachField(m.Dback)));
     gs.producedAll({ &U, &V, &W }, std::min(gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                             gpuMapper::minValid({ &Ui, &Vi, &Wi }) - reachField(m.Dback)));
 
     trace_point("v.advect");
     // stage 1: error at time 0, u_src = blend9(U(psi_fwd(x))) - Ui(x)      (GPU_Advection.h:499-501 zeroes u_src)
     bool stage2_done;
+    // The error itself is correct on fewer ghost planes, but with the fused stage 2 the same launch leaves the copy of U in
+    // Ui, and that copy is wanted wherever U is correct (the limiter reads it): the kernels run on all of those planes.
+    const int err_valid = std::max(0, gs.validAfter({ &U, &V, &W }, reachField(m.Dfwd)));
     {
         // fused: the kernels zero the error outside their window and store U into Ui after reading it (stage 2)
         FusedScope fused(gs.fuse_housekeeping, 1 | 2);
@@ -137,7 +141,7 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
         gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &U, &V, &W }, reachField(m.Dfwd) } }, [&] {
             gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
                                           m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
-        });
+        }, err_valid);
     }
     gs.producedAll({ &gs.u_src, &gs.v_src, &gs.w_src },
                    std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
@@ -145,12 +149,14 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
                               gpuMapper::minValid({ &Ui, &Vi, &Wi }) }));
     trace_point("v.stage1");
     // stage 2: Ui <- uncompensated U (clobbers the caller's init)
-    if (stage2_done) { Ui.valid = U.valid; Vi.valid = V.valid; Wi.valid = W.valid; }
+    // (the fused copy exists on the planes the error kernels ran on: owned + err_valid ghost planes)
+    if (stage2_done) { Ui.valid = std::min(U.valid, err_valid); Vi.valid = std::min(V.valid, err_valid); Wi.valid = std::min(W.valid, err_valid); }
     else { Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W); }
     // stage 3: U += blend9(-0.5 * u_src(psi_back(x)))
     gs.withGhosts({ { { &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
         gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
-    });
+    }, std::min({ gpuMapper::minValid({ &U, &V, &W }), gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
+                  gs.validAfter({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback)) - reachField(m.Dback) }));
     gs.producedAll({ &U, &V, &W }, std::min({ gpuMapper::minValid({ &U, &V, &W }),
                                               gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                               gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) }));
@@ -248,7 +254,8 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
         if (!fused.on) { f1.zero(); f2.zero(); }                            // GPU_Advection.h:507
         gs.withGhosts({ { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap }, { { &f1Init, &f2Init }, reachField(m.Dback) } }, [&] {
             gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
-        });
+        }, std::min(gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
+                    gs.validAfter({ &f1Init, &f2Init }, reachField(m.Dback)) - reachField(m.Dback)));
     }
     gs.produced(f1, std::min(back() - kReachMap, f1Init.valid - reachField(m.Dback)));
     gs.produced(f2, std::min(back() - kReachMap, f2Init.valid - reachField(m.Dback)));
@@ -262,7 +269,7 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
         if (!fused.on) { fl_memset(e1, 0, g.n() * sizeof(float)); fl_memset(e2, 0, g.n() * sizeof(float)); }
         gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &f1, &f2 }, reachField(m.Dfwd) } }, [&] {
             gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
-        });
+        }, std::max(0, gs.validAfter({ &f1, &f2 }, reachField(m.Dfwd))));      // (wherever f is correct: the fused copy into fInit)
     }
     const size_t plane1 = e1.plane, plane2 = e2.plane;
     e1.plane = e2.plane = (size_t)ni * nj;
@@ -272,7 +279,8 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
     else { f1Init.copy_from(f1); f2Init.copy_from(f2); }
     gs.withGhosts({ { { &e1, &e2 }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
         gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
-    });
+    }, std::min({ f1.valid, f2.valid, gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
+                  gs.validAfter({ &e1, &e2 }, reachField(m.Dback)) - reachField(m.Dback) }));
     gs.produced(f1, std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) }));
     gs.produced(f2, std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) }));
     e1.plane = plane1; e2.plane = plane2;
@@ -311,7 +319,8 @@ void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, Devic
             gpu_accumulate_velocity_identity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false, coeff);
         else
             gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
-    });
+    }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }), gs.validAfter({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap) - kReachMap,
+                  gs.validAfter({ &Uc, &Vc, &Wc }, reachField(m.Dfwd)) - reachField(m.Dfwd) }));
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc, &Vc, &Wc }) - reachField(m.Dfwd) }));
@@ -328,7 +337,8 @@ void MapperBaseGPU::accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, Devi
             gpu_accumulate_component(Uc2, coeff2, nullptr, 0.f, dUi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 0, false);
             gpu_accumulate_component(Vc1, coeff1, Vc2, coeff2, dVi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 1, false);
             gpu_accumulate_component(Wc2, coeff2, nullptr, 0.f, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 2, false);
-        });
+        }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }), gs.validAfter({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap) - kReachMap,
+                      gs.validAfter({ &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd)) - reachField(m.Dfwd) }));
         gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                         gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                         gpuMapper::minValid({ &Vc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
@@ -337,7 +347,8 @@ void MapperBaseGPU::accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, Devi
     gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd) } }, [&] {
         gpu_accumulate_velocity2(Uc1, Vc1, Wc1, coeff1, Uc2, Vc2, Wc2, coeff2, dUi, dVi, dWi,
                                  m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false);
-    });
+    }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }), gs.validAfter({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap) - kReachMap,
+                  gs.validAfter({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd)) - reachField(m.Dfwd) }));
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
