@@ -1,23 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- bimocq3D per-step throughput on MI355X.
 
-Metric (BASELINE.json): Mvoxels/s per step of the 256^3 rising-smoke scene (L=1, h=1/N,
+Metric (BASELINE.json): Mvoxels/s per step of the rising-smoke scene (L=1, h=1/N,
 dt=2h, nu=0, blend=1, alpha=0, beta=1, one spherical source at step 0, Jacobi 200 iterations,
 halfrdx=0.5 = the reference's value), plus the HBM roofline fraction of the dominant kernel (the
-Jacobi sweep, 12 algorithmic bytes per voxel per sweep) and the CPU oracle timed beside it.
+Jacobi sweep) and the CPU oracle timed beside it.
 
 A "step" is one BimocqGPUSolver::advance(): map update, advection with error compensation, forces,
 projection (divergence, Jacobi sweeps, gradient), accumulation, re-initialisation -- all resident in
-HBM; nothing crosses PCIe inside the timed region.
+HBM; nothing crosses PCIe inside the timed region (with --dump the density download of frame f
+overlaps frame f+1 on a third stream).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--jacobi-iters 200]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--jacobi-iters 200]
 
-N > 1: launched by torch.distributed.run, one rank per GPU (see DESIGN.md "Multi-GPU").
+Workloads:
+    N = 1 (default)   BASELINE config 3: 256^3, 200 Jacobi iterations, one MI355X
+    N > 1 (default)   BASELINE config 4: ONE 512^3 grid split into N z-slabs (strong scaling), ghost planes
+                      exchanged with RCCL send/recv over xGMI; --weak gives size^3 per GPU instead
+    --scene leapfrog --grid 1024 1024 512 --dump DIR     BASELINE config 5 (two coaxial vortex rings, density dumped
+                      every frame, one file per slab and frame)
+
+`python bench.py --gpus N` (N > 1) started on its own launches `python -m torch.distributed.run` with N ranks as a
+CHILD process before anything touches the GPU and relays rank 0's JSON line and the exit code; started by
+torch.distributed.run (RANK/WORLD_SIZE in the environment) it is one rank of that job.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+INFINITY_CACHE_BYTES = 256 << 20
 JACOBI_BYTES_PER_VOXEL = 12.0   # read p + read div + write p'  
+
+SMOKE = (0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)     # (cx, cy, cz, radius, density, temperature, emiter, frames): SURVEY 8d
 
 
 def parse():
@@ -33,10 +48,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=180)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", dest="n", type=int, default=256, help="grid is size^3 (per rank when --gpus > 1)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling (BASELINE config 4: 512^3 across 8 GPUs): the global grid is size^3 and each of the N "
-                         "ranks owns size/N planes; default is weak scaling, size^3 per GPU")
+    ap.add_argument("--size", dest="n", type=int, default=None,
+                    help="grid is size^3; default 256 on one GPU (BASELINE config 3), 512 across N > 1 GPUs (config 4)")
+    ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
+                    help="non-cubic global grid (config 5: 1024 1024 512); h = 1/NX")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: weak scaling, size^3 (default 256) PER GPU, the grid grows along z; the default for N > 1 is "
+                         "strong scaling of one global grid (BASELINE config 4)")
+    ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for round-1 command lines)")
+    ap.add_argument("--scene", choices=["smoke", "leapfrog"], default="smoke",
+                    help="smoke: SURVEY 8d rising smoke; leapfrog: two coaxial vortex rings blown along x by the reference's "
+                         "emitter formula (src/bimocq3D/main.cpp:52-78), no buoyancy (BASELINE config 5)")
+    ap.add_argument("--dump", default=None, metavar="DIR",
+                    help="write the density of every frame (outputResultAsync: download on a third stream, writer thread; "
+                         "one density_render_%%04d[.k%%05d].bqd per frame [and slab]) INSIDE the timed region")
     ap.add_argument("--jacobi-iters", type=int, default=200)
     ap.add_argument("--halfrdx", type=float, default=0.5)
     ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi",
@@ -44,16 +69,38 @@ def parse():
                          "shipped binary runs (SURVEY 8f N1), --mg-iters outer iterations, single GPU")
     ap.add_argument("--mg-iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the two 'extra' legs (dead-state elision, fast lerps)")
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
-    ap.add_argument("--emulate-slab", action="store_true",
-                    help="debug, one GPU: run the z-slab code path of rank 0 of 2 (size^3 owned planes + ghost planes, chunked "
-                         "Jacobi, split operators) with exchanges that move nothing -- the compute-side cost of the slab path; "
-                         "the line is labelled and is not a benchmark result")
+    ap.add_argument("--keep-dmc-border", type=int, default=None,
+                    help="N > 1: BQ_OPT_KEEP_DMC_BORDER (see DESIGN.md section 7); default = the library's slab default")
+    ap.add_argument("--emulate-slab", type=int, nargs="?", const=2, default=0, metavar="R",
+                    help="debug, one GPU: run the z-slab code path of ONE rank of R (own planes + ghost planes, chunked "
+                         "Jacobi, split operators) with exchanges that move nothing -- the compute-side cost of the slab "
+                         "path; the line is labelled and is not a benchmark result")
+    ap.add_argument("--emulate-rank", type=int, default=None, help="which rank to emulate (default: a middle one)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="N > 1: ghost planes over RCCL/xGMI (default) or staged through the host over gloo (debug)")
     return ap.parse_args()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: become the launcher.  Nothing in this process
+    has touched HIP or torch.cuda (torch is not even imported), and the ranks are CHILD processes, never an exec."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def usable_cores():
@@ -91,7 +138,7 @@ def cpu_baseline(args):
     oracle_lib.lib(march="native", out="_build_native")        # rebuilt for this host's ISA
     n = args.cpu_n
     s = oracle_lib.OracleSolver(n, n, n, 1.0, 0.0, 1.0)
-    s.set_smoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
+    s.set_smoke(0.0, 1.0, [SMOKE])
     mg = args.projection == "mgcg"
     s.set_projection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
     dt = 2.0 / n
@@ -108,25 +155,34 @@ def cpu_baseline(args):
                       + f"), OpenMP C oracle (-O2 -march=native), {el:.1f} s"}
 
 
-def pmc_traffic(n, sweeps_per_launch=1.0, kernel=""):
-    """HBM bytes per Jacobi launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+def pmc_traffic(dims, kernel):
+    """Fabric bytes per Jacobi launch from the committed rocprofv3 PMC passes (profiles/jacobi_pmc_traffic.json:
+    FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950 + WRITE_SIZE, separate passes), or None
+    when no pass exists for this grid and kernel."""
     path = os.path.join(ROOT, "profiles", "jacobi_pmc_traffic.json")
-    key = str(n) if sweeps_per_launch < 1.5 else (f"{n}_fused2r" if kernel == "jacobi_march2r_kernel" else f"{n}_fused2")
+    nx, ny, nz = dims
+    if not (nx == ny == nz):
+        return None
     try:
         with open(path) as f:
-            return json.load(f).get(key, {}).get("bytes_per_launch")
+            table = json.load(f)
     except Exception:
         return None
+    for key in (f"{nx}_{kernel}", f"{nx}_fused2r" if kernel == "jacobi_march2r_kernel" else f"{nx}_fused2"):
+        if key in table and table[key].get("bytes_per_launch"):
+            return table[key]["bytes_per_launch"]
+    return None
 
 
 def main():
     args = parse()
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch
@@ -151,11 +207,26 @@ def main():
     from gpufluidsimulation_amd import transport
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     lib = bq.hip_lib()
-    n = args.n
     if lib.fl_init(local_rank) != 0:
         bq.check()
-    # N > 1: weak scaling -- the grid grows along z, n x n x (n*N), one z-slab of n planes per GPU, one
-    # source per slab (same work everywhere); N = 1 is exactly BASELINE's n^3 workload
+
+    # ---- the grid -------------------------------------------------------------------------------------
+    emul = args.emulate_slab if world == 1 else 0
+    multi = world > 1 or emul > 1
+    nslabs = world if world > 1 else (emul if emul > 1 else 1)
+    weak = args.weak and not args.strong
+    if args.grid:
+        nx, ny, nz_global = args.grid
+        weak = False
+    else:
+        n = args.n if args.n else (256 if (not multi or weak) else 512)
+        nx = ny = n
+        nz_global = n * nslabs if (multi and weak) else n
+    if multi and nz_global % nslabs:
+        sys.exit("the global plane count must be divisible by the number of ranks")
+    h = 1.0 / nx
+    dt = 2.0 * h
+
     keep = None
     side = None                                 # gloo side channel: agreement on the transport, fallback exchange
     if world > 1:
@@ -186,30 +257,37 @@ def main():
                 args.transport_note = "host-staged over gloo (FALLBACK: RCCL set-up failed)"
         else:
             keep = transport.HostStagedTransport(lib, dist)
-        if args.strong and n % world:
-            sys.exit("--strong needs size divisible by the number of ranks")
-        nz_global = n if args.strong else n * world
-        s = BimocqGPUSolver(n, n, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
-    elif args.emulate_slab:
-        keep = transport.NullTransport(lib, 0, 2)
-        nz_global = n
-        s = BimocqGPUSolver(n, n, 2 * n, 1.0, 0.0, 1.0, device=local_rank, rank=0, nranks=2, ghost=args.ghost)
+        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
+    elif emul > 1:
+        erank = args.emulate_rank if args.emulate_rank is not None else emul // 2
+        keep = transport.NullTransport(lib, erank, emul)
+        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=erank, nranks=emul, ghost=args.ghost)
     else:
-        nz_global = n
-        s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=local_rank)
-    if args.strong:
-        s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])         # BASELINE's one source in the n^3 box
+        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank)
+    comm_size = int(lib.fl_comm_size())
+
+    # ---- the scene ------------------------------------------------------------------------------------
+    if args.scene == "leapfrog":
+        # the reference's vortex-collision emitters (main.cpp:52-78: 10 frames, density 1, velocity ring of its
+        # emitter formula), placed coaxially and both blowing along +x: the rear ring threads the front one
+        zc = 0.5 * nz_global * h
+        s.setSmoke(0.0, 0.0, [(0.15, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10), (0.35, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10)])
+    elif multi and weak:
+        s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(nslabs)])    # one source per slab
     else:
-        s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(world)])
+        s.setSmoke(0.0, 1.0, [(SMOKE[0], SMOKE[1], 0.5 * nz_global * h) + SMOKE[3:]])
     mg = args.projection == "mgcg"
-    if mg and world > 1:
+    if mg and multi:
         sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
     s.setProjection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
     # The headline number is measured with the reference's FULL per-step sequence (BQ_OPT_FULL_STATE = 1): every
     # buffer the reference updates is updated, including the *Prev state that nothing reads when blend == 1.  The
     # library's default elides that dead state; its rate is reported next to the headline as "extra".
     s.setOption(3, 1)
-    dt = 2.0 / n
+    if args.keep_dmc_border is not None:
+        s.setOption(1, args.keep_dmc_border)
+    if args.dump:
+        os.makedirs(args.dump, exist_ok=True)
 
     def barrier():
         lib.fl_sync()
@@ -219,108 +297,154 @@ def main():
         lib.fl_sync()
 
     frame = 0
-    for _ in range(args.warmup):
-        s.advance(frame, dt)
-        frame += 1
+
+    def run(k):
+        nonlocal frame
+        for _ in range(k):
+            s.advance(frame, dt)
+            if args.dump:
+                s.outputResultAsync(frame, args.dump)        # joins the previous frame's dump, starts this one
+            frame += 1
+        if args.dump:
+            s.waitOutput()
+
+    run(args.warmup)
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s.advance(frame, dt)
-        frame += 1
+    run(args.steps)
     barrier()
     el = time.perf_counter() - t0
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 0)
     bq.check()
-    # the same scene continued with the library's default (dead *Prev state not computed), a shorter untimed-in-the-
-    # headline leg: reported as extra information only
-    extra_steps = max(1, min(40, args.steps))
-    s.setOption(3, 0)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(extra_steps):
-        s.advance(frame, dt)
-        frame += 1
-    barrier()
-    el_extra = time.perf_counter() - t1
-    # ... and with the fast arithmetic variant on top (FL_OPT_FAST_LERP: one fp32 fma per lerp; within 1e-6 RMS of
-    # the exact fields after 200 steps, tests/test_gpu_solver.py::test_fast_lerp_variant) -- extra information too
-    lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 1)
-    barrier()
-    t2 = time.perf_counter()
-    for _ in range(extra_steps):
-        s.advance(frame, dt)
-        frame += 1
-    barrier()
-    el_fast = time.perf_counter() - t2
-    lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
     ms, launches, sweeps = C.c_double(0.0), C.c_longlong(0), C.c_longlong(0)
     lib.fl_jacobi_profile(C.byref(ms), C.byref(launches), C.byref(sweeps))
+    extra = None
+    if not args.no_extra and args.scene == "smoke" and not args.dump:
+        # the same scene continued with the library's default (dead *Prev state not computed), a shorter leg outside
+        # the headline: reported as extra information only
+        extra_steps = max(1, min(40, args.steps))
+        s.setOption(3, 0)
+        barrier()
+        t1 = time.perf_counter()
+        run(extra_steps)
+        barrier()
+        el_extra = time.perf_counter() - t1
+        # ... and with the fast arithmetic variant on top (FL_OPT_FAST_LERP: one fp32 fma per lerp; NOT the reference
+        # arithmetic) -- extra information too
+        lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 1)
+        barrier()
+        t2 = time.perf_counter()
+        run(extra_steps)
+        barrier()
+        el_fast = time.perf_counter() - t2
+        lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
+        extra = (extra_steps, el_extra, el_fast)
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=side if (side is not None and args.transport == "host") else None)
         el = float(t.item())
 
-    voxels = n * n * nz_global                  # weak scaling: every rank advances its own n^3 grid; strong: n^3 in all
+    voxels = nx * ny * nz_global                # the whole job's grid: every rank advances its slab of it once per step
+    own_planes = nz_global // nslabs
     ms_per_step = el / args.steps * 1e3
     value = voxels * args.steps / el / 1e6
+    grid_txt = f"{nx}^3" if nx == ny == nz_global else f"{nx}x{ny}x{nz_global}"
+    scene_txt = "rising smoke" if args.scene == "smoke" else "leapfrogging vortex rings"
+    border_txt = ""
+    if multi:
+        kb = s.getOption(1) if hasattr(s, "getOption") else None
+        border_txt = {1: ", DMC map border kept (BQ_OPT_KEEP_DMC_BORDER = 1: slab ranks bit-identical to one GPU in this mode)",
+                      0: ", DMC map border zeroed as in the reference (BQ_OPT_KEEP_DMC_BORDER = 0)"}.get(kb, "")
     line = {
-        "metric": "Mvoxels/s per step (bimocq3D rising smoke" + (", multigrid-CG projection)" if mg else ")"),
+        "metric": f"Mvoxels/s per step (bimocq3D {scene_txt}" + (", multigrid-CG projection)" if mg else ")"),
         "value": round(value, 2), "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64" if mg else "f32", "data": "synthetic",
-        "config": {"workload": f"bimocq3D {n}^3 rising smoke, "
+        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
+        "dtype": "f64" if mg else "f32", "data": "synthetic",
+        "config": {"workload": f"bimocq3D {grid_txt} {scene_txt}, "
                                + (f"fp64 multigrid-CG projection ({args.mg_iters} outer iterations, 6 levels), fp32 advection, "
                                   if mg else f"{args.jacobi_iters} Jacobi iters, fp32, ")
-                               + f"halfrdx {args.halfrdx}, reinit every step",
-                   "grid_per_gpu": [n, n, nz_global // world], "global_grid": [n, n, nz_global], "dt": dt,
+                               + f"halfrdx {args.halfrdx}, reinit every step"
+                               + (", density dumped every frame (async, per slab)" if args.dump else ""),
+                   "grid_per_gpu": [nx, ny, own_planes], "global_grid": [nx, ny, nz_global], "dt": dt,
+                   "comm_size": comm_size,
                    "parallelism": "1 GPU" if world == 1 else
-                   f"{world} z-slabs of {nz_global // world} planes, {args.ghost} ghost planes, neighbour exchange over "
-                   + getattr(args, "transport_note", args.transport)},
+                   f"{world} z-slabs of {own_planes} planes, {args.ghost} ghost planes, neighbour exchange over "
+                   + getattr(args, "transport_note", args.transport + (f" ({comm_size} ranks in the communicator)" if args.transport == "rccl" else ""))
+                   + border_txt},
     }
-    if args.emulate_slab:
-        line["metric"] += " [EMULATED z-slab rank 0 of 2 on one GPU, exchanges move nothing: compute-side cost only]"
-        line["config"]["parallelism"] = f"emulated slab: {n} owned + 2 x {args.ghost} ghost planes, no data exchanged"
-    line["extra"] = {"dead_state_elision": {"value": round(voxels * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
-                                            "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
-                                            "note": "library default: with blend == 1 and a re-initialisation every frame the "
-                                                    "*Prev fields are never read, so the accumulation that only feeds them is "
-                                                    "skipped; every observable field is identical (DESIGN.md section 3)"},
-                     "fast_lerp_variant": {"value": round(voxels * extra_steps / el_fast / 1e6, 2), "unit": "Mvoxels/s",
-                                           "ms_per_step": round(el_fast / extra_steps * 1e3, 3), "steps": extra_steps,
-                                           "note": "FL_OPT_FAST_LERP = 1 on top of the elision: every lerp of the gather kernels is "
-                                                   "one fp32 fma; NOT bit-identical to the reference arithmetic, within 1e-6 RMS "
-                                                   "after 200 steps (tolerance 1e-5; DESIGN.md section 12)"}}
+    if emul > 1:
+        line["metric"] += f" [EMULATED z-slab rank {s.rank} of {emul} on one GPU, exchanges move nothing: compute-side cost only]"
+        line["config"]["parallelism"] = (f"emulated slab rank {s.rank} of {emul}: {own_planes} owned + 2 x {args.ghost} ghost planes, "
+                                         f"no data exchanged" + border_txt)
+        # what the rank advances per step is its own slab
+        line["value"] = round(nx * ny * own_planes * args.steps / el / 1e6, 2)
+        line["config"]["value_counts"] = "owned voxels of the emulated rank only"
+    if extra:
+        extra_steps, el_extra, el_fast = extra
+        line["extra"] = {"dead_state_elision": {"value": round(voxels * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
+                                                "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
+                                                "note": "library default: with blend == 1 and a re-initialisation every frame the "
+                                                        "*Prev fields are never read, so the accumulation that only feeds them is "
+                                                        "skipped; every observable field is identical (DESIGN.md section 3)"},
+                         "fast_lerp_variant": {"value": round(voxels * extra_steps / el_fast / 1e6, 2), "unit": "Mvoxels/s",
+                                               "ms_per_step": round(el_fast / extra_steps * 1e3, 3), "steps": extra_steps,
+                                               "note": "FL_OPT_FAST_LERP = 1 on top of the elision: every lerp of the gather kernels is "
+                                                       "one fp32 fma; NOT the reference arithmetic (DESIGN.md section 12: deviation "
+                                                       "from the exact fields measured per grid size, tolerance 1e-5 RMS)"}}
     if launches.value > 0 and mg:
-        # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_smooth2_kernel:
-        # 24 B/cell/sweep (x, rhs in, x' out)
+        # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_smooth2_kernel: one launch reads x and
+        # rhs and writes x' once (24 B/cell compulsory), which is 24 B/cell/sweep x 2 sweeps in SURVEY 8(d)'s per-sweep
+        # accounting
         us = ms.value * 1e3 / launches.value
         spl = sweeps.value / launches.value
-        alg = 24 * n ** 3 * spl
-        achieved = alg / (us * 1e-6) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "mg_smooth2_kernel (level 0)", "achieved": round(achieved, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        cells = nx * ny * nz_global
+        compulsory = 24.0 * cells
+        alg = compulsory * spl
+        ach = compulsory / (us * 1e-6) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": "mg_smooth2_kernel (level 0)", "achieved": round(ach, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "frac_traffic": None, "compulsory_bytes_per_launch": int(compulsory),
+                            "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
+                                                  "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "note": "24 B/cell/sweep x sweeps per launch: what unfused sweeps would move"},
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
-                            "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3),
-                            "algorithmic_bytes_per_launch": int(alg)}
+                            "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3)}
     elif launches.value > 0:
-        # dominant kernel: the Jacobi sweep.  A launch of jacobi_march2_kernel performs two sweeps, so the
-        # algorithmic bytes of a launch are 12 B/voxel x voxels x sweeps-per-launch.
+        # Dominant kernel: the Jacobi sweep.  A fused launch performs two sweeps but reads p and div and writes p' ONCE:
+        # its compulsory bytes are 12 B/voxel x voxels, whatever the number of sweeps.  `achieved`/`frac` are those
+        # bytes over the launch time -- a true fraction of the HBM peak.  SURVEY 8(d)'s per-sweep accounting
+        # (12 B/voxel/sweep x sweeps per launch = what unfused sweeps would move) is kept as `algorithmic_equiv`.
         us = ms.value * 1e3 / launches.value
         spl = sweeps.value / launches.value
-        # a z-slab rank sweeps its ghost planes too (communication-avoiding chunks): n x n x (n + 2G) cells per sweep;
-        # the overlapped first sweep of a chunk (three range launches) is not inside the timed spans
-        cells = n ** 3 if (world == 1 and not args.emulate_slab) else n * n * (nz_global // world + 2 * args.ghost)
-        alg = JACOBI_BYTES_PER_VOXEL * cells * spl
-        achieved = alg / (us * 1e-6) / 1e9
+        # a z-slab rank sweeps its ghost planes too (communication-avoiding chunks); the overlapped first launches of
+        # a chunk (plane ranges) are not inside the timed spans
+        planes = nz_global if not multi else own_planes + 2 * args.ghost
+        cells = nx * ny * planes
+        compulsory = JACOBI_BYTES_PER_VOXEL * cells
+        alg = compulsory * spl
+        ach = compulsory / (us * 1e-6) / 1e9
         kname = (lib.fl_jacobi_kernel_name() or b"").decode() or "jacobi_march2_kernel"
-        line["roofline"] = {"bound": "hbm", "kernel": kname if spl > 1.5 else "jacobi_march_kernel",
-                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n, spl, kname) if (world == 1 and not args.emulate_slab) else None,
+        kname = kname if spl > 1.5 else "jacobi_march_kernel"
+        traffic = pmc_traffic((nx, ny, nz_global), kname) if not multi else None
+        resident = compulsory <= INFINITY_CACHE_BYTES
+        line["roofline"] = {"bound": "hbm", "kernel": kname,
+                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": traffic,
+                            "frac_traffic": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                            "compulsory_bytes_per_launch": int(compulsory),
+                            "working_set": ("infinity-cache" if resident else "hbm"),
+                            "bound_note": (f"p, p', div = {compulsory / 1e6:.0f} MB fit the 256 MiB Infinity Cache: the launch is bound "
+                                           "by the fabric/Infinity Cache, not by DRAM; the HBM peak is the yardstick BASELINE names"
+                                           if resident else f"p, p', div = {compulsory / 1e6:.0f} MB: HBM-resident"),
+                            "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
+                                                  "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "note": "SURVEY 8(d): 12 B/voxel/SWEEP x sweeps per launch -- the bytes unfused "
+                                                          "sweeps would move; above 1 only because a fused launch moves one sweep's bytes"},
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
-                            "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3),
-                            "algorithmic_bytes_per_launch": int(alg)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                            "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3)}
+    if rank == 0 and world == 1 and not emul and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(args)
         except Exception as e:                  # never lose the GPU numbers to a host-side hiccup

@@ -1009,8 +1009,52 @@ void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk
     if (max_abs) *max_abs = *(float *)(host + 8);
 }
 
+} // extern "C"
+
+// The boundary shell (outermost cell layer) of a pressure buffer is never written by a sweep; the reference
+// ping-pongs, so odd iterates carry p_temp's shell and even ones p's (GPU_kernel.cu:1819-1837: interior only).
+// A fused two-sweep launch reads the intermediate iterate's shell from its INPUT buffer, which is the same thing
+// only when both shells hold the same values.  One compare of the two shells, one flag.
+__global__ void __launch_bounds__(256) shell_differs_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           int ni, int nj, int nk, int *__restrict__ flag)
+{
+    const long n = (long)ni * nj * nk;
+    bool bad = false;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(id % ni), j = (int)((id / ni) % nj), k = (int)(id / ((long)ni * nj));
+        const bool shell = i == 0 || j == 0 || k == 0 || i == ni - 1 || j == nj - 1 || k == nk - 1;
+        // value equality, with NaN == NaN (a NaN shell propagates identically from either buffer)
+        if (shell && !(a[id] == b[id] || (a[id] != a[id] && b[id] != b[id]))) bad = true;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// true when p and p_temp carry the same boundary shell (blocking: one 4-byte read-back)
+static bool shells_match(const float *p, const float *p_temp, int ni, int nj, int nk)
+{
+    int *dflag = (int *)scratch(64);
+    int *hflag = (int *)pinned(64);
+    if (!dflag || !hflag) return false;
+    hipStream_t st = rt().compute;
+    if (!BQ_HIP(hipMemsetAsync(dflag, 0, 4, st))) return false;
+    // the shell is 6 faces of a box: walk the whole index space only when it is small, else face by face would be
+    // cheaper -- but a single pass at HBM rate costs 20 us at 256^3 against a 3.5 ms projection
+    const long n = (long)ni * nj * nk;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    shell_differs_kernel<<<blocks, 256, 0, st>>>(p, p_temp, ni, nj, nk, dflag);
+    if (!BQ_LAUNCH_CHECK("shell_differs_kernel")) return false;
+    if (!BQ_HIP(hipMemcpyAsync(hflag, dflag, 4, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return false;
+    return *hflag == 0;
+}
+
+extern "C" {
+
 // GPU_kernel.cu:1839-1895.  iter sweeps are specified, iterate iter-1 is what the reference
 // applies and leaves in p -> run iter-1 sweeps and make sure the result is in p.
+// Two sweeps share a launch (FL_OPT_JACOBI_FUSE) only when that cannot change a value: with the option at 1 (default)
+// after checking that p and p_temp carry the same boundary shell -- true for the reference's own caller, which clears
+// both (gpuMapper::projectionJacobi, GPU_Advection.h:604-606), not guaranteed for any other caller of this symbol
+// (a warm-started p, a p_temp with stale contents) --, at 2 on the caller's word, at 0 never.
 void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *p_temp, float *debugParam,
                            int ni, int nj, int nk, int iter, float halfrdx, float alpha, float beta)
 {
@@ -1026,12 +1070,19 @@ void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
     SweepSpan span{nullptr, nullptr, 0, (long long)(iter - 1)};
     if (prof && BQ_HIP(hipEventCreate(&span.a)) && BQ_HIP(hipEventCreate(&span.b))) BQ_HIP(hipEventRecord(span.a, st));
     long long launches = 0;
+    const bool may_fuse = iter > 2 && (rt().opt_jacobi_fuse >= 2 ||
+                                      (rt().opt_jacobi_fuse == 1 && !rt().slab_on && shells_match(p, p_temp, ni, nj, nk)));
+    if (iter == 0) {
+        // the reference's swap loop does not run: p_out is still p_temp, which is copied over p (:1876-1879) and used
+        // by the gradient (:1883-1891)
+        fl_memcpy_d2d(p, p_temp, (size_t)ni * nj * nk * sizeof(float));
+    }
     for (int it = 0; it + 1 < iter; ) {
         if (dbg && it % stride == 0 && it < 2000)
             residual_norms_async(div, in, ni, nj, nk, nullptr, nullptr, debugParam + it, debugParam + 2000 + it);
-        // the caller has zeroed p and p_temp (GPU_Advection.h:604-606): equal boundary layers, so two
-        // sweeps may share a launch -- unless residual norms are wanted for the iterate in between
-        const bool pair_ok = rt().opt_jacobi_fuse >= 1 && it + 2 < iter && !(dbg && (it + 1) % stride == 0);
+        // equal boundary shells (checked above): two sweeps may share a launch -- unless residual norms are wanted
+        // for the iterate in between
+        const bool pair_ok = may_fuse && it + 2 < iter && !(dbg && (it + 1) % stride == 0);
         if (pair_ok && jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta)) {
             it += 2;
         } else {

@@ -612,7 +612,14 @@ bool BimocqGPUSolver::outputResultAsync(unsigned frame, const std::string &filep
     waitOutput();
     if (!dump_host_) dump_host_ = static_cast<float *>(fl_malloc_host(g.n() * sizeof(float)));
     if (!dump_host_) return false;
-    void *ticket = fl_download_begin(dump_host_, Density.get(), g.n() * sizeof(float));
+    // The next advance() rewrites Density in place (and swaps buffers) long before a 67 MB (256^3) or 2 GB download
+    // has left the device, and the copy stream's download is ordered only against compute work queued BEFORE it.  So
+    // the frame is first snapshot on the compute stream (a device-to-device copy at HBM rate: 25 us at 256^3) and the
+    // copy stream downloads the snapshot; the simulation never waits for PCIe.  waitOutput() above has retired the
+    // previous download, so the snapshot buffer is free.
+    if (dump_dev_.count() != g.n() && !dump_dev_.alloc(g.n())) return false;
+    fl_memcpy_d2d(dump_dev_.get(), Density.get(), g.n() * sizeof(float));
+    void *ticket = fl_download_begin(dump_host_, dump_dev_.get(), g.n() * sizeof(float));
     if (!ticket) return false;
     const SlabCtx sl = GpuSolver->slab;
     const GridDims gd = g;

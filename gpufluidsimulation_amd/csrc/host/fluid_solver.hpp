@@ -108,6 +108,7 @@ public:
 private:
     bool ok_ = false;
     float *dump_host_ = nullptr;        // pinned staging buffer of the asynchronous dump
+    DeviceField dump_dev_;              // device snapshot of the dumped frame (the next advance() rewrites Density)
     std::thread dump_thread_;
     long dump_result_ = 0;
 };

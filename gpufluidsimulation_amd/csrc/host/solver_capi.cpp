@@ -104,6 +104,19 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
     }
 }
 
+int bq_solver_get_option(const bq_solver *s, int option)
+{
+    if (!s) return -1;
+    switch (option) {
+    case BQ_OPT_KEEP_DMC_BORDER:     return s->solver->VelocityAdvector.keepDmcBorder ? 1 : 0;
+    case BQ_OPT_REINIT_POLICY:       return s->solver->reinit_policy;
+    case BQ_OPT_FULL_STATE:          return s->solver->keep_full_state ? 1 : 0;
+    case BQ_OPT_FUSED_HOUSEKEEPING:  return s->solver->GpuSolver->fuse_housekeeping ? 1 : 0;
+    case BQ_OPT_OVERLAP_EXCHANGES:   return s->solver->GpuSolver->overlap_exchanges ? 1 : 0;
+    default:                         return -1;
+    }
+}
+
 int bq_solver_reinit_counts(const bq_solver *s, int which)
 {
     if (!s) return 0;

@@ -29,6 +29,7 @@ HOST_SIGS = {
     "bq_solver_set_smoke": (None, [C.c_void_p, C.c_float, C.c_float, C.POINTER(Emitter), C.c_int]),
     "bq_solver_set_projection": (None, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
     "bq_solver_set_option": (None, [C.c_void_p, C.c_int, C.c_int]),
+    "bq_solver_get_option": (C.c_int, [C.c_void_p, C.c_int]),
     "bq_solver_advance": (None, [C.c_void_p, C.c_int, C.c_float]),
     "bq_solver_output_result": (C.c_long, [C.c_void_p, C.c_uint, C.c_char_p]),
     "bq_solver_output_result_async": (C.c_int, [C.c_void_p, C.c_uint, C.c_char_p]),
@@ -118,6 +119,9 @@ class BimocqGPUSolver:
         3 = BQ_OPT_FULL_STATE, 4 = BQ_OPT_FUSED_HOUSEKEEPING (include/bimocq_solver.h)"""
         self.lib.bq_solver_set_option(self.s, option, value)
         self._check()
+
+    def getOption(self, option):
+        return self.lib.bq_solver_get_option(self.s, option)
 
     def reinitCounts(self):
         """(velocity map re-initialisations, scalar map re-initialisations) so far"""

@@ -157,7 +157,12 @@ void gpu_add_field(float *out, float *field1, float *field2, float coeff, int nu
  * otherwise it needs >= 2000+iter floats and receives, for it = 0..iter-1,
  * debugParam[it] = sum r^2 and debugParam[2000+it] = max|r| of iterate `it`
  * (exact norms; the reference's buggy reductions are re-specified),
- * evaluated every fl_set_option(FL_OPT_RESIDUAL_STRIDE) iterates (0 = never). */
+ * evaluated every fl_set_option(FL_OPT_RESIDUAL_STRIDE) iterates (0 = never).
+ * A caller that does NOT clear p / p_temp (warm start) gets the reference's values too: sweeps ping-pong, odd
+ * iterates carry p_temp's boundary shell, iter == 0 copies p_temp over p (:1876-1879).  Two sweeps share a launch only
+ * where that cannot change a value: FL_OPT_JACOBI_FUSE = 1 (default) compares the two boundary shells first (one small
+ * kernel and a 4-byte read-back per call), 2 skips the check on the caller's word, 0 never fuses.  p_temp is scratch:
+ * its contents on return differ from the reference's (which performs one sweep more and discards it). */
 void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, float *p_temp,
                            float *debugParam, int ni, int nj, int nk, int iter,
                            float halfrdx, float alpha, float beta);
@@ -249,8 +254,9 @@ enum {
     FL_OPT_JACOBI_KCHUNK   = 5, /* planes marched per block in the tiled kernel (0 = auto)         */
     FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread: tiled kernel 1, 2, 4; fused kernel 1, 2 (0 = auto) */
     FL_OPT_STRUCTURED_MAPS = 7, /* 9-point kernels: compile-time taps when h is a power of two (1)  */
-    FL_OPT_JACOBI_FUSE     = 8, /* two sweeps per launch: 0 never, 1 in gpu_projection_jacobi (default),
-                                   2 also in gpu_jacobi_sweeps (caller vouches for equal boundary layers) */
+    FL_OPT_JACOBI_FUSE     = 8, /* two sweeps per launch: 0 never, 1 in gpu_projection_jacobi after it has checked that p and
+                                   p_temp carry the same boundary shell (default), 2 there without the check and also in
+                                   gpu_jacobi_sweeps (caller vouches for equal boundary shells) */
     FL_OPT_JACOBI_KCHUNK2  = 9, /* planes marched per block in the fused kernel (0 = auto)           */
     FL_OPT_MGCG_GRAPH      = 10,/* 1 (default): the multigrid V-cycle is captured into a hipGraph once and
                                  * replayed in every outer iteration; 0: plain launches                */

@@ -83,6 +83,8 @@ enum {
 int   bq_solver_reinit_counts(const bq_solver *s, int which);
 float bq_solver_last_distortion(const bq_solver *s, int which);
 void  bq_solver_set_option(bq_solver *s, int option, int value);
+/* current value of an option above (-1: unknown option) */
+int   bq_solver_get_option(const bq_solver *s, int option);
 /* advance (BimocqGPUSolver.cpp:108-127) */
 void  bq_solver_advance(bq_solver *s, int framenum, float dt);
 /* outputResult (BimocqGPUSolver.cpp:536-543): D2H of rho,u,v,w and a sparse density dump

@@ -873,7 +873,9 @@ void orc_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
         orc_residual_norms(div, p_in, ni, nj, nk, &ss, &mx);
         debug[iter - 1] = (float)ss; debug[2000 + iter - 1] = mx;
     }
-    if (p_in != p) memcpy(p, p_in, number * sizeof(float));
+    /* iter == 0: the swap loop does not run, p_out is still p_temp and is copied over p (GPU_kernel.cu:1876-1879) */
+    if (iter == 0) memcpy(p, p_temp, number * sizeof(float));
+    else if (p_in != p) memcpy(p, p_in, number * sizeof(float));
     orc_gradient(u, p, ni + 1, nj, nk, 1, 0, 0, halfrdx);
     orc_gradient(v, p, ni, nj + 1, nk, 0, 1, 0, halfrdx);
     orc_gradient(w, p, ni, nj, nk + 1, 0, 0, 1, halfrdx);

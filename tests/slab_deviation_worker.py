@@ -1,0 +1,140 @@
+"""z-slab ranks against the SINGLE-GPU run of the same library, in exactly the mode `bench.py --gpus N` runs.
+
+Two roles (GPU only; the product libraries, no oracle anywhere):
+
+  python tests/slab_deviation_worker.py --make-reference DIR [scene options]
+      one process, one GPU, no slab context: advances the scene and stores rho, u, v, w at the checkpoint
+      steps as DIR/step%04d_<field>.npy
+
+  python -m torch.distributed.run --nproc-per-node R tests/slab_deviation_worker.py --reference DIR [scene options]
+      R z-slab ranks sharing GPU 0 (ghost planes staged through the host over gloo: the transport differs from
+      RCCL, the solver code path -- ghost bookkeeping, chunked Jacobi, split operators -- is the one bench.py runs),
+      compares the planes each rank owns with the reference at every checkpoint and prints, per field, the RMS
+      over ALL entries of the global field (the north star's parity figure) and the largest difference.
+      Exit code 0 when every RMS <= --rms-tol.
+
+The single-GPU run itself is pinned bit for bit to the CPU oracle by tests/test_gpu_solver.py and
+tests/test_golden.py (128^3 hashes); this file only measures what the decomposition adds.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+FIELDS = ("rho", "u", "v", "w")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--make-reference", default=None, metavar="DIR")
+    ap.add_argument("--reference", default=None, metavar="DIR")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--checkpoints", type=int, nargs="*", default=None, help="steps (1-based) to compare; default: 1, 5, 10, ... and the last")
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--ghost", type=int, default=8)
+    ap.add_argument("--keep-dmc-border", type=int, default=None, help="default: the library's default for this kind of solver")
+    ap.add_argument("--rms-tol", type=float, default=1e-5)
+    ap.add_argument("--json", default=None, help="rank 0 writes the figures here")
+    return ap.parse_args()
+
+
+def scene(s, n, iters):
+    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])      # what bench.py runs
+    s.setProjection(iters, 0.5)
+    s.setOption(3, 1)                                                    # BQ_OPT_FULL_STATE, as in bench.py's headline
+
+
+def checkpoints(a):
+    cps = a.checkpoints if a.checkpoints else sorted(set([1] + list(range(5, a.steps + 1, 5)) + [a.steps]))
+    return [c for c in cps if 1 <= c <= a.steps]
+
+
+def main():
+    a = parse()
+    n = a.size
+    dt = 2.0 / n
+    cps = checkpoints(a)
+    import gpufluidsimulation_amd as bq
+    from gpufluidsimulation_amd import solver, transport
+
+    if a.make_reference:
+        os.makedirs(a.make_reference, exist_ok=True)
+        lib = bq.hip_lib()
+        assert lib.fl_init(0) == 0
+        s = solver.BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=0)
+        scene(s, n, a.iters)
+        if a.keep_dmc_border is not None:
+            s.setOption(1, a.keep_dmc_border)
+        for f in range(a.steps):
+            s.advance(f, dt)
+            if f + 1 in cps:
+                for name in FIELDS:
+                    np.save(os.path.join(a.make_reference, f"step{f + 1:04d}_{name}.npy"), s.field(name))
+        s._check()
+        print(f"[reference] {a.steps} steps of {n}^3 on one GPU, checkpoints {cps}, max|v| = {np.abs(s.field('v')).max():.4f}", flush=True)
+        s.close()
+        return 0
+
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.set_num_threads(1)
+    lib = bq.hip_lib()
+    assert lib.fl_init(0) == 0
+    tr = transport.HostStagedTransport(lib, dist)
+    s = solver.BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=0, rank=rank, nranks=world, ghost=a.ghost)
+    scene(s, n, a.iters)
+    if a.keep_dmc_border is not None:
+        s.setOption(1, a.keep_dmc_border)
+    mode = s.getOption(1)
+    plane = {"u": (n + 1) * n, "v": n * (n + 1)}
+    report, worst = [], 0.0
+    for f in range(a.steps):
+        s.advance(f, dt)
+        s._check()
+        if f + 1 not in cps:
+            continue
+        row = {"step": f + 1}
+        for name in FIELDS:
+            pe = plane.get(name, n * n)
+            ref = np.load(os.path.join(a.reference, f"step{f + 1:04d}_{name}.npy"), mmap_mode="r")
+            mine = s.owned(name).astype(np.float64)
+            want = np.asarray(ref[pe * s.own0: pe * s.own0 + mine.size], dtype=np.float64)
+            d = want - mine
+            acc = torch.tensor([float(np.sum(d * d)), float(d.size), float(np.sum(want * want))], dtype=torch.float64)
+            mx = torch.tensor([float(np.abs(d).max()) if d.size else 0.0], dtype=torch.float64)
+            dist.all_reduce(acc)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            rms = float(np.sqrt(acc[0] / acc[1]))
+            row[name] = {"rms": rms, "max": float(mx.item()), "rms_of_field": float(np.sqrt(acc[2] / acc[1]))}
+            worst = max(worst, rms)
+        report.append(row)
+        if rank == 0:
+            print(f"[slab-deviation] step {f + 1:3d}: " + "  ".join(f"{k} rms {row[k]['rms']:.2e} max {row[k]['max']:.2e}" for k in FIELDS), flush=True)
+    ok = worst <= a.rms_tol
+    if rank == 0:
+        out = {"grid": [n, n, n], "ranks": world, "ghost": a.ghost, "jacobi_iters": a.iters, "steps": a.steps,
+               "keep_dmc_border": mode, "transport": "host-staged over gloo, ranks share GPU 0",
+               "compared_with": "single-GPU run of the same library in the same mode (itself bit-identical to the CPU oracle)",
+               "worst_rms": worst, "rms_tol": a.rms_tol, "exchanges_per_rank": tr.exchanges, "checkpoints": report}
+        print(f"[slab-deviation] {world} ranks, {n}^3, BQ_OPT_KEEP_DMC_BORDER = {mode}: worst RMS {worst:.3e} "
+              f"({'within' if ok else 'ABOVE'} {a.rms_tol:g})", flush=True)
+        if a.json:
+            with open(a.json, "w") as fjs:
+                json.dump(out, fjs, indent=1)
+    s.close()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -109,6 +109,35 @@ def test_projection_jacobi(hip, ni, nj, nk, iters):
     m.check()
 
 
+@pytest.mark.parametrize("ni,nj,nk", [(32, 32, 32), (64, 20, 12)])
+@pytest.mark.parametrize("iters", [0, 1, 2, 5, 6])
+@pytest.mark.parametrize("same_shell", [False, True])
+def test_projection_jacobi_raw_abi_warm_start(hip, ni, nj, nk, iters, same_shell):
+    """The extern "C" symbol called directly, the way a maintainer's binding would, WITHOUT gpuMapper's clears: a
+    warm-started p and a p_temp with its own contents.  The reference ping-pongs, so odd iterates carry p_temp's
+    boundary shell (GPU_kernel.cu:1860-1875); the fused two-sweep launch may only be taken when both shells are equal
+    (checked inside gpu_projection_jacobi); iter == 0 copies p_temp over p (:1876-1879)."""
+    import gpufluidsimulation_amd as bq
+    h = 1.0 / ni
+    u, v, w = F.velocity(ni, nj, nk, h)
+    n = ni * nj * nk
+    p0 = F.scalar(ni, nj, nk, 0.3)
+    t0 = p0.copy() if same_shell else F.scalar(ni, nj, nk, 2.2, amp=0.7)
+    if same_shell:                                       # same shell, different interior
+        t3 = t0.reshape(nk, nj, ni)
+        t3[1:-1, 1:-1, 1:-1] = F.scalar(ni, nj, nk, 2.2, amp=0.7).reshape(nk, nj, ni)[1:-1, 1:-1, 1:-1]
+    ru, rv, rw, rp, rt = u.copy(), v.copy(), w.copy(), p0.copy(), t0.copy()
+    rd = np.zeros(n, np.float32)
+    oracle().orc_projection_jacobi(fp(ru), fp(rv), fp(rw), fp(rd), fp(rp), fp(rt), None, ni, nj, nk, iters, 0.5, ALPHA, BETA)
+    du, dv, dw, dd, dp, dt = dev(u, v, w, np.zeros(n, np.float32), p0, t0)
+    assert hip.fl_get_option(bq._lib.FL_OPT_JACOBI_FUSE) == 1
+    hip.gpu_projection_jacobi(du.ptr, dv.ptr, dw.ptr, dd.ptr, dp.ptr, dt.ptr, None, ni, nj, nk, iters, 0.5, ALPHA, BETA)
+    bq.check()
+    assert F.same(rd, dd.numpy())
+    assert F.same(rp, dp.numpy()), "p"
+    assert F.same(ru, du.numpy()) and F.same(rv, dv.numpy()) and F.same(rw, dw.numpy())
+
+
 def test_residual_norms(hip):
     import gpufluidsimulation_amd as bq
     ni, nj, nk = 64, 40, 24

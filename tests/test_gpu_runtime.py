@@ -60,9 +60,10 @@ def test_async_download_snapshots_the_request_point(lib):
     lib.fl_memcpy_h2d(dev, a.ctypes.data, 4 * n)
     ticket = lib.fl_download_begin(host, dev, 4 * n)
     assert ticket
-    # work queued AFTER the request must not leak into the download... (the copy stream is ordered after the compute
-    # work queued so far; a later overwrite of the source has to wait for nothing, so snapshot semantics need the caller
-    # to keep the source intact until the ticket is waited on -- which is what the solver does: it only reads Density)
+    # the copy stream is ordered after the compute work queued so far; compute work queued LATER does not wait for the
+    # download, so the caller must keep the source intact until the ticket is waited on -- the solver's dump path
+    # downloads a device snapshot of Density for that reason (the next advance() rewrites Density in place:
+    # tests/test_gpu_solver.py::test_async_dump_survives_immediate_overwrite)
     assert lib.fl_download_wait(ticket) == 0
     got = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_float)), shape=(n,))
     assert np.array_equal(got, a)

@@ -243,6 +243,33 @@ def test_async_dump_overlaps_next_step(tmp_path):
     s.close()
 
 
+def test_async_dump_survives_immediate_overwrite(tmp_path):
+    """The next advance() rewrites Density in place while a 256^3 density (67 MB, milliseconds over PCIe) is still
+    being downloaded: the dump must hold frame f, not a mixture of f and f+1.  outputResultAsync snapshots the frame
+    on the compute stream first; this test fails with a download straight from Density."""
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    n = 256
+    dt = 2.0 / n
+    em = [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)]
+    a_dir, b_dir = str(tmp_path / "async"), str(tmp_path / "sync")
+    s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0); s.setSmoke(0.0, 1.0, em); s.setProjection(20, 0.5)
+    for f in range(4):
+        s.advance(f, dt)
+    assert s.outputResultAsync(3, a_dir)
+    for f in range(4, 8):
+        s.advance(f, dt)                               # queued at once: overwrites Density while frame 3 downloads
+    n_async = s.waitOutput()
+    s.close()
+    t = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0); t.setSmoke(0.0, 1.0, em); t.setProjection(20, 0.5)
+    for f in range(4):
+        t.advance(f, dt)
+    n_sync = t.outputResult(3, b_dir)
+    t.close()
+    assert n_async == n_sync and n_sync > 10000
+    fa, fb = os.path.join(a_dir, "density_render_0004.bqd"), os.path.join(b_dir, "density_render_0004.bqd")
+    assert open(fa, "rb").read() == open(fb, "rb").read()
+
+
 def test_dead_state_elision_changes_no_observable_field():
     """blend == 1 + re-initialisation every frame: the pre-reinit accumulation only survives in the *Prev fields,
     which nothing samples; the default skips it, BQ_OPT_FULL_STATE = 1 executes it -- every field and the
