@@ -102,6 +102,12 @@ HIP_SIGS = {
     "fl_halo_exchange": (None, [c_i, C.POINTER(VP), C.POINTER(C.c_size_t), C.POINTER(c_i), c_i, c_i, c_i, c_i]),
     "fl_halo_wait": (None, []),
     "fl_comm_set_custom": (None, [c_i, c_i, VP, VP]),
+    # wall sheets (reference-faithful DMC border on z-slab ranks)
+    "fl_box_pack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),
+    "fl_box_unpack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),
+    "fl_p2p_exchange": (None, [c_i, VP, VP, VP, VP, VP]),
+    "fl_comm_set_custom_p2p": (None, [VP]),
+    "gpu_accumulate_wall_fixup": (None, [VP, c_i, c_i, VP, VP, VP, VP, VP, c_f, c_i, c_i, c_i, c_i, c_f, VP, c_i, VP, c_i, VP, c_i]),
 }
 
 FL_OK, FL_ERR_NO_DEVICE, FL_ERR_HIP, FL_ERR_BAD_ARGUMENT, FL_ERR_UNSUPPORTED, FL_ERR_COMM = range(6)

@@ -356,6 +356,44 @@ __global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void cumulate_kernel(Cumulate
     }
 }
 
+// ---- z-slab ranks: cumulate_kernel's expression on ONE wall layer of its index window, source in a wall-sheet copy --
+// (include/bimocq_gpu.h: gpu_accumulate_wall_fixup.)  face_axis 0/1/2: the layer i == face_index, j == face_index or
+// GLOBAL plane kg == face_index; threads cover the other two axes.  The map look-up is mapped9 (direct loads: the same
+// lerps as the LDS-staged form), the gather is blend9_gather_w in its general form (bit-identical to the one-fma form
+// wherever that applies) -- so a node comes out exactly as cumulate_kernel would produce it from the same values.
+template <bool P2, int SD>
+__global__ __launch_bounds__(256) void wall_fixup_kernel(const float *src, int src_nk, int src_koff,
+                                                         const float *before, float *dst,
+                                                         const float *mx, const float *my, const float *mz,
+                                                         Spacing sp, Grid g, int dx, int dy, int dz, float coeff,
+                                                         int face_axis, int face_index, int kw1)
+{
+    const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
+    const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+    int i, j, k;
+    if (face_axis == 0)      { i = face_index; j = a; k = b + g.kw0; }
+    else if (face_axis == 1) { i = a; j = face_index; k = b + g.kw0; }
+    else                     { i = a; j = b; k = face_index - g.koff; }
+    if (i >= nbi || j >= nbj || k < g.kw0 || k >= kw1 || k >= nbk) return;
+    const int kg = k + g.koff;
+    if (!(1 + dx < i && i < nbi - 2 && 1 + dy < j && j < nbj - 2 && 1 + dz < kg && kg < g.nkg + dz - 2)) return;
+    const float h = sp.h;
+    Map3 m{make_field(mx, g.ni, g.nj, g.nk, g.koff), make_field(my, g.ni, g.nj, g.nk, g.koff), make_field(mz, g.ni, g.nj, g.nk, g.koff)};
+    Nine n = nine_setup(h, dx, dy, dz);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
+    f3 c = nine_centre(n, i, j, kg);
+    f3 mp[9];
+    mapped9<P2, false, SD>(m, sp, n, c, i, j, k, mp);
+#pragma unroll
+    for (int a9 = 0; a9 < 9; a9++) mp[a9] = clamp3_ordered(mp[a9], lo, hi);
+    const Field s1[1] = { make_field(src, nbi, nbj, src_nk, src_koff) };
+    float sum[1] = { 0.f }, value[1], w[1] = { 0.125f * coeff };
+    blend9_gather_w<P2, false, 1, false>(s1, sp, n.org, mp, w, sum, value);
+    const float v = coeff * value[0];
+    const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
+    dst[id] = before[id] + (float)(0.5 * (double)sum[0] + 0.5 * (double)v);
+}
+
 // ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
 template <bool P2, bool PT, int SD, int NF>
 __global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a,
@@ -1055,6 +1093,44 @@ BQ_ENTRY(gpu_compensate_error_velocity, (float *u, float *v, float *w, float *du
     compensate_comp(u, du, u_src, forward_x, forward_y, forward_z, sp, g, 1, 0, 0, is_point);
     compensate_comp(v, dv, v_src, forward_x, forward_y, forward_z, sp, g, 0, 1, 0, is_point);
     compensate_comp(w, dw, w_src, forward_x, forward_y, forward_z, sp, g, 0, 0, 1, is_point);
+}
+
+BQ_ENTRY(gpu_accumulate_wall_fixup, (const float *src, int src_koff, int src_nk, const float *before, float *dst,
+                               const float *mx, const float *my, const float *mz,
+                               float h, int ni, int nj, int nk, int axis, float coeff,
+                               const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl),
+         (src, src_koff, src_nk, before, dst, mx, my, mz, h, ni, nj, nk, axis, coeff, xlist, nxl, ylist, nyl, zlist, nzl))
+{
+    BQ_ENTER("gpu_accumulate_wall_fixup", src, before, dst, mx, my, mz)
+    BQ_REQUIRE(axis >= -1 && axis <= 2 && src_nk >= 1 && nxl >= 0 && nyl >= 0 && nzl >= 0 && nxl <= 8 && nyl <= 8 && nzl <= 8 &&
+               (nxl == 0 || xlist) && (nyl == 0 || ylist) && (nzl == 0 || zlist), "gpu_accumulate_wall_fixup");
+    const int dx = axis == 0, dy = axis == 1, dz = axis == 2;
+    if (4.0 * (double)(ni + dx) * (double)(nj + dy) * (double)src_nk >= 2147483648.0) {
+        latch(FL_ERR_BAD_ARGUMENT, "gpu_accumulate_wall_fixup", "wall-sheet copy larger than 2 GiB"); return;
+    }
+    int planes;
+    Spacing sp = make_spacing(h); Grid g = mk_grid_win(ni, nj, nk, dz, &planes);
+    if (planes <= 0) return;
+    const int kw1 = g.kw0 + planes;
+    const int nbi = ni + dx, nbj = nj + dy;
+    hipStream_t st = rt().compute;
+    auto launch = [&](int face_axis, int face_index, int na, int nb) {
+        const dim3 grid((na + 63) / 64, (nb + 3) / 4, 1);
+        const bool structured = sp.pow2 && rt().opt_structured_maps;
+        const int sd = stag_axis(dx, dy, dz);
+#define BQ_WF(P2V, SDV) wall_fixup_kernel<P2V, SDV><<<grid, kBlock, 0, st>>>(src, src_nk, src_koff, before, dst, mx, my, mz, sp, g, dx, dy, dz, coeff, face_axis, face_index, kw1)
+        if (structured) { switch (sd) { case 0: BQ_WF(true, 0); break; case 1: BQ_WF(true, 1); break; case 2: BQ_WF(true, 2); break; default: BQ_WF(true, 3); break; } }
+        else if (sp.pow2) BQ_WF(true, -1);
+        else BQ_WF(false, -1);
+#undef BQ_WF
+        BQ_LAUNCH_CHECK("wall_fixup_kernel");
+    };
+    for (int a = 0; a < nxl; a++) launch(0, xlist[a], nbj, planes);
+    for (int a = 0; a < nyl; a++) launch(1, ylist[a], nbi, planes);
+    for (int a = 0; a < nzl; a++) {
+        const int kl = zlist[a] - g.koff;
+        if (kl >= g.kw0 && kl < kw1) launch(2, zlist[a], nbi, nbj);
+    }
 }
 
 BQ_ENTRY(gpu_compensate_error_field, (float *u, float *du, float *u_src,

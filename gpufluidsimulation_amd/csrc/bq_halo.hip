@@ -12,6 +12,7 @@
 #include "bq_host.h"
 
 #include <dlfcn.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 
@@ -43,8 +44,26 @@ static int g_rank = 0, g_nranks = 1;
 // optional host-side transport (fl_comm_set_custom): used instead of RCCL when set
 static fl_exchange_cb g_custom_exchange = nullptr;
 static fl_allreduce_cb g_custom_allreduce = nullptr;
-static hipEvent_t g_ev_ready = nullptr, g_ev_done = nullptr;
+// Every exchange gets its own (ready, done) event pair from a small ring: an exchange that is still in flight when the
+// next one is issued keeps its events (the ring is far longer than the number of exchanges a step ever overlaps).
+struct EvPair { hipEvent_t ready = nullptr, done = nullptr; };
+static constexpr int kEvRing = 16;
+static EvPair g_ev[kEvRing];
+static int g_ev_next = 0;
+static hipEvent_t g_ev_pending = nullptr;   // `done` of the newest exchange nobody has waited for yet (fl_halo_wait)
 static bool g_null_transport = false;       // fl_comm_set_null: exchanges and all-reduces are skipped (timing aid)
+static fl_p2p_cb g_custom_p2p = nullptr;
+
+static EvPair *next_events()
+{
+    EvPair &e = g_ev[g_ev_next];
+    g_ev_next = (g_ev_next + 1) % kEvRing;
+    if (!e.ready) {
+        if (!BQ_HIP(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming)) ||
+            !BQ_HIP(hipEventCreateWithFlags(&e.done, hipEventDisableTiming))) return nullptr;
+    }
+    return &e;
+}
 
 static bool load_rccl()
 {
@@ -144,15 +163,15 @@ int fl_comm_init(const void *id128, int rank, int nranks)
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     if (!BQ_NCCL(CommInitRank(&g_comm, nranks, id, rank))) return FL_ERR_COMM;
-    if (!g_ev_ready) { BQ_HIP(hipEventCreateWithFlags(&g_ev_ready, hipEventDisableTiming)); BQ_HIP(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming)); }
     return fl_last_error();
 }
 
 void fl_comm_destroy(void)
 {
     if (g_comm) { fl_sync(); g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
-    g_custom_exchange = nullptr; g_custom_allreduce = nullptr;
+    g_custom_exchange = nullptr; g_custom_allreduce = nullptr; g_custom_p2p = nullptr;
     g_null_transport = false;
+    g_ev_pending = nullptr;
     g_rank = 0; g_nranks = 1;
 }
 
@@ -199,8 +218,10 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
         return;
     }
     if (!g_comm) { latch(FL_ERR_COMM, "fl_halo_exchange", "no communicator (fl_comm_init)"); return; }
-    BQ_HIP(hipEventRecord(g_ev_ready, r.compute));
-    BQ_HIP(hipStreamWaitEvent(r.halo, g_ev_ready, 0));
+    EvPair *ev = next_events();
+    if (!ev) return;
+    BQ_HIP(hipEventRecord(ev->ready, r.compute));
+    BQ_HIP(hipStreamWaitEvent(r.halo, ev->ready, 0));
     const int lo = g_rank - 1, hi = g_rank + 1;
     if (!BQ_NCCL(GroupStart())) return;
     for (int f = 0; f < n; f++) {
@@ -218,8 +239,118 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
         }
     }
     if (!BQ_NCCL(GroupEnd())) return;
-    BQ_HIP(hipEventRecord(g_ev_done, r.halo));
-    if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, g_ev_done, 0));
+    BQ_HIP(hipEventRecord(ev->done, r.halo));
+    if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, ev->done, 0));
+    else g_ev_pending = ev->done;
+}
+
+} // extern "C"
+
+// ---- wall sheets (include/bimocq_gpu.h, section 4): box gather / scatter and point-to-point messages -------------
+namespace {
+constexpr int kBoxChunk = 16;
+struct BoxChunk {
+    int n;
+    int x0[kBoxChunk], y0[kBoxChunk], z0[kBoxChunk], wx[kBoxChunk], wy[kBoxChunk];
+    long long off[kBoxChunk + 1];       // element offset of each box inside this chunk's packed range
+};
+}
+
+// one thread per packed element; MODE 0: packed <- field, 1: field <- packed, 2: field <- NaN
+template <int MODE>
+__global__ __launch_bounds__(256) void box_copy_kernel(float *__restrict__ field, float *__restrict__ packed, BoxChunk c,
+                                                       int nbi, int nbj, int koff)
+{
+    const long long total = c.off[c.n];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        int b = 0;
+        while (b + 1 < c.n && t >= c.off[b + 1]) b++;
+        const long long e = t - c.off[b];
+        const int x = (int)(e % c.wx[b]);
+        const long long r = e / c.wx[b];
+        const int y = (int)(r % c.wy[b]), z = (int)(r / c.wy[b]);
+        const size_t id = (size_t)(c.x0[b] + x) + (size_t)nbi * ((size_t)(c.y0[b] + y) + (size_t)nbj * (size_t)(c.z0[b] + z - koff));
+        if (MODE == 0) packed[t] = field[id];
+        else if (MODE == 1) field[id] = packed[t];
+        else field[id] = __builtin_nanf("");
+    }
+}
+
+template <int MODE>
+static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed, const char *op)
+{
+    if (!ensure_ready(op)) return;
+    if (nboxes <= 0) return;
+    if (!field || !boxes || (MODE != 2 && !packed) || nbi < 1 || nbj < 1 || nk_field < 1) { latch(FL_ERR_BAD_ARGUMENT, op, "null pointer or bad dims"); return; }
+    long long base = 0;
+    for (int first = 0; first < nboxes; first += kBoxChunk) {
+        BoxChunk c;
+        c.n = 0; c.off[0] = 0;
+        for (int b = first; b < nboxes && c.n < kBoxChunk; b++) {
+            const fl_box &q = boxes[b];
+            if (q.x0 < 0 || q.y0 < 0 || q.z0 < koff || q.x1 > nbi || q.y1 > nbj || q.z1 > koff + nk_field || q.x1 < q.x0 || q.y1 < q.y0 || q.z1 < q.z0) {
+                latch(FL_ERR_BAD_ARGUMENT, op, "box outside the field"); return;
+            }
+            const long long vol = (long long)(q.x1 - q.x0) * (q.y1 - q.y0) * (q.z1 - q.z0);
+            if (vol == 0) continue;
+            c.x0[c.n] = q.x0; c.y0[c.n] = q.y0; c.z0[c.n] = q.z0; c.wx[c.n] = q.x1 - q.x0; c.wy[c.n] = q.y1 - q.y0;
+            c.off[c.n + 1] = c.off[c.n] + vol;
+            c.n++;
+        }
+        const long long total = c.off[c.n];
+        if (total == 0) continue;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        box_copy_kernel<MODE><<<blocks, 256, 0, rt().compute>>>(field, MODE == 2 ? nullptr : packed + base, c, nbi, nbj, koff);
+        if (!BQ_LAUNCH_CHECK("box_copy_kernel")) return;
+        base += total;
+    }
+}
+
+extern "C" {
+
+void fl_box_pack(const float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed)
+{
+    box_copy<0>(const_cast<float *>(field), nbi, nbj, nk_field, koff, boxes, nboxes, packed, "fl_box_pack");
+}
+
+void fl_box_unpack(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, const float *packed)
+{
+    if (packed) box_copy<1>(field, nbi, nbj, nk_field, koff, boxes, nboxes, const_cast<float *>(packed), "fl_box_unpack");
+    else        box_copy<2>(field, nbi, nbj, nk_field, koff, boxes, nboxes, nullptr, "fl_box_unpack");
+}
+
+void fl_comm_set_custom_p2p(fl_p2p_cb p2p) { g_custom_p2p = p2p; }
+
+void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
+                     float *const *recv, const size_t *recv_count)
+{
+    if (g_nranks <= 1 || n <= 0) return;
+    Runtime &r = rt();
+    if (!peers || !send || !send_count || !recv || !recv_count) { latch(FL_ERR_BAD_ARGUMENT, "fl_p2p_exchange", "null argument"); return; }
+    for (int m = 0; m < n; m++)
+        if (peers[m] < 0 || peers[m] >= g_nranks || peers[m] == g_rank || (send_count[m] && !send[m]) || (recv_count[m] && !recv[m])) {
+            latch(FL_ERR_BAD_ARGUMENT, "fl_p2p_exchange", "bad peer or null buffer"); return;
+        }
+    if (g_null_transport) return;
+    if (g_custom_exchange || g_custom_p2p) {
+        if (!g_custom_p2p) { latch(FL_ERR_COMM, "fl_p2p_exchange", "the custom transport has no point-to-point callback (fl_comm_set_custom_p2p)"); return; }
+        BQ_HIP(hipStreamSynchronize(r.compute));
+        g_custom_p2p(n, peers, send, send_count, recv, recv_count);
+        return;
+    }
+    if (!g_comm) { latch(FL_ERR_COMM, "fl_p2p_exchange", "no communicator (fl_comm_init)"); return; }
+    EvPair *ev = next_events();
+    if (!ev) return;
+    BQ_HIP(hipEventRecord(ev->ready, r.compute));
+    BQ_HIP(hipStreamWaitEvent(r.halo, ev->ready, 0));
+    if (!BQ_NCCL(GroupStart())) return;
+    for (int m = 0; m < n; m++) {
+        if (send_count[m]) BQ_NCCL(Send(send[m], send_count[m], ncclFloat, peers[m], g_comm, r.halo));
+        if (recv_count[m]) BQ_NCCL(Recv(recv[m], recv_count[m], ncclFloat, peers[m], g_comm, r.halo));
+    }
+    if (!BQ_NCCL(GroupEnd())) return;
+    BQ_HIP(hipEventRecord(ev->done, r.halo));
+    BQ_HIP(hipStreamWaitEvent(r.compute, ev->done, 0));
 }
 
 // Exercises every RCCL entry point this file binds on a throw-away ONE-rank communicator: unique id,
@@ -265,8 +396,9 @@ int fl_comm_selftest(void)
 
 void fl_halo_wait(void)
 {
-    if (g_nranks <= 1 || !g_ev_done) return;
-    BQ_HIP(hipStreamWaitEvent(rt().compute, g_ev_done, 0));
+    if (g_nranks <= 1 || !g_ev_pending) return;
+    BQ_HIP(hipStreamWaitEvent(rt().compute, g_ev_pending, 0));
+    g_ev_pending = nullptr;
 }
 
 } // extern "C"

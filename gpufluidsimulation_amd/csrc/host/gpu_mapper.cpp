@@ -1,5 +1,6 @@
 // gpu_mapper.cpp -- see gpu_mapper.hpp.  Reference: src/bimocq3D/GPU_Advection.h:110-627.
 #include "gpu_mapper.hpp"
+#include <algorithm>
 #include <cstdio>
 
 #include <cstdlib>
@@ -58,6 +59,129 @@ void gpuMapper::require(std::initializer_list<DeviceField *> fields, int depth)
     fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, slab.G, 1);
     for (DeviceField *f : fields)
         if (always || f->valid < depth) f->valid = slab.G;
+}
+
+const WallPlan &gpuMapper::wallPlan(FieldKind kind, int Dback, int need)
+{
+    const auto key = std::make_tuple((int)kind, Dback, need);
+    auto it = wall_plans_.find(key);
+    if (it == wall_plans_.end())
+        it = wall_plans_.emplace(key, make_wall_plan(g.ni, g.nj, slab.nkg, kind == FIELD_U, kind == FIELD_V, kind == FIELD_W,
+                                                     slab.rank, slab.nranks, slab.G, Dback, need)).first;
+    return it->second;
+}
+
+void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx, DeviceField &by, DeviceField &bz,
+                          int Dback, int need, float coeff, int out_valid)
+{
+    if (!slab.on || slab.nranks <= 1 || items.size() == 0 || items.size() > 3) return;
+    const int nr = slab.nranks;
+    const WallPlan *plans[3] = { nullptr, nullptr, nullptr };
+    const WallItem *its[3] = { nullptr, nullptr, nullptr };
+    int n = 0;
+    for (const WallItem &it : items) { its[n] = &it; plans[n] = &wallPlan(it.kind, Dback, need); n++; }
+    // the assembled copies: the global planes [k0, k1) of the sampled field, NaN wherever nothing has been placed
+    size_t local_max = 0;
+    std::vector<size_t> send_off((size_t)nr + 1, 0), recv_off((size_t)nr + 1, 0);
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *plans[a];
+        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
+        const FieldKind kind = its[a]->kind;
+        const size_t plane = (size_t)(g.ni + (kind == FIELD_U)) * (size_t)(g.nj + (kind == FIELD_V));
+        Shadow &sh = wall_shadow_[a];
+        const size_t count = plane * (size_t)(p.shadow_k1 - p.shadow_k0);
+        if (sh.buf.count() < count || sh.plane != plane || sh.k0 != p.shadow_k0 || sh.k1 != p.shadow_k1) {
+            if (sh.buf.count() < count && !sh.buf.alloc(count)) return;
+            fl_memset(sh.buf.get(), 0xFF, sh.buf.bytes());           // all-ones bytes: a NaN in every float
+            sh.k0 = p.shadow_k0; sh.k1 = p.shadow_k1; sh.plane = plane;
+        }
+        local_max = std::max(local_max, WallPlan::volume(p.local));
+        for (int q = 0; q < nr; q++) {
+            send_off[(size_t)q + 1] += WallPlan::volume(p.send[(size_t)q]);
+            recv_off[(size_t)q + 1] += WallPlan::volume(p.recv[(size_t)q]);
+        }
+    }
+    for (int q = 0; q < nr; q++) { send_off[(size_t)q + 1] += send_off[(size_t)q]; recv_off[(size_t)q + 1] += recv_off[(size_t)q]; }
+    const size_t send_total = send_off[(size_t)nr], recv_total = recv_off[(size_t)nr];
+    if ((wall_send_.count() < send_total && !wall_send_.alloc(send_total + send_total / 8 + 64)) ||
+        (wall_recv_.count() < recv_total && !wall_recv_.alloc(recv_total + recv_total / 8 + 64)) ||
+        (wall_local_.count() < local_max && !wall_local_.alloc(local_max + local_max / 8 + 64))) return;
+    // gather: my own pieces straight into the copies, the pieces other ranks need into the send buffer (per peer:
+    // item after item, the order both sides derive from the same plan)
+    std::vector<size_t> cur(send_off.begin(), send_off.end() - 1);
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *plans[a];
+        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
+        const FieldKind kind = its[a]->kind;
+        const int nbi = g.ni + (kind == FIELD_U), nbj = g.nj + (kind == FIELD_V), nkf = g.nk + (kind == FIELD_W);
+        const float *src = its[a]->src->get();
+        Shadow &sh = wall_shadow_[a];
+        if (!p.local.empty()) {
+            fl_box_pack(src, nbi, nbj, nkf, slab.koff(), p.local.data(), (int)p.local.size(), wall_local_.get());
+            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size(), wall_local_.get());
+        }
+        for (int q = 0; q < nr; q++) {
+            const std::vector<fl_box> &v = p.send[(size_t)q];
+            if (v.empty()) continue;
+            fl_box_pack(src, nbi, nbj, nkf, slab.koff(), v.data(), (int)v.size(), wall_send_.get() + cur[(size_t)q]);
+            cur[(size_t)q] += WallPlan::volume(v);
+        }
+    }
+    // one group of point-to-point messages with every rank that owes me planes or that I owe planes
+    {
+        std::vector<int> peers; std::vector<float *> sp, rp; std::vector<size_t> sc, rc;
+        for (int q = 0; q < nr; q++) {
+            const size_t ns = send_off[(size_t)q + 1] - send_off[(size_t)q], nrv = recv_off[(size_t)q + 1] - recv_off[(size_t)q];
+            if (q == slab.rank || (ns == 0 && nrv == 0)) continue;
+            peers.push_back(q); sp.push_back(wall_send_.get() + send_off[(size_t)q]); sc.push_back(ns);
+            rp.push_back(wall_recv_.get() + recv_off[(size_t)q]); rc.push_back(nrv);
+        }
+        if (!peers.empty()) fl_p2p_exchange((int)peers.size(), peers.data(), sp.data(), sc.data(), rp.data(), rc.data());
+        wall_bytes_moved += (long long)recv_total * 4;
+    }
+    // scatter what arrived, re-evaluate the wall layers on the planes the stage produced, then blank the copies again
+    // (a cell the plan did not foresee must read NaN next time as well, never stale data)
+    const bool can_window = overlap_exchanges && fuse_housekeeping && fl_get_option(FL_OPT_FUSED_HOUSEKEEPING) >= 0;
+    const int ov = out_valid < 0 ? 0 : (out_valid > slab.G ? slab.G : out_valid);
+    const int w0 = can_window ? slab.G - ov : 0, w1 = can_window ? g.nk - slab.G + (ov > 1 ? ov : 1) : g.nk;
+    std::vector<size_t> rcur(recv_off.begin(), recv_off.end() - 1);
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *plans[a];
+        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
+        const FieldKind kind = its[a]->kind;
+        const int nbi = g.ni + (kind == FIELD_U), nbj = g.nj + (kind == FIELD_V);
+        Shadow &sh = wall_shadow_[a];
+        for (int q = 0; q < nr; q++) {
+            const std::vector<fl_box> &v = p.recv[(size_t)q];
+            if (v.empty()) continue;
+            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, v.data(), (int)v.size(), wall_recv_.get() + rcur[(size_t)q]);
+            rcur[(size_t)q] += WallPlan::volume(v);
+        }
+    }
+    const bool windowed = can_window && (w0 > 0 || w1 < g.nk) && fl_set_plane_window(w0, w1) == 1;
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *plans[a];
+        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
+        const FieldKind kind = its[a]->kind;
+        const int axis = kind == FIELD_U ? 0 : kind == FIELD_V ? 1 : kind == FIELD_W ? 2 : -1;
+        Shadow &sh = wall_shadow_[a];
+        gpu_accumulate_wall_fixup(sh.buf.get(), sh.k0, sh.k1 - sh.k0, its[a]->before->get(), its[a]->dst->get(),
+                                  bx.get(), by.get(), bz.get(), g.h, g.ni, g.nj, g.nk, axis, coeff,
+                                  p.xlist.data(), (int)p.xlist.size(), p.ylist.data(), (int)p.ylist.size(),
+                                  p.zlist.data(), (int)p.zlist.size());
+    }
+    if (windowed) fl_set_plane_window(-1, -1);
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *plans[a];
+        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
+        const FieldKind kind = its[a]->kind;
+        const int nbi = g.ni + (kind == FIELD_U), nbj = g.nj + (kind == FIELD_V);
+        Shadow &sh = wall_shadow_[a];
+        if (!p.local.empty()) fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size(), nullptr);
+        for (int q = 0; q < nr; q++)
+            if (!p.recv[(size_t)q].empty())
+                fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.recv[(size_t)q].data(), (int)p.recv[(size_t)q].size(), nullptr);
+    }
 }
 
 void gpuMapper::startEventRecord()

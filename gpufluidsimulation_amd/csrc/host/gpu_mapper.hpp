@@ -12,8 +12,11 @@
 #include <cstdlib>
 #include <cstddef>
 #include <initializer_list>
+#include <map>
+#include <tuple>
 #include <vector>
 #include "bimocq_gpu.h"
+#include "wall_sheets.hpp"
 
 namespace bqhost {
 
@@ -208,6 +211,15 @@ public:
         fl_set_plane_window(k1, w1); op();
         fl_set_plane_window(-1, -1);
     }
+    // z-slab ranks, reference-faithful DMC border (wall_sheets.hpp): re-evaluate the wall layers of stage 3 of the
+    // compensation (dst = before + blend9(coeff * src(psi_back(x)))) from a copy of `src` assembled out of the sheets
+    // the border taps can touch, fetched from the ranks that own them.  Call right after the stage-3 operator, with
+    // the out_valid that operator was given.  `need`: ghost planes of src known to be correct (the operator's
+    // requirement).  No-op on one rank.
+    struct WallItem { DeviceField *src, *before, *dst; FieldKind kind; };
+    void wallFixup(std::initializer_list<WallItem> items, DeviceField &bx, DeviceField &by, DeviceField &bz,
+                   int Dback, int need, float coeff, int out_valid);
+    long long wall_bytes_moved = 0;         // floats received through wallFixup so far x 4 (statistics)
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
     static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes
@@ -280,6 +292,12 @@ public:
 private:
     bool ok_ = false;
     void *ev_start_ = nullptr, *ev_stop_ = nullptr;
+    // wall sheets: plans per (field kind, Dback, need); assembled copies (one per item of a batch), staging buffers
+    std::map<std::tuple<int, int, int>, WallPlan> wall_plans_;
+    struct Shadow { DeviceField buf; int k0 = 0, k1 = 0; size_t plane = 0; };
+    Shadow wall_shadow_[3];
+    DeviceField wall_send_, wall_recv_, wall_local_;
+    const WallPlan &wallPlan(FieldKind kind, int Dback, int need);
 };
 
 } // namespace bqhost

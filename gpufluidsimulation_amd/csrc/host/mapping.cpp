@@ -157,9 +157,14 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
         gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
     }, std::min({ gpuMapper::minValid({ &U, &V, &W }), gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
                   gs.validAfter({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback)) - reachField(m.Dback) }));
-    gs.producedAll({ &U, &V, &W }, std::min({ gpuMapper::minValid({ &U, &V, &W }),
-                                              gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
-                                              gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) }));
+    const int stage3_valid = std::min({ gpuMapper::minValid({ &U, &V, &W }),
+                                        gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                                        gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) });
+    // z-slab ranks, zeroed map border (Q13): the wall layers sample the error far outside the slab -> wall_sheets.hpp
+    if (!keepDmcBorder)
+        gs.wallFixup({ { &gs.u_src, &Ui, &U, FIELD_U }, { &gs.v_src, &Vi, &V, FIELD_V }, { &gs.w_src, &Wi, &W, FIELD_W } },
+                     m.BackwardX, m.BackwardY, m.BackwardZ, m.Dback, reachField(m.Dback), -0.5f, stage3_valid);
+    gs.producedAll({ &U, &V, &W }, stage3_valid);
     trace_point("v.stage3");
     // stage 4: limiter against the 3x3x3 box of the uncompensated field
     gs.require({ &Ui, &Vi, &Wi }, 1);
@@ -216,8 +221,12 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
     gs.require({ &gs.u_src }, reachField(m.Dback));
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
     gs.accumulateField(gs.u_src, f, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
-    gs.produced(f, std::min({ f.valid, gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
-                              gs.u_src.valid - reachField(m.Dback) }));
+    const int stage3_valid = std::min({ f.valid, gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
+                                        gs.u_src.valid - reachField(m.Dback) });
+    if (!keepDmcBorder)
+        gs.wallFixup({ { &gs.u_src, &fInit, &f, FIELD_S } }, m.BackwardX, m.BackwardY, m.BackwardZ, m.Dback, reachField(m.Dback), -0.5f,
+                     DeviceField::kAlwaysValid);           // (this form runs the operator on every local plane)
+    gs.produced(f, stage3_valid);
     gs.u_src.plane = saved_plane;
     gs.require({ &fInit }, 1);
     gpu_clamp_extrema_box(fInit, f, ni, nj, nk);
@@ -281,8 +290,13 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
         gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
     }, std::min({ f1.valid, f2.valid, gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
                   gs.validAfter({ &e1, &e2 }, reachField(m.Dback)) - reachField(m.Dback) }));
-    gs.produced(f1, std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) }));
-    gs.produced(f2, std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) }));
+    const int s3v1 = std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) });
+    const int s3v2 = std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) });
+    if (!keepDmcBorder)
+        gs.wallFixup({ { &e1, &f1Init, &f1, FIELD_S }, { &e2, &f2Init, &f2, FIELD_S } }, m.BackwardX, m.BackwardY, m.BackwardZ,
+                     m.Dback, reachField(m.Dback), -0.5f, std::min(s3v1, s3v2));
+    gs.produced(f1, s3v1);
+    gs.produced(f2, s3v2);
     e1.plane = plane1; e2.plane = plane2;
     gs.require({ &f1Init, &f2Init }, 1);
     gpu_clamp_extrema_box(f1Init, f1, ni, nj, nk);

@@ -14,6 +14,8 @@ import numpy as np
 EXCHANGE_CB = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                           C.c_int, C.c_int, C.c_int)
 ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int)
+P2P_CB = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 
 
 def init_rccl(lib, dist):
@@ -46,10 +48,15 @@ class HostStagedTransport:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self._ex = EXCHANGE_CB(self._exchange)
         self._ar = ALLREDUCE_CB(self._allreduce)
+        self._pp = P2P_CB(self._p2p)
         lib.fl_comm_set_custom.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.fl_comm_set_custom(self.rank, self.world, C.cast(self._ex, C.c_void_p), C.cast(self._ar, C.c_void_p))
+        lib.fl_comm_set_custom_p2p.argtypes = [C.c_void_p]
+        lib.fl_comm_set_custom_p2p(C.cast(self._pp, C.c_void_p))
         self.exchanges = 0
         self.planes_moved = 0
+        self.p2p_messages = 0
+        self.p2p_floats = 0
         self.trace = None                       # set to [] to record (fields, depth, bytes sent per neighbour) per exchange
 
     def _get(self, ptr, offset_elems, count):
@@ -90,6 +97,27 @@ class HostStagedTransport:
         self.planes_moved += n * depth
         if self.trace is not None:
             self.trace.append((n, depth, 4 * sum(plane_elems[f] * depth for f in range(n))))
+
+    def _p2p(self, n, peers, send, send_count, recv, recv_count):
+        """fl_p2p_exchange: message m goes to / comes from rank peers[m] (wall sheets; any pair of ranks)"""
+        torch, dist = self.torch, self.dist
+        reqs, recvs, keep = [], [], []
+        for m in range(n):
+            peer, ns, nr = peers[m], send_count[m], recv_count[m]
+            if ns:
+                t = torch.from_numpy(self._get(send[m], 0, ns))
+                keep.append(t)
+                reqs.append(dist.isend(t, peer, group=self.group, tag=1000))
+            if nr:
+                r = torch.empty(nr, dtype=torch.float32)
+                reqs.append(dist.irecv(r, peer, group=self.group, tag=1000))
+                recvs.append((recv[m], r))
+        for r in reqs:
+            r.wait()
+        for ptr, r in recvs:
+            self._put(ptr, 0, r.numpy())
+            self.p2p_floats += r.numel()
+        self.p2p_messages += n
 
     def _allreduce(self, host, count, is_double, is_max):
         torch, dist = self.torch, self.dist

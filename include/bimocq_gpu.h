@@ -423,6 +423,39 @@ void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb exchange, fl_allred
  * of the z-slab path on one GPU; results near the slab boundary are meaningless) */
 void fl_comm_set_null(int rank, int nranks);
 
+/* ---- wall sheets: what makes z-slab ranks reproduce ONE GPU bit for bit in the reference-faithful mode -------------
+ * The reference zeroes the border nodes of the backward map in every DMC update (GPU_Advection.h:464-468, the protecting
+ * pre-copy is commented out at :335-337).  Stage 3 of gpu_compensate_* (cumulate_kernel with the backward map,
+ * GPU_kernel.cu:659-661) interpolates towards those zeros on the first and last node layer of its index window: such a
+ * tap lands at 1/4, 1/2 or 3/4 (or a product of those) of its position -- near the wall on one GPU, arbitrarily far
+ * along z for a slab rank.  The cells those taps can touch form a few thin sheets; a slab rank collects them from the
+ * ranks that own them into a copy of the sampled field that spans the needed global planes, and re-evaluates the wall
+ * layers from that copy.  Pieces (host computes WHICH boxes; csrc/host/wall_sheets.*): */
+typedef struct fl_box { int x0, x1, y0, y1, z0, z1; } fl_box;   /* half-open, GLOBAL indices of the field's buffer */
+/* packed <- the boxes of `field`, one after the other, x fastest.  `field` holds the global planes [koff, koff + nk_field)
+ * of a buffer with rows of nbi and planes of nbi*nbj floats; every box must lie inside them.  `boxes` is a HOST array. */
+void fl_box_pack(const float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed);
+/* the inverse, into `field`; packed == NULL fills the boxes with NaN (a cell the plan missed must not pass for data) */
+void fl_box_unpack(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, const float *packed);
+/* n point-to-point messages in one RCCL group on the halo stream: send[m] (send_count[m] floats) goes to rank peers[m],
+ * recv[m] (recv_count[m] floats) comes from it; a count may be 0.  Ordered after the compute work queued so far; the
+ * compute stream waits for the transfers.  Peers need not be z-neighbours (xGMI is a full mesh: one link per pair). */
+void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
+                     float *const *recv, const size_t *recv_count);
+/* host-side transport for fl_p2p_exchange (see fl_comm_set_custom; called with the compute stream idle) */
+typedef void (*fl_p2p_cb)(int n, const int *peers, float *const *send, const size_t *send_count,
+                          float *const *recv, const size_t *recv_count);
+void fl_comm_set_custom_p2p(fl_p2p_cb p2p);
+/* cumulate_kernel's expression (GPU_kernel.cu:376-436) on the nodes of its index window with i in xlist, j in ylist or
+ * GLOBAL plane in zlist (host arrays, at most 8 entries each), the source read from `src`, which holds the global
+ * planes [src_koff, src_koff + src_nk) of the sampled field:  dst = before + blend9(coeff * src(map(x))), `before`
+ * being dst's value ahead of the stage (gpu_compensate_*'s stage-2 copy).  axis: -1 scalar, 0/1/2 = u/v/w buffers.
+ * The maps and before/dst are local slab buffers (slab context, plane window honoured). */
+void gpu_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const float *before, float *dst,
+                               const float *mx, const float *my, const float *mz,
+                               float h, int ni, int nj, int nk, int axis, float coeff,
+                               const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,24 @@ static inline float sample(const float *b, int nx, int ny, int nz, float h, f3 o
                    fx, fy, fz);
 }
 
+/* the same for a buffer that holds the global planes [koff, koff + nz) whatever the slab context says (the wall-sheet
+ * copy a z-slab rank assembles for the border nodes of the compensation, orc_accumulate_wall_fixup) */
+static inline float sample_k(const float *b, int nx, int ny, int nz, int koff, float h, f3 off, f3 pos)
+{
+    float sx = pos.x - off.x, sy = pos.y - off.y, sz = pos.z - off.z;
+    float qx = sx / h, qy = sy / h, qz = sz / h;
+    int i = (int)floorf(qx), j = (int)floorf(qy), k = (int)floorf(qz);
+    float fx = qx - (float)i, fy = qy - (float)j, fz = qz - (float)k;
+    long sj = nx, sk = (long)nx * ny, count = (long)nx * ny * nz;
+    long base = (long)i + sj * j + sk * (k - koff);
+    if (base < 0) base = count;
+    return trilerp(ld(b, base, count),           ld(b, base + 1, count),
+                   ld(b, base + sj, count),      ld(b, base + sj + 1, count),
+                   ld(b, base + sk, count),      ld(b, base + sk + 1, count),
+                   ld(b, base + sk + sj, count), ld(b, base + sk + sj + 1, count),
+                   fx, fy, fz);
+}
+
 float orc_sample(const float *b, int nx, int ny, int nz, float h,
                  float ox, float oy, float oz, float px, float py, float pz)
 {
@@ -365,6 +383,45 @@ static void cumulate_comp(const float *src, float *dst, map3 m,
                 float value = coeff * sample(src, n.nbi, n.nbj, n.nbk, h, n.origin, mp);
                 sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
                 dst[IDX3(i, j, k, n.nbi, n.nbj)] += sum;
+            }
+}
+
+/* z-slab ranks, reference-faithful DMC border (GPU_Advection.h:464-468): the border nodes of the backward
+ * map are zero, so the taps of the first and last node layer of cumulate_kernel's window that interpolate towards such
+ * a node land at a fraction (1/4, 1/2, 3/4 or a product of those) of their position -- arbitrarily far along z.  A slab
+ * rank assembles the cells those taps can touch in `src` (global planes [src_koff, src_koff + src_nk), same rows as the
+ * local buffer) and re-evaluates exactly the nodes (i, j, kg) of the window with
+ *     i in {xlist}  or  j in {ylist}  or  kg in {zlist}   (wall indices, lists of nx/ny/nz entries)
+ * as dst = before + blend9(coeff * src(map(x))): the expression of cumulate_comp with `before` = dst's value ahead of it.
+ * Planes: the slab context's, cut to the plane window. */
+void orc_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const float *before, float *dst,
+                               const float *mx, const float *my, const float *mz,
+                               float h, int ni, int nj, int nk, int axis, float coeff,
+                               const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl)
+{
+    map3 m = { mx, my, mz };
+    const int dx = axis == 0, dy = axis == 1, dz = axis == 2;
+    nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, 0);
+    f3 lo = mk3(0.f, 0.f, 0.f), hi = mk3(h * (float)ni, h * (float)nj, h * (float)NKG(nk));
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = KLO(2 + dz); k < KHI(NKG(nk) + dz - 2, n.nbk); k++)
+        for (int j = 2 + dy; j < n.nbj - 2; j++)
+            for (int i = 2 + dx; i < n.nbi - 2; i++) {
+                int hit = 0;
+                for (int a = 0; a < nxl; a++) hit |= xlist[a] == i;
+                for (int a = 0; a < nyl; a++) hit |= ylist[a] == j;
+                for (int a = 0; a < nzl; a++) hit |= zlist[a] == k + KOFF;
+                if (!hit) continue;
+                float sum = 0.f;
+                for (int ii = 0; ii < n.evals; ii++) {
+                    f3 mp = clamp3(map_at(m, ni, nj, nk, h, nine_pos(&n, h, i, j, k, ii)), lo, hi);
+                    sum += n.weight * coeff * sample_k(src, n.nbi, n.nbj, src_nk, src_koff, h, n.origin, mp);
+                }
+                f3 mp = clamp3(map_at(m, ni, nj, nk, h, nine_pos(&n, h, i, j, k, -1)), lo, hi);
+                float value = coeff * sample_k(src, n.nbi, n.nbj, src_nk, src_koff, h, n.origin, mp);
+                sum = (float)(0.5 * (double)sum + 0.5 * (double)value);
+                long id = IDX3(i, j, k, n.nbi, n.nbj);
+                dst[id] = before[id] + sum;
             }
 }
 

@@ -123,6 +123,13 @@ void orc_divergence(const float *u, const float *v, const float *w, float *div,
                     int ni, int nj, int nk, float halfrdx);
 /* restrict every operator to the local planes [k0, k1) (k0 < 0: off); nk_cells = local cell planes */
 void orc_set_plane_window(int k0, int k1, int nk_cells);
+/* z-slab ranks: cumulate_kernel's expression on the wall layers of its window, with the source read from an assembled copy
+ * that holds the global planes [src_koff, src_koff + src_nk): dst = before + blend9(coeff * src(map(x))) on the window nodes
+ * with i in xlist, j in ylist or GLOBAL plane in zlist (bimocq_oracle.c) */
+void orc_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const float *before, float *dst,
+                               const float *mx, const float *my, const float *mz,
+                               float h, int ni, int nj, int nk, int axis, float coeff,
+                               const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl);
 void orc_jacobi_sweep(const float *p, const float *div, float *out,
                       int ni, int nj, int nk, float alpha, float beta);
 /* ---- fp64 multigrid-CG projection (mgcg_oracle.c; GPU_kernel.cu:1420-1815) ---- */

@@ -183,6 +183,42 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
 }
 void fl_halo_wait(void) {}
 
+/* ---- wall sheets (include/bimocq_gpu.h, section 4) on host memory ---- */
+static fl_p2p_cb c_p2p;
+void fl_comm_set_custom_p2p(fl_p2p_cb p2p) { c_p2p = p2p; }
+void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
+                     float *const *recv, const size_t *recv_count)
+{
+    if (c_nranks <= 1 || n <= 0) return;
+    if (!c_p2p) { latch(FL_ERR_COMM, "fl_p2p_exchange: no transport"); return; }
+    c_p2p(n, peers, send, send_count, recv, recv_count);
+}
+static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed, int mode)
+{
+    size_t t = 0;
+    for (int b = 0; b < nboxes; b++) {
+        const fl_box q = boxes[b];
+        if (q.x0 < 0 || q.y0 < 0 || q.z0 < koff || q.x1 > nbi || q.y1 > nbj || q.z1 > koff + nk_field) { latch(FL_ERR_BAD_ARGUMENT, "fl_box_*: box outside the field"); return; }
+        for (int z = q.z0; z < q.z1; z++)
+            for (int y = q.y0; y < q.y1; y++)
+                for (int x = q.x0; x < q.x1; x++, t++) {
+                    size_t id = (size_t)x + (size_t)nbi * ((size_t)y + (size_t)nbj * (size_t)(z - koff));
+                    if (mode == 0) packed[t] = field[id];
+                    else if (mode == 1) field[id] = packed[t];
+                    else field[id] = NAN;
+                }
+    }
+}
+void fl_box_pack(const float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed)
+{ box_copy((float *)field, nbi, nbj, nk_field, koff, boxes, nboxes, packed, 0); }
+void fl_box_unpack(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, const float *packed)
+{ box_copy(field, nbi, nbj, nk_field, koff, boxes, nboxes, (float *)packed, packed ? 1 : 2); }
+void gpu_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const float *before, float *dst,
+                               const float *mx, const float *my, const float *mz,
+                               float h, int ni, int nj, int nk, int axis, float coeff,
+                               const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl)
+{ orc_accumulate_wall_fixup(src, src_koff, src_nk, before, dst, mx, my, mz, h, ni, nj, nk, axis, coeff, xlist, nxl, ylist, nyl, zlist, nzl); }
+
 void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk)
 {
     for (int k = 0; k < nk; k++)

@@ -44,10 +44,11 @@ KERNEL(k_cvt3264, D_MIX, B_CVT_32_64, S_MIX)
 KERNEL(k_floor32, D_F32, B_FLOOR32, S_F32)
 KERNEL(k_pkfma32, D_F64, B_PKFMA32, S_F64)
 
+static int g_wps = 2;
 template <class K> static void run(const char *name, K k, double clock_ghz, int cus)
 {
     float *out; hipMalloc(&out, 4);
-    const int blocks = cus * 2;                  // 2 blocks x 4 waves per CU = 2 waves per SIMD
+    const int blocks = cus * g_wps;              // g_wps blocks x 4 waves per CU = g_wps waves per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<<<blocks, 256>>>(out, 1.0f);
     hipDeviceSynchronize();
@@ -55,7 +56,7 @@ template <class K> static void run(const char *name, K k, double clock_ghz, int 
     k<<<blocks, 256>>>(out, 1.0f);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double instr_per_simd = 2.0 * ITER * 16;      // 2 waves per SIMD
+    const double instr_per_simd = (double)g_wps * ITER * 16;
     const double cycles = ms * 1e-3 * clock_ghz * 1e9;
     printf("%-14s %8.3f ms  %6.2f cycles per wave64 instruction\n", name, ms, cycles / instr_per_simd);
     hipFree(out);
@@ -66,6 +67,9 @@ int main()
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const double ghz = p.clockRate * 1e-6;
     printf("%s: %d CUs, %.2f GHz\n", p.name, p.multiProcessorCount, ghz);
+    for (int wps : {1, 2, 4, 6}) {
+    g_wps = wps;
+    printf("---- %d wave(s) per SIMD\n", wps);
     run("v_fma_f32", k_fma32, ghz, p.multiProcessorCount);
     run("v_mul_f32", k_mul32, ghz, p.multiProcessorCount);
     run("v_pk_fma_f32", k_pkfma32, ghz, p.multiProcessorCount);
@@ -75,5 +79,6 @@ int main()
     run("v_cvt_f64_f32", k_cvt6432, ghz, p.multiProcessorCount);
     run("v_cvt_f32_f64", k_cvt3264, ghz, p.multiProcessorCount);
     run("v_floor_f32", k_floor32, ghz, p.multiProcessorCount);
+    }
     return 0;
 }
