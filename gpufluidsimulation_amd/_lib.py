@@ -67,6 +67,7 @@ HIP_SIGS = {
     "fl_jacobi_kernel_name": (C.c_char_p, []),
     # 3. additive
     "gpu_init_maps": (None, [VP, VP, VP] + _G),
+    "gpu_maps_quarter_safe": (c_i, [VP, VP, VP] + _G),
     "gpu_max_abs3": (c_f, [VP, VP, VP, c_i, c_i, c_i]),
     "gpu_divergence": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f, c_f]),
@@ -115,6 +116,7 @@ FL_OPT_RESIDUAL_STRIDE, FL_OPT_SKIP_UNIT_BLEND, FL_OPT_JACOBI_VARIANT = 1, 2, 3
 FL_OPT_PROFILE_JACOBI, FL_OPT_JACOBI_KCHUNK, FL_OPT_JACOBI_ROWS, FL_OPT_STRUCTURED_MAPS = 4, 5, 6, 7
 FL_OPT_JACOBI_FUSE, FL_OPT_JACOBI_KCHUNK2, FL_OPT_MGCG_GRAPH, FL_OPT_FAST_LERP = 8, 9, 10, 11
 FL_OPT_FUSED_HOUSEKEEPING = 12
+FL_OPT_MAP_QUARTER_FP32 = 13
 
 
 class BimocqLibraryMissing(RuntimeError):

@@ -194,7 +194,8 @@ template <int NF> struct CumulateArgs { const float *src[NF]; float *dst[NF]; fl
 template <int NF> struct CompensateArgs { const float *src[NF]; float *init[NF]; float *err[NF]; };
 
 // ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
-template <bool P2, bool PT, int SD, int NF>
+// Q4: the caller vouches for the map's values (tile_value_ok): the quarter-weight map lerps run in fp32
+template <bool P2, bool PT, int SD, int NF, bool Q4 = false>
 __global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void advect_kernel(AdvectArgs<NF> a,
                                                      const float *bx, const float *by, const float *bz,
                                                      Spacing sp, Grid g, int dx, int dy, int dz, int fused)
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void advect_kernel(AdvectArgs
         const Field mf[3] = {back.x, back.y, back.z};
         stage_tiles<3>(mf, i0, j0, k, tile);
         if (!active) return;
-        map9_lds<SD == 1, SD == 2, SD == 3>(tile, mp);
+        map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
     } else {
         if (!active) return;
         mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 
 // ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
 // ID: the map is the identity map of gpu_init_maps (mx/my/mz are not read).
-template <bool P2, bool PT, int SD, int NF, bool ID>
+template <bool P2, bool PT, int SD, int NF, bool ID, bool Q4 = false>
 __global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void cumulate_kernel(CumulateArgs<NF> a,
                                                        const float *mx, const float *my, const float *mz,
                                                        Spacing sp, Grid g, int dx, int dy, int dz)
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void cumulate_kernel(Cumulate
         const Field mf[3] = {m.x, m.y, m.z};
         stage_tiles<3>(mf, i0, j0, k, tile);
         if (!active) return;
-        map9_lds<SD == 1, SD == 2, SD == 3>(tile, mp);
+        map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
     } else {
         if (!active) return;
         mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void wall_fixup_kernel(const float *src, int s
 }
 
 // ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
-template <bool P2, bool PT, int SD, int NF>
+template <bool P2, bool PT, int SD, int NF, bool Q4 = false>
 __global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a,
                                                          const float *mx, const float *my, const float *mz,
                                                          Spacing sp, Grid g, int dx, int dy, int dz, int fused)
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a
         const Field mf[3] = {m.x, m.y, m.z};
         stage_tiles<3>(mf, i0, j0, k, tile);
         if (!active) return;
-        map9_lds<SD == 1, SD == 2, SD == 3>(tile, mp);
+        map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
     } else {
         if (!active) return;
         mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
@@ -548,6 +549,17 @@ __global__ __launch_bounds__(256) void clamp_extrema_kernel(const float *field, 
     if (t < mn || t > mx) field_temp[id] = gather(src, c);
 }
 
+// ---- map-value scan behind FL_OPT_MAP_QUARTER_FP32 (bq_device.hip.h: tile_value_ok) ------------------------
+__global__ __launch_bounds__(256) void maps_quarter_safe_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                const float *__restrict__ z, size_t n, float lo, float hi,
+                                                                int *__restrict__ bad)
+{
+    bool ok = true;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (size_t)gridDim.x * 256)
+        ok = ok && tile_value_ok(x[id], lo, hi) && tile_value_ok(y[id], lo, hi) && tile_value_ok(z[id], lo, hi);
+    if (__any(!ok) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
 // ---- host-side dispatch helpers -----------------------------------------------------------
 // local dims + the library's slab context (fl_set_slab); single GPU: koff = 0, nkg = nk
 static inline Grid mk_grid(int ni, int nj, int nk)
@@ -579,6 +591,8 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
     double bytes = 4.0 * (double)(ni + 1) * (double)(nj + 1) * (double)(nk + 1);
     if (bytes >= 2147483648.0) { latch(FL_ERR_BAD_ARGUMENT, op, "field larger than 2 GiB"); return false; }
     if (nk + 1 > 65535) { latch(FL_ERR_BAD_ARGUMENT, op, "nk too large for grid.z"); return false; }
+    // locate() forms the flat index with signed 24-bit multiplies: plane stride and indices must stay below 2^23
+    if ((double)(ni + 1) * (double)(nj + 1) >= 8388608.0) { latch(FL_ERR_BAD_ARGUMENT, op, "plane larger than 2^23 elements"); return false; }
     return true;
 }
 
@@ -641,8 +655,14 @@ static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, con
     if (planes <= 0) return;
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
+    const bool q4 = rt().opt_map_quarter_fp32 != 0;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
-        advect_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
+        constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
+        constexpr int sd = decltype(SD)::value;
+        if constexpr (kStaged<p2, ptc, sd>) {
+            if (q4) { advect_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping); return; }
+        }
+        advect_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
     });
     BQ_LAUNCH_CHECK("advect_kernel");
 }
@@ -662,6 +682,7 @@ static void cumulate_multi(CumulateArgs<NF> a, const float *mx, const float *my,
         constexpr int sd = decltype(SD)::value;
         if constexpr (p2 && !ptc && sd >= 0) {
             if (identity) { cumulate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz); return; }
+            if (rt().opt_map_quarter_fp32) { cumulate_kernel<p2, ptc, sd, NF, false, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz); return; }
         }
         cumulate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz);
     });
@@ -676,8 +697,14 @@ static void compensate_multi(CompensateArgs<NF> a, const float *mx, const float 
     if (planes <= 0) return;
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
+    const bool q4 = rt().opt_map_quarter_fp32 != 0;
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
-        compensate_kernel<decltype(P2)::value, decltype(PT)::value, decltype(SD)::value, NF><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
+        constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
+        constexpr int sd = decltype(SD)::value;
+        if constexpr (kStaged<p2, ptc, sd>) {
+            if (q4) { compensate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping); return; }
+        }
+        compensate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
     });
     BQ_LAUNCH_CHECK("compensate_kernel");
 }
@@ -1132,6 +1159,39 @@ BQ_ENTRY(gpu_accumulate_wall_fixup, (const float *src, int src_koff, int src_nk,
         if (kl >= g.kw0 && kl < kw1) launch(2, zlist[a], nbi, nbj);
     }
 }
+
+#ifndef BQ_FAST_LERP
+// 1 when every value of the three map arrays is 0 or lies in [h/256, 1024 h] (tile_value_ok): the precondition of
+// FL_OPT_MAP_QUARTER_FP32.  Blocking (one 4-byte read-back); z-slab ranks agree on the answer (all-reduced).
+int gpu_maps_quarter_safe(const float *x, const float *y, const float *z, float h, int ni, int nj, int nk)
+{
+    if (!ensure_ready("gpu_maps_quarter_safe") || !dims_ok(ni, nj, nk, "gpu_maps_quarter_safe")) return 0;
+    if (!x || !y || !z || !(h > 0.f)) { latch(FL_ERR_BAD_ARGUMENT, "gpu_maps_quarter_safe", "null pointer or bad spacing"); return 0; }
+    int *dflag = (int *)scratch(64);
+    int *hflag = (int *)pinned(64);
+    if (!dflag || !hflag) return 0;
+    hipStream_t st = rt().compute;
+    if (!BQ_HIP(hipMemsetAsync(dflag, 0, 4, st))) return 0;
+    const size_t n = (size_t)ni * nj * nk;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    maps_quarter_safe_kernel<<<blocks, 256, 0, st>>>(x, y, z, n, h * 0.00390625f, h * 1024.f, dflag);
+    if (!BQ_LAUNCH_CHECK("maps_quarter_safe_kernel")) return 0;
+    float *fflag = (float *)(dflag + 4);
+    if (comm_ranks() > 1) {                         // every rank must take the same view of the shared ghost planes
+        // (int flag -> float so that the scalar all-reduce of the slab path can carry it)
+        int hbad = 0;
+        if (!BQ_HIP(hipMemcpyAsync(hflag, dflag, 4, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return 0;
+        hbad = *hflag;
+        float fb = hbad ? 1.f : 0.f;
+        if (!BQ_HIP(hipMemcpyAsync(fflag, &fb, 4, hipMemcpyHostToDevice, st))) return 0;
+        if (!comm_allreduce(fflag, 1, false, true, st)) return 0;
+        if (!BQ_HIP(hipMemcpyAsync(hflag, fflag, 4, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return 0;
+        return *(float *)hflag == 0.f ? 1 : 0;
+    }
+    if (!BQ_HIP(hipMemcpyAsync(hflag, dflag, 4, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return 0;
+    return *hflag == 0 ? 1 : 0;
+}
+#endif
 
 BQ_ENTRY(gpu_compensate_error_field, (float *u, float *du, float *u_src,
                                 float *forward_x, float *forward_y, float *forward_z,

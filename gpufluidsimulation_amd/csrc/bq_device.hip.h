@@ -161,12 +161,17 @@ __device__ __forceinline__ float lerp_const(float a, float b, float c, double om
 //   c = 0, 1/2, 3/4: (1 - c)*a is itself a float and the sum of two floats cannot do that -- always identical;
 //   c = 1/4: 3/4*a can sit on a float midpoint (results differ when 0 < |c*b| <= 2^-53 |3/4 a|) -- stays lerp_const.
 // tools/lerp_q_check.c compares both forms on 1.2e9 random and adversarial operand pairs per weight.
+// Q4: the caller vouches that the c = 1/4 lerps may take the fp32 form too (a tile whose values passed tile_value_ok):
+// with 3/4*a + 1/4*b exactly representable in double the contract's two roundings collapse into RN32 of the exact sum,
+// which is what fmaf(3/4, a, b/4) returns (b/4 is exact).  Exactness in double needs |a| and |b| within 2^25 of each
+// other or one of them zero: the 26 bits of 3a and the 24 of b then fit 53.
+template <bool Q4 = false>
 __device__ __forceinline__ float lerp_q(float a, float b, float c)
 {
 #ifdef BQ_FAST_LERP
     return __builtin_fmaf(c, b - a, a);
 #else
-    if (c == 0.25f) return lerp_const(a, b, c, 0.75);
+    if (c == 0.25f) return Q4 ? __builtin_fmaf(0.75f, a, 0.25f * b) : lerp_const(a, b, c, 0.75);
     if (c == 0.0f) return __builtin_fmaf(0.0f, b, a);     // 1*a + 0*b: a for a finite b, NaN otherwise -- one instruction
     return __builtin_fmaf(1.0f - c, a, c * b);
 #endif
@@ -208,7 +213,9 @@ __device__ __forceinline__ Cell locate(const Field &f, const Spacing &sp, f3 off
     Cell c;
     if (NONNEG) { c.fx = __builtin_amdgcn_fractf(qx); c.fy = __builtin_amdgcn_fractf(qy); c.fz = __builtin_amdgcn_fractf(qz); }
     else { c.fx = qx - (float)i; c.fy = qy - (float)j; c.fz = qz - (float)k; }
-    int idx = i + f.nx * j + f.nx * f.ny * (k - f.koff);
+    // row and plane strides times signed 24-bit indices (fields stay below 2^29 elements, dims_ok): two full-rate
+    // v_mad_i32_i24 instead of the 64-bit multiply-adds a plain `int` product turns into
+    int idx = i + __mul24(f.nx, j) + __mul24(f.nx * f.ny, k - f.koff);
     c.base = idx < 0 ? 0x80000000u : (unsigned)idx * 4u;    // negative base: every corner out of range (see corners())
     return c;
 }
@@ -288,7 +295,7 @@ __device__ constexpr float tap_frac(int S, int t)
 // out[0..7]: corners in the reference's order (bit2 x, bit1 y, bit0 z; 0 = '+'), out[8]: centre.
 // (i, j, kl): node indices in the map's LOCAL index space.
 // node(x, y, z): value of map node (i - 1 + x, j - 1 + y, kl - 1 + z) by flat index (see NodesGlobal / NodesLds)
-template <int SX, int SY, int SZ, class Nodes>
+template <int SX, int SY, int SZ, class Nodes, bool Q4 = false>
 __device__ __forceinline__ void map9_nodes(const Nodes &node, float out[9])
 {
     constexpr int NX = SX ? 2 : 3, NY = SY ? 2 : 3, NZ = SZ ? 2 : 3;
@@ -310,7 +317,7 @@ __device__ __forceinline__ void map9_nodes(const Nodes &node, float out[9])
         for (int z = 0; z < NZ; z++)
 #pragma unroll
             for (int y = 0; y < NY; y++)
-                LX[t][z][y] = lerp_q(N[z][y][r], N[z][y][r + 1], c);
+                LX[t][z][y] = lerp_q<Q4>(N[z][y][r], N[z][y][r + 1], c);
     }
     // level 2: along y
     float LY[3][3][NZ];     // [tx][ty][z]; centre only pairs with centre
@@ -323,18 +330,18 @@ __device__ __forceinline__ void map9_nodes(const Nodes &node, float out[9])
             const float c = tap_frac(SY, ty);
 #pragma unroll
             for (int z = 0; z < NZ; z++)
-                LY[tx][ty][z] = lerp_q(LX[tx][z][r], LX[tx][z][r + 1], c);
+                LY[tx][ty][z] = lerp_q<Q4>(LX[tx][z][r], LX[tx][z][r + 1], c);
         }
     // level 3: along z
 #pragma unroll
     for (int ii = 0; ii < 8; ii++) {
         const int tx = (ii >> 2) & 1, ty = (ii >> 1) & 1, tz = ii & 1;
         const int r = tap_rel(SZ, tz);
-        out[ii] = lerp_q(LY[tx][ty][r], LY[tx][ty][r + 1], tap_frac(SZ, tz));
+        out[ii] = lerp_q<Q4>(LY[tx][ty][r], LY[tx][ty][r + 1], tap_frac(SZ, tz));
     }
     {
         const int r = tap_rel(SZ, 2);
-        out[8] = lerp_q(LY[2][2][r], LY[2][2][r + 1], tap_frac(SZ, 2));
+        out[8] = lerp_q<Q4>(LY[2][2][r], LY[2][2][r + 1], tap_frac(SZ, 2));
     }
 }
 
@@ -359,6 +366,14 @@ __device__ __forceinline__ void map9_component(const Field &f, int i, int j, int
 // Each tile element is loaded by the same flat index the direct path uses (a column left of 0 / right of nx - 1
 // is the neighbouring row's end, outside the allocation reads 0), so both paths see identical values.
 constexpr int kTileX = 66, kTileY = 6, kTileZ = 3, kTile = kTileX * kTileY * kTileZ;
+
+// A map value that lets the quarter-weight lerps of map9 run in fp32 (lerp_q<true>): zero, or a coordinate in
+// [h/256, 1024 h].  Every value map9 then combines is a convex combination (weights 0, 1/4, 1/2, 3/4, 1, three levels)
+// of such values: zero, or within [h/256/64, 1024 h] -- any two of them less than 2^24 apart, inside lerp_q's 2^25.
+// Map components are coordinates in [0, n h], n <= 1024, zero on the border the DMC update clears: in practice every
+// map passes (gpu_maps_quarter_safe scans a map set); a NaN, an Inf, a negative or a denormal-small value anywhere
+// keeps every launch on that map on the double-rounding path.
+__device__ __forceinline__ bool tile_value_ok(float v, float lo, float hi) { return v == 0.f || (v >= lo && v <= hi); }
 
 // all 256 threads of the block call this (no early exit before it); ends with a barrier
 template <int NC>
@@ -387,14 +402,14 @@ struct NodesLds {
     const float *t;         // tile + (threadIdx.y * kTileX + threadIdx.x): this thread's node (i - 1, j - 1, kl - 1)
     __device__ __forceinline__ float operator()(int x, int y, int z) const { return t[(z * kTileY + y) * kTileX + x]; }
 };
-template <int SX, int SY, int SZ>
+template <int SX, int SY, int SZ, bool Q4 = false>
 __device__ __forceinline__ void map9_lds(const float *tile, f3 out[9])
 {
     const float *t = tile + threadIdx.y * kTileX + threadIdx.x;
     float x[9], y[9], z[9];
-    map9_nodes<SX, SY, SZ>(NodesLds{t}, x);
-    map9_nodes<SX, SY, SZ>(NodesLds{t + kTile}, y);
-    map9_nodes<SX, SY, SZ>(NodesLds{t + 2 * kTile}, z);
+    map9_nodes<SX, SY, SZ, NodesLds, Q4>(NodesLds{t}, x);
+    map9_nodes<SX, SY, SZ, NodesLds, Q4>(NodesLds{t + kTile}, y);
+    map9_nodes<SX, SY, SZ, NodesLds, Q4>(NodesLds{t + 2 * kTile}, z);
 #pragma unroll
     for (int a = 0; a < 9; a++) out[a] = mk3(x[a], y[a], z[a]);
 }

@@ -25,6 +25,7 @@ struct Runtime {
     int         opt_jacobi_kchunk = 0;      // 0 = auto
     int         opt_fused_housekeeping = 0; // FL_OPT_FUSED_HOUSEKEEPING bit mask
     int         opt_fast_lerp = 0;          // gather kernels: one fp32 fma per lerp instead of the double-evaluated one
+    int         opt_map_quarter_fp32 = 0;   // FL_OPT_MAP_QUARTER_FP32: the caller vouches for the maps (gpu_maps_quarter_safe)
     int         opt_mgcg_graph = 1;         // replay the multigrid V-cycle from a captured hipGraph
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;

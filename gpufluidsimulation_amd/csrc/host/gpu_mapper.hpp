@@ -165,8 +165,12 @@ public:
     // passes to produced()).  Nothing may read an output beyond that, so the operator is not run there at all: with
     // G = 8 and a typical out_valid of 4 it covers 264 instead of 272 planes.
     struct GhostNeed { std::initializer_list<DeviceField *> fields; int depth; };
+    // writes: the fields `op` stores into.  None of them may be among the fields in flight (the halo stream reads their
+    // owned planes and writes their ghost planes while `op` runs): checked, not assumed -- a violation latches an error
+    // and falls back to exchange-then-operator.
     template <class Op>
-    void withGhosts(std::initializer_list<GhostNeed> needs, Op &&op, int out_valid = DeviceField::kAlwaysValid)
+    void withGhosts(std::initializer_list<GhostNeed> needs, Op &&op, int out_valid = DeviceField::kAlwaysValid,
+                    std::initializer_list<const DeviceField *> writes = {})
     {
         if (!slab.on || slab.nranks <= 1) { op(); return; }
         // planes worth computing: the owned ones and out_valid ghost planes per side
@@ -193,8 +197,12 @@ public:
             else op();
             return;
         }
+        bool hazard = false;
+        for (const DeviceField *wf : writes)
+            for (int a = 0; a < n; a++) hazard = hazard || wf == moved[a] || wf->get() == ptrs[a];
+        if (hazard) fl_report_error(FL_ERR_BAD_ARGUMENT, "withGhosts: the operator writes a field whose ghost planes are in flight");
         const int k0 = slab.G + reach, k1 = g.nk - slab.G - reach;
-        const bool split = can_window && k1 - k0 >= 8 && fl_set_plane_window(k0, k1) == 1;
+        const bool split = !hazard && can_window && k1 - k0 >= 8 && fl_set_plane_window(k0, k1) == 1;
         if (!split) {
             for (const GhostNeed &nd : needs) require(nd.fields, nd.depth);
             if (trimmed && fl_set_plane_window(w0, w1) == 1) { op(); fl_set_plane_window(-1, -1); }

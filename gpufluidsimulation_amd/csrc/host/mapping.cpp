@@ -15,6 +15,16 @@ static const int kReachMap = 1;
 static inline int reachField(int D) { return D + 2; }
 static const int kReachDMC = 3;
 
+// FL_OPT_MAP_QUARTER_FP32 for the duration of one operator call on a map set whose values have been checked
+struct QuarterScope {
+    explicit QuarterScope(bool on) : on_(on) { if (on_) fl_set_option(FL_OPT_MAP_QUARTER_FP32, 1); }
+    ~QuarterScope() { if (on_) fl_set_option(FL_OPT_MAP_QUARTER_FP32, 0); }
+    QuarterScope(const QuarterScope &) = delete;
+    QuarterScope &operator=(const QuarterScope &) = delete;
+private:
+    bool on_;
+};
+
 bool MapSet::alloc(const gpuMapper &m)
 {
     DeviceField *all[] = { &ForwardX, &ForwardY, &ForwardZ, &BackwardX, &BackwardY, &BackwardZ,
@@ -73,7 +83,7 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
         if (keepDmcBorder && !fused.on) { out[0]->copy_from(*in[0]); out[1]->copy_from(*in[1]); out[2]->copy_from(*in[2]); }
         gs.withGhosts({ { { &U, &V, &W, in[0], in[1], in[2] }, kReachDMC } }, [&] {
             gs.solveBackwardDMC(U, V, W, *in[0], *in[1], *in[2], *out[0], *out[1], *out[2], substep);
-        }, gs.validAfter({ &U, &V, &W, in[0], in[1], in[2] }, kReachDMC) - kReachDMC);
+        }, gs.validAfter({ &U, &V, &W, in[0], in[1], in[2] }, kReachDMC) - kReachDMC, { out[0], out[1], out[2] });
         const int v = gpuMapper::minValid({ &U, &V, &W, in[0], in[1], in[2] }) - kReachDMC;
         gs.producedAll({ out[0], out[1], out[2] }, v);
         in[0] = out[0]; in[1] = out[1]; in[2] = out[2];
@@ -89,6 +99,7 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
         m.BackwardX.copy_from(*in[0]); m.BackwardY.copy_from(*in[1]); m.BackwardZ.copy_from(*in[2]);
     }
     m.Dback += dcells;
+    m.backQ4 = any ? gpu_maps_quarter_safe(m.BackwardX, m.BackwardY, m.BackwardZ, g.h, g.ni, g.nj, g.nk) == 1 : m.backQ4;
 }
 
 // Mapping.cpp:370-373.  In place; a node's trace starts at its own map value and samples the
@@ -100,12 +111,14 @@ void MapperBaseGPU::updateForward(DeviceField &U, DeviceField &V, DeviceField &W
     const int reach = reachField(m.Dfwd + dcells);
     gs.withGhosts({ { { &U, &V, &W }, reach } }, [&] {
         gs.solveForward(U, V, W, m.ForwardX, m.ForwardY, m.ForwardZ, cfldt, dt);
-    }, std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }), gs.validAfter({ &U, &V, &W }, reach) - reach));
+    }, std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }), gs.validAfter({ &U, &V, &W }, reach) - reach),
+       { &m.ForwardX, &m.ForwardY, &m.ForwardZ });
     const int v = std::min(gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }),
                            gpuMapper::minValid({ &U, &V, &W }) - reach);
     gs.producedAll({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, v);
     m.Dfwd += dcells;
     m.fwdIdentity = false;
+    m.fwdQ4 = gpu_maps_quarter_safe(m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk) == 1;
 }
 
 // Mapping.cpp:375-391.  gpu_compensate_velocity is issued as its four stages (GPU_kernel.cu:652-665)
@@ -121,9 +134,10 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
 
     // advect: U(x) = blend9(Ui(psi_back(x)))
     gs.withGhosts({ { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap }, { { &Ui, &Vi, &Wi }, reachField(m.Dback) } }, [&] {
+        QuarterScope q4(m.backQ4);
         gs.advectVelocity(U, V, W, Ui, Vi, Wi, m.BackwardX, m.BackwardY, m.BackwardZ, false);
     }, std::min(gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
-                gs.validAfter({ &Ui, &Vi, &Wi }, reachField(m.Dback)) - reachField(m.Dback)));
+                gs.validAfter({ &Ui, &Vi, &Wi }, reachField(m.Dback)) - reachField(m.Dback)), { &U, &V, &W });
     gs.producedAll({ &U, &V, &W }, std::min(gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                             gpuMapper::minValid({ &Ui, &Vi, &Wi }) - reachField(m.Dback)));
 
@@ -139,9 +153,10 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
         stage2_done = fused.on;
         if (!fused.on) { gs.u_src.zero(); gs.v_src.zero(); gs.w_src.zero(); }
         gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &U, &V, &W }, reachField(m.Dfwd) } }, [&] {
+            QuarterScope q4(m.fwdQ4);
             gpu_compensate_error_velocity(U, V, W, Ui, Vi, Wi, gs.u_src, gs.v_src, gs.w_src,
                                           m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
-        }, err_valid);
+        }, err_valid, { &gs.u_src, &gs.v_src, &gs.w_src, &Ui, &Vi, &Wi });
     }
     gs.producedAll({ &gs.u_src, &gs.v_src, &gs.w_src },
                    std::min({ gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
@@ -154,9 +169,10 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     else { Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W); }
     // stage 3: U += blend9(-0.5 * u_src(psi_back(x)))
     gs.withGhosts({ { { &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
+        QuarterScope q4(m.backQ4);
         gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
     }, std::min({ gpuMapper::minValid({ &U, &V, &W }), gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
-                  gs.validAfter({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback)) - reachField(m.Dback) }));
+                  gs.validAfter({ &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback)) - reachField(m.Dback) }), { &U, &V, &W });
     const int stage3_valid = std::min({ gpuMapper::minValid({ &U, &V, &W }),
                                         gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                         gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) });
@@ -198,7 +214,7 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
 
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
     gs.require({ &fInit }, reachField(m.Dback));
-    gs.advectField(f, fInit, m.BackwardX, m.BackwardY, m.BackwardZ, false);
+    { QuarterScope q4(m.backQ4); gs.advectField(f, fInit, m.BackwardX, m.BackwardY, m.BackwardZ, false); }
     gs.produced(f, std::min(gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                             fInit.valid - reachField(m.Dback)));
 
@@ -210,6 +226,7 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
         FusedScope fused(gs.fuse_housekeeping, 1 | 2);
         stage2_done = fused.on;
         if (!fused.on) fl_memset(gs.u_src, 0, g.n() * sizeof(float));     // GPU_Advection.h:526 (u_src doubles as scalar scratch)
+        QuarterScope q4(m.fwdQ4);
         gpu_compensate_error_field(f, fInit, gs.u_src, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
     }
     // u_src is the u-sized scratch: as a scalar field its planes are ni*nj wide
@@ -220,7 +237,7 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
     if (stage2_done) fInit.valid = f.valid; else fInit.copy_from(f);
     gs.require({ &gs.u_src }, reachField(m.Dback));
     gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
-    gs.accumulateField(gs.u_src, f, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
+    { QuarterScope q4(m.backQ4); gs.accumulateField(gs.u_src, f, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f); }
     const int stage3_valid = std::min({ f.valid, gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                         gs.u_src.valid - reachField(m.Dback) });
     if (!keepDmcBorder)
@@ -262,9 +279,10 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
         FusedScope fused(gs.fuse_housekeeping, 1);
         if (!fused.on) { f1.zero(); f2.zero(); }                            // GPU_Advection.h:507
         gs.withGhosts({ { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap }, { { &f1Init, &f2Init }, reachField(m.Dback) } }, [&] {
+            QuarterScope q4(m.backQ4);
             gpu_advect_field2(f1, f1Init, f2, f2Init, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
         }, std::min(gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
-                    gs.validAfter({ &f1Init, &f2Init }, reachField(m.Dback)) - reachField(m.Dback)));
+                    gs.validAfter({ &f1Init, &f2Init }, reachField(m.Dback)) - reachField(m.Dback)), { &f1, &f2 });
     }
     gs.produced(f1, std::min(back() - kReachMap, f1Init.valid - reachField(m.Dback)));
     gs.produced(f2, std::min(back() - kReachMap, f2Init.valid - reachField(m.Dback)));
@@ -277,8 +295,10 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
         stage2_done = fused.on;
         if (!fused.on) { fl_memset(e1, 0, g.n() * sizeof(float)); fl_memset(e2, 0, g.n() * sizeof(float)); }
         gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &f1, &f2 }, reachField(m.Dfwd) } }, [&] {
+            QuarterScope q4(m.fwdQ4);
             gpu_compensate_error_field2(f1, f1Init, e1, f2, f2Init, e2, m.ForwardX, m.ForwardY, m.ForwardZ, h, ni, nj, nk, false);
-        }, std::max(0, gs.validAfter({ &f1, &f2 }, reachField(m.Dfwd))));      // (wherever f is correct: the fused copy into fInit)
+        }, std::max(0, gs.validAfter({ &f1, &f2 }, reachField(m.Dfwd))),       // (wherever f is correct: the fused copy into fInit)
+           { &e1, &e2, &f1Init, &f2Init });
     }
     const size_t plane1 = e1.plane, plane2 = e2.plane;
     e1.plane = e2.plane = (size_t)ni * nj;
@@ -287,9 +307,10 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
     if (stage2_done) { f1Init.valid = f1.valid; f2Init.valid = f2.valid; }
     else { f1Init.copy_from(f1); f2Init.copy_from(f2); }
     gs.withGhosts({ { { &e1, &e2 }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
+        QuarterScope q4(m.backQ4);
         gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
     }, std::min({ f1.valid, f2.valid, gs.validAfter({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap) - kReachMap,
-                  gs.validAfter({ &e1, &e2 }, reachField(m.Dback)) - reachField(m.Dback) }));
+                  gs.validAfter({ &e1, &e2 }, reachField(m.Dback)) - reachField(m.Dback) }), { &f1, &f2 });
     const int s3v1 = std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) });
     const int s3v2 = std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) });
     if (!keepDmcBorder)
@@ -329,12 +350,13 @@ void MapperBaseGPU::accumulateVelocity(DeviceField &dUi, DeviceField &dVi, Devic
     MapSet &m = *maps;
     gpuMapper &gs = *gpuSolver;
     gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Uc, &Vc, &Wc }, reachField(m.Dfwd) } }, [&] {
+        QuarterScope q4(m.fwdQ4);
         if (m.fwdIdentity)
             gpu_accumulate_velocity_identity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false, coeff);
         else
             gs.accumulateVelocity(Uc, Vc, Wc, dUi, dVi, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, false, coeff);
     }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }), gs.validAfter({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap) - kReachMap,
-                  gs.validAfter({ &Uc, &Vc, &Wc }, reachField(m.Dfwd)) - reachField(m.Dfwd) }));
+                  gs.validAfter({ &Uc, &Vc, &Wc }, reachField(m.Dfwd)) - reachField(m.Dfwd) }), { &dUi, &dVi, &dWi });
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc, &Vc, &Wc }) - reachField(m.Dfwd) }));
@@ -348,21 +370,23 @@ void MapperBaseGPU::accumulateVelocity2(DeviceField &dUi, DeviceField &dVi, Devi
     gpuMapper &gs = *gpuSolver;
     if (first_uw_zero) {
         gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd) } }, [&] {
+            QuarterScope q4(m.fwdQ4);
             gpu_accumulate_component(Uc2, coeff2, nullptr, 0.f, dUi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 0, false);
             gpu_accumulate_component(Vc1, coeff1, Vc2, coeff2, dVi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 1, false);
             gpu_accumulate_component(Wc2, coeff2, nullptr, 0.f, dWi, m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, 2, false);
         }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }), gs.validAfter({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap) - kReachMap,
-                      gs.validAfter({ &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd)) - reachField(m.Dfwd) }));
+                      gs.validAfter({ &Vc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd)) - reachField(m.Dfwd) }), { &dUi, &dVi, &dWi });
         gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                         gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                         gpuMapper::minValid({ &Vc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
         return;
     }
     gs.withGhosts({ { { &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap }, { { &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd) } }, [&] {
+        QuarterScope q4(m.fwdQ4);
         gpu_accumulate_velocity2(Uc1, Vc1, Wc1, coeff1, Uc2, Vc2, Wc2, coeff2, dUi, dVi, dWi,
                                  m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk, false);
     }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }), gs.validAfter({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap) - kReachMap,
-                  gs.validAfter({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd)) - reachField(m.Dfwd) }));
+                  gs.validAfter({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }, reachField(m.Dfwd)) - reachField(m.Dfwd) }), { &dUi, &dVi, &dWi });
     gs.producedAll({ &dUi, &dVi, &dWi }, std::min({ gpuMapper::minValid({ &dUi, &dVi, &dWi }),
                                                     gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                                     gpuMapper::minValid({ &Uc1, &Vc1, &Wc1, &Uc2, &Vc2, &Wc2 }) - reachField(m.Dfwd) }));
@@ -374,7 +398,7 @@ void MapperBaseGPU::accumulateField(DeviceField &dfInit, DeviceField &fChange)
     gpuMapper &gs = *gpuSolver;
     gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, kReachMap);
     gs.require({ &fChange }, reachField(m.Dfwd));
-    gs.accumulateField(fChange, dfInit, m.ForwardX, m.ForwardY, m.ForwardZ, false, 1.0f);
+    { QuarterScope q4(m.fwdQ4); gs.accumulateField(fChange, dfInit, m.ForwardX, m.ForwardY, m.ForwardZ, false, 1.0f); }
     gs.produced(dfInit, std::min({ dfInit.valid, gpuMapper::minValid({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }) - kReachMap,
                                    fChange.valid - reachField(m.Dfwd) }));
 }
@@ -395,6 +419,7 @@ void MapperBaseGPU::reinitializeMapping()
     m.Dback = 0;
     m.Dfwd = 0;
     m.fwdIdentity = true;
+    m.backQ4 = m.fwdQ4 = true;          // identity maps: 0 or n*h with 1 <= n <= 1024 (planes outside the global grid: 0)
 }
 
 // The reference scans gpuSolver->du on the host (Mapping.cpp:497-516); that scratch still holds older data

@@ -26,6 +26,10 @@ struct MapSet {
     int Dfwd = 0, Dback = 0, DbackPrev = 0;
     // Forward* still hold exactly what gpu_init_maps wrote (fresh or just re-initialised, not yet updated)
     bool fwdIdentity = true;
+    // every value of the Backward* / Forward* arrays is 0 or a coordinate in [h/256, 1024 h] (gpu_maps_quarter_safe, checked
+    // after each update; true for the identity maps): the operators may run the weight-1/4 lerps of the structured map
+    // look-up in fp32 (FL_OPT_MAP_QUARTER_FP32) -- same values, fewer issue cycles
+    bool backQ4 = true, fwdQ4 = true;
     bool alloc(const gpuMapper &m);
 };
 

@@ -269,10 +269,15 @@ enum {
                                  *   4: gpu_solve_backwardDMC writes zeros to the border nodes of x/y/z_out (what the
                                  *      reference's cleared scratch holds there, GPU_Advection.h:464-468);
                                  *   8: gpu_solve_backwardDMC copies the border nodes of x/y/z_in to x/y/z_out instead.  */
-    FL_OPT_FAST_LERP       = 11 /* 0 (default): the reference's double-evaluated lerp, results bit-identical to the
-                                 * oracle.  1: every lerp of the gather kernels is one fp32 fma, fmaf(c, b-a, a) --
-                                 * ~3 orders of magnitude inside the 1e-5 RMS tolerance after 200 steps; the single-field
-                                 * gather kernels run ~10 % faster, the step ~5 %     */
+    FL_OPT_FAST_LERP       = 11,/* 0 (default): the reference's double-evaluated lerp, results bit-identical to the
+                                 * oracle.  1: every lerp of the gather kernels is one fp32 fma, fmaf(c, b-a, a) -- NOT the
+                                 * reference arithmetic; deviation measured per grid size   */
+    FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
+                                 * contract.  1: the caller vouches that every value of the map arrays it passes to the
+                                 * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map
+                                 * set); the weight-1/4 lerps of the look-up then run as one fp32 fma, which is provably
+                                 * the same value under that bound (bq_device.hip.h: lerp_q) -- same results, ~15 % fewer
+                                 * issue cycles per launch.  The host solver checks its maps after every update.     */
 };
 void fl_set_option(int option, int value);
 int  fl_get_option(int option);
@@ -285,6 +290,9 @@ const char *fl_jacobi_kernel_name(void);
 /* ------------------------------------------------------------------------------------------
  * 3. Additive entry points (no reference counterpart)
  * ---------------------------------------------------------------------------------------- */
+/* precondition check of FL_OPT_MAP_QUARTER_FP32: 1 when every value of x, y, z is 0 or in [h/256, 1024 h]; blocking;
+ * z-slab ranks get one common answer */
+int  gpu_maps_quarter_safe(const float *x, const float *y, const float *z, float h, int ni, int nj, int nk);
 /* maps <- (i*h, j*h, k*h): the host loop + H2D of MapperBaseGPU::init (Mapping.cpp:306-328) */
 void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk);
 /* device getCFL (BimocqGPUSolver.cpp:348-373): max(1e-4, max|u|,|v|,|w|); blocking */

@@ -32,6 +32,59 @@ def test_headers_declare_the_reference_entry_points():
     assert len(names) >= 50
 
 
+REF_HEADER = "/root/reference/src/bimocq3D/GPU_Advection.h"
+REF_NAMES = ["gpu_solve_forward", "gpu_solve_backwardDMC", "gpu_advect_velocity", "gpu_advect_vel_double", "gpu_advect_field",
+             "gpu_advect_field_double", "gpu_accumulate_velocity", "gpu_accumulate_field", "gpu_estimate_distortion", "gpu_add",
+             "gpu_compensate_velocity", "gpu_compensate_field", "gpu_semilag", "gpu_emit_smoke", "gpu_add_buoyancy",
+             "gpu_diffuse_field", "gpu_add_field", "gpu_projection_jacobi", "gpu_clamp_extrema", "gpu_mad",
+             "gpu_conjugate_gradient", "gpu_multi_grid_conjugate_gradient"]
+
+
+def prototypes(text):
+    """{name: (return type, [parameter types])} of every `gpu_*(...)` prototype in a header's text, types
+    normalised (no parameter names, no `const`, `struct`/`extern "C"` dropped, spaces around `*` removed)"""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in re.finditer(r'(?:extern\s+"C"\s+)?([A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(gpu_[A-Za-z0-9_]+)\s*\(([^)]*)\)\s*;', text):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+
+        def norm(t):
+            t = re.sub(r"\b(const|struct|extern)\b", " ", t)
+            t = re.sub(r"\s+", " ", t).strip()
+            return t.replace(" *", "*").replace("* ", "*")
+
+        types = []
+        for prm in params.split(","):
+            prm = prm.strip()
+            if not prm or prm == "void":
+                continue
+            mm = re.match(r"(.*?[\s\*])([A-Za-z_][A-Za-z0-9_]*)$", prm)       # drop the parameter name
+            types.append(norm(mm.group(1) if mm else prm))
+        out[name] = (norm(ret), types)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HEADER), reason="the reference tree is not present on this box")
+def test_prototypes_equal_the_reference_header():
+    """all 22 extern "C" prototypes of the reference's operator boundary (GPU_Advection.h:26-108): same return type,
+    same parameter types in the same order in include/bimocq_gpu.h -- parsed from both headers at test time"""
+    ref = prototypes(open(REF_HEADER).read())
+    ours = prototypes(open(os.path.join(ROOT, "include", "bimocq_gpu.h")).read())
+    assert sorted(n for n in ref) == sorted(REF_NAMES), sorted(ref)
+    for name in REF_NAMES:
+        assert name in ours, name
+        assert ours[name][0] == ref[name][0], (name, ours[name][0], ref[name][0])
+        assert ours[name][1] == ref[name][1], (name, ours[name][1], ref[name][1])
+
+
+def test_every_reference_entry_point_is_declared_and_exported():
+    names = declared("bimocq_gpu.h")
+    lib = C.CDLL(os.path.join(ROOT, "gpufluidsimulation_amd", "libbimocq_hip.so"))
+    for ref in REF_NAMES:
+        assert ref in names and hasattr(lib, ref), ref
+
+
 @pytest.mark.parametrize("header,so", [("bimocq_gpu.h", "libbimocq_hip.so"), ("bimocq_solver.h", "libbimocq_host.so")])
 def test_library_exports_every_declared_symbol(header, so):
     path = os.path.join(ROOT, "gpufluidsimulation_amd", so)

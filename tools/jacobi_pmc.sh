@@ -5,7 +5,7 @@ set -e
 v=${1:-4:2:32}; tag=${2:-x}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o run -- python3 tools/jacobi_tune.py --variants $v --sweeps 20 --reps 1 > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o run -- python3 tools/jacobi_tune.py --n ${N:-256} --variants $v --sweeps 20 --reps 1 > gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, sys
