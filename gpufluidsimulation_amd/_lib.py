@@ -68,6 +68,8 @@ HIP_SIGS = {
     # 3. additive
     "gpu_init_maps": (None, [VP, VP, VP] + _G),
     "gpu_maps_quarter_safe": (c_i, [VP, VP, VP] + _G),
+    "fl_map_guard_reset": (None, [c_i]),
+    "fl_map_guard_read": (None, [C.POINTER(c_i)]),
     "gpu_max_abs3": (c_f, [VP, VP, VP, c_i, c_i, c_i]),
     "gpu_divergence": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f, c_f]),
@@ -106,6 +108,7 @@ HIP_SIGS = {
     # wall sheets (reference-faithful DMC border on z-slab ranks)
     "fl_box_pack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),
     "fl_box_unpack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),
+    "fl_box_copy": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, c_i, VP, c_i]),
     "fl_p2p_exchange": (None, [c_i, VP, VP, VP, VP, VP]),
     "fl_comm_set_custom_p2p": (None, [VP]),
     "gpu_accumulate_wall_fixup": (None, [VP, c_i, c_i, VP, VP, VP, VP, VP, c_f, c_i, c_i, c_i, c_i, c_f, VP, c_i, VP, c_i, VP, c_i]),

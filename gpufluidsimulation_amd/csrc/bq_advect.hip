@@ -66,10 +66,21 @@ __device__ __forceinline__ f3 nine_corner(const Nine &n, f3 c, int ii)
 }
 
 // ---- A3: forward_kernel (GPU_kernel.cu:127-144) -------------------------------------------
+// guard (may be null): word that gets a 1 when a stored map value fails tile_value_ok (fl_map_guard_*)
+__device__ __forceinline__ void guard_map_values(int *guard, f3 r, float h)
+{
+    if (!guard) return;
+    const float lo = h * 0.00390625f, hi = h * 1024.f;
+    const bool bad = !(tile_value_ok(r.x, lo, hi) && tile_value_ok(r.y, lo, hi) && tile_value_ok(r.z, lo, hi));
+    if (__any(bad)) {
+        if (bad) atomicOr(guard, 1);
+    }
+}
+
 template <bool P2>
 __global__ __launch_bounds__(256) void forward_kernel(const float *u, const float *v, const float *w,
                                                       float *xf, float *yf, float *zf,
-                                                      Spacing sp, Grid g, float cfldt, float dt)
+                                                      Spacing sp, Grid g, float cfldt, float dt, int *guard)
 {
     BQ_IJK(g.ni, g.nj, g.nk)
     if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) return;
@@ -78,6 +89,7 @@ __global__ __launch_bounds__(256) void forward_kernel(const float *u, const floa
     size_t id = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
     f3 q = trace<P2>(vel, sp, hi, cfldt, dt, mk3(xf[id], yf[id], zf[id]));
     xf[id] = q.x; yf[id] = q.y; zf[id] = q.z;
+    guard_map_values(guard, q, sp.h);
 }
 
 // ---- A4: DMC_backward_kernel (GPU_kernel.cu:169-204) --------------------------------------
@@ -91,7 +103,7 @@ template <bool P2>
 __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v, const float *w,
                                                   const float *xi, const float *yi, const float *zi,
                                                   float *xo, float *yo, float *zo,
-                                                  Spacing sp, Grid g, float substep, int border)
+                                                  Spacing sp, Grid g, float substep, int border, int *guard)
 {
     BQ_IJK(g.ni, g.nj, g.nk)
     if (!(i > 1 && i < g.ni - 2 && j > 1 && j < g.nj - 2 && kg > 1 && kg < g.nkg - 2)) {
@@ -101,7 +113,9 @@ __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v
         if (border) {
             const size_t b = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
             const bool copy = border == 2;
-            xo[b] = copy ? xi[b] : 0.f; yo[b] = copy ? yi[b] : 0.f; zo[b] = copy ? zi[b] : 0.f;
+            const f3 bv = mk3(copy ? xi[b] : 0.f, copy ? yi[b] : 0.f, copy ? zi[b] : 0.f);
+            xo[b] = bv.x; yo[b] = bv.y; zo[b] = bv.z;
+            guard_map_values(guard, bv, sp.h);
         }
         return;
     }
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(256) void dmc_kernel(const float *u, const float *v
     f3 r = map_at<P2>(in, sp, pn);
     size_t id = (size_t)i + (size_t)g.ni * j + (size_t)g.ni * g.nj * k;
     xo[id] = r.x; yo[id] = r.y; zo[id] = r.z;
+    guard_map_values(guard, r, sp.h);
 }
 
 // The 9 mapped positions of a node: out[0..7] corners (reference order), out[8] centre.  SD >= 0 selects
@@ -767,15 +782,24 @@ __global__ __launch_bounds__(256) void clamp_box_march_kernel(const float *__res
     // min/max over the 3x3 (x, y) neighbourhood of every cell of this float4 on plane pl
     // rows of 4*cw + 1 floats (the u component: 257): the last lane of a row fetches the one extra column itself
     const bool tail = ni % 4 == 1 && xraw + 4 == ni - 1;
+    // rows of several waves (cw > 64: 512 and 1024 wide grids): the lanes at a wave's ends fetch the column just outside
+    // their wave themselves (three scalar loads per plane), what the lane exchange cannot reach
+    const int lane = threadIdx.x & 63;
+    const bool wedgeL = cw > 64 && lane == 0 && c > 0 && xok;
+    const bool wedgeR = cw > 64 && lane == 63 && xraw + 4 < ni && !tail;
     auto plane_box = [&](int pl) -> MinMax4 {
         const size_t p0 = sk * (size_t)min(max(pl, 0), nk - 1);
         const float4 a = ld4(p0 + o_m), b = ld4(p0 + o_0), d = ld4(p0 + o_p);
         float4 lo = make_float4(mn3(a.x, b.x, d.x), mn3(a.y, b.y, d.y), mn3(a.z, b.z, d.z), mn3(a.w, b.w, d.w));
         float4 hi = make_float4(mx3(a.x, b.x, d.x), mx3(a.y, b.y, d.y), mx3(a.z, b.z, d.z), mx3(a.w, b.w, d.w));
         float llo = lane_up(lo.w), rlo = lane_down(lo.x), lhi = lane_up(hi.w), rhi = lane_down(hi.x);
-        if (tail) {
+        if (tail || wedgeR) {
             const float ta = before[p0 + o_m + 4], tb = before[p0 + o_0 + 4], td = before[p0 + o_p + 4];
             rlo = mn3(ta, tb, td); rhi = mx3(ta, tb, td);
+        }
+        if (wedgeL) {
+            const float ta = before[p0 + o_m - 1], tb = before[p0 + o_0 - 1], td = before[p0 + o_p - 1];
+            llo = mn3(ta, tb, td); lhi = mx3(ta, tb, td);
         }
         MinMax4 m;
         m.lo = make_float4(mn3(llo, lo.x, lo.y), mn3(lo.x, lo.y, lo.z), mn3(lo.y, lo.z, lo.w), mn3(lo.z, lo.w, rlo));
@@ -813,9 +837,9 @@ static void clamp_box(const float *before, float *after, int ni, int nj, int nk,
     // float4 columns; rows of 4m + 1 floats (u: 257) go through the same kernel with unaligned 16-byte accesses and one
     // extra column fetched by the last lane (102 -> 48 us at 257 x 256 x 256)
     const int nv = ni % 4 == 1 ? ni - 1 : ni;            // floats per row handled as float4
-    const bool pow2row = nv >= 32 && nv <= 256 && (nv & (nv - 1)) == 0;
+    const bool pow2row = nv >= 32 && nv <= 1024 && (nv & (nv - 1)) == 0;
     const bool vec_ok = nj >= 3 && nk >= 3 && rt().opt_jacobi_variant != 1 &&
-                        ((ni % 4 == 0 && ni >= 32 && ni <= 256 && (((uintptr_t)before | (uintptr_t)after) & 15u) == 0) ||
+                        ((ni % 4 == 0 && ni >= 32 && ni <= 1024 && (((uintptr_t)before | (uintptr_t)after) & 15u) == 0) ||
                          (ni % 4 == 1 && pow2row && (((uintptr_t)before | (uintptr_t)after) & 3u) == 0));
     if (vec_ok) {
         int cw = 16;
@@ -869,7 +893,8 @@ BQ_ENTRY(gpu_solve_forward, (float *u, float *v, float *w, float *x_fwd, float *
     int planes;
     Spacing sp = make_spacing(h); Grid g = mk_grid_win(ni, nj, nk, 0, &planes);
     if (planes <= 0) return;
-    BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, planes), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt);
+    int *guard = rt().map_guard_on ? rt().map_guard + 1 : nullptr;
+    BQ_DISPATCH1(forward_kernel, sp.pow2, grid_for(ni, nj, planes), u, v, w, x_fwd, y_fwd, z_fwd, sp, g, cfldt, dt, guard);
 }
 
 BQ_ENTRY(gpu_solve_backwardDMC, (float *u, float *v, float *w, float *x_in, float *y_in, float *z_in,
@@ -882,7 +907,8 @@ BQ_ENTRY(gpu_solve_backwardDMC, (float *u, float *v, float *w, float *x_in, floa
     Spacing sp = make_spacing(h); Grid g = mk_grid_win(ni, nj, nk, 0, &planes);
     if (planes <= 0) return;
     const int border = (rt().opt_fused_housekeeping & 8) ? 2 : (rt().opt_fused_housekeeping & 4) ? 1 : 0;
-    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, planes), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep, border);
+    int *guard = rt().map_guard_on ? rt().map_guard : nullptr;
+    BQ_DISPATCH1(dmc_kernel, sp.pow2, grid_for(ni, nj, planes), u, v, w, x_in, y_in, z_in, x_out, y_out, z_out, sp, g, substep, border, guard);
 }
 
 BQ_ENTRY(gpu_advect_velocity, (float *u, float *v, float *w, float *u_init, float *v_init, float *w_init,
@@ -1161,6 +1187,44 @@ BQ_ENTRY(gpu_accumulate_wall_fixup, (const float *src, int src_koff, int src_nk,
 }
 
 #ifndef BQ_FAST_LERP
+// ---- the same check fused into the map updates: gpu_solve_backwardDMC / gpu_solve_forward flag what they store -------
+// fl_map_guard_reset(which): arm the guard and clear word `which` (0: backward, 1: forward; -1: switch the guard off);
+// fl_map_guard_read(ok): ok[0], ok[1] = 1 when no value stored since the word's reset failed the test -- blocking, one
+// 8-byte read-back for both; z-slab ranks agree on the answer.  A map update that also copies or keeps values it did not
+// compute (border nodes of the forward map, ghost planes received from a neighbour) is covered as long as those values
+// were themselves produced under the guard or by gpu_init_maps.
+void fl_map_guard_reset(int which)
+{
+    if (!ensure_ready("fl_map_guard_reset")) return;
+    Runtime &r = rt();
+    if (which < 0) { r.map_guard_on = false; return; }
+    if (which > 1) { latch(FL_ERR_BAD_ARGUMENT, "fl_map_guard_reset", "which must be 0, 1 or negative"); return; }
+    if (!r.map_guard && !BQ_HIP(hipMalloc((void **)&r.map_guard, 16))) { r.map_guard = nullptr; return; }
+    if (!BQ_HIP(hipMemsetAsync(r.map_guard + which, 0, 4, r.compute))) return;
+    r.map_guard_on = true;
+}
+
+void fl_map_guard_read(int ok[2])
+{
+    if (!ok) return;
+    ok[0] = ok[1] = 0;
+    Runtime &r = rt();
+    if (!r.ready || !r.map_guard) return;
+    int *host = (int *)pinned(64);
+    if (!host) return;
+    hipStream_t st = r.compute;
+    if (!BQ_HIP(hipMemcpyAsync(host, r.map_guard, 8, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return;
+    int bad[2] = { host[0], host[1] };
+    if (comm_ranks() > 1) {                         // every rank reads its neighbours' values in its ghost planes
+        float *dev = (float *)(r.map_guard + 2), *hf = (float *)host;
+        hf[0] = bad[0] ? 1.f : 0.f; hf[1] = bad[1] ? 1.f : 0.f;
+        if (!BQ_HIP(hipMemcpyAsync(dev, hf, 8, hipMemcpyHostToDevice, st)) || !comm_allreduce(dev, 2, false, true, st)) return;
+        if (!BQ_HIP(hipMemcpyAsync(hf, dev, 8, hipMemcpyDeviceToHost, st)) || !BQ_HIP(hipStreamSynchronize(st))) return;
+        bad[0] = hf[0] != 0.f; bad[1] = hf[1] != 0.f;
+    }
+    ok[0] = !bad[0]; ok[1] = !bad[1];
+}
+
 // 1 when every value of the three map arrays is 0 or lies in [h/256, 1024 h] (tile_value_ok): the precondition of
 // FL_OPT_MAP_QUARTER_FP32.  Blocking (one 4-byte read-back); z-slab ranks agree on the answer (all-reduced).
 int gpu_maps_quarter_safe(const float *x, const float *y, const float *z, float h, int ni, int nj, int nk)

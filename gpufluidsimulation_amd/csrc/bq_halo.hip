@@ -248,7 +248,7 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
 
 // ---- wall sheets (include/bimocq_gpu.h, section 4): box gather / scatter and point-to-point messages -------------
 namespace {
-constexpr int kBoxChunk = 16;
+constexpr int kBoxChunk = 64;
 struct BoxChunk {
     int n;
     int x0[kBoxChunk], y0[kBoxChunk], z0[kBoxChunk], wx[kBoxChunk], wy[kBoxChunk];
@@ -256,10 +256,11 @@ struct BoxChunk {
 };
 }
 
-// one thread per packed element; MODE 0: packed <- field, 1: field <- packed, 2: field <- NaN
+// one thread per packed element; MODE 0: packed <- field, 1: field <- packed, 2: field <- NaN,
+// 3: packed[same global cell] <- field, `packed` being a second field that holds the planes [koff2, ...)
 template <int MODE>
 __global__ __launch_bounds__(256) void box_copy_kernel(float *__restrict__ field, float *__restrict__ packed, BoxChunk c,
-                                                       int nbi, int nbj, int koff)
+                                                       int nbi, int nbj, int koff, int koff2 = 0)
 {
     const long long total = c.off[c.n];
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -272,12 +273,14 @@ __global__ __launch_bounds__(256) void box_copy_kernel(float *__restrict__ field
         const size_t id = (size_t)(c.x0[b] + x) + (size_t)nbi * ((size_t)(c.y0[b] + y) + (size_t)nbj * (size_t)(c.z0[b] + z - koff));
         if (MODE == 0) packed[t] = field[id];
         else if (MODE == 1) field[id] = packed[t];
-        else field[id] = __builtin_nanf("");
+        else if (MODE == 2) field[id] = __builtin_nanf("");
+        else packed[(size_t)(c.x0[b] + x) + (size_t)nbi * ((size_t)(c.y0[b] + y) + (size_t)nbj * (size_t)(c.z0[b] + z - koff2))] = field[id];
     }
 }
 
 template <int MODE>
-static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed, const char *op)
+static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed, const char *op,
+                     int nk2 = 0, int koff2 = 0)
 {
     if (!ensure_ready(op)) return;
     if (nboxes <= 0) return;
@@ -291,6 +294,7 @@ static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, con
             if (q.x0 < 0 || q.y0 < 0 || q.z0 < koff || q.x1 > nbi || q.y1 > nbj || q.z1 > koff + nk_field || q.x1 < q.x0 || q.y1 < q.y0 || q.z1 < q.z0) {
                 latch(FL_ERR_BAD_ARGUMENT, op, "box outside the field"); return;
             }
+            if (MODE == 3 && (q.z0 < koff2 || q.z1 > koff2 + nk2)) { latch(FL_ERR_BAD_ARGUMENT, op, "box outside the destination"); return; }
             const long long vol = (long long)(q.x1 - q.x0) * (q.y1 - q.y0) * (q.z1 - q.z0);
             if (vol == 0) continue;
             c.x0[c.n] = q.x0; c.y0[c.n] = q.y0; c.z0[c.n] = q.z0; c.wx[c.n] = q.x1 - q.x0; c.wy[c.n] = q.y1 - q.y0;
@@ -300,7 +304,7 @@ static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, con
         const long long total = c.off[c.n];
         if (total == 0) continue;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        box_copy_kernel<MODE><<<blocks, 256, 0, rt().compute>>>(field, MODE == 2 ? nullptr : packed + base, c, nbi, nbj, koff);
+        box_copy_kernel<MODE><<<blocks, 256, 0, rt().compute>>>(field, MODE == 2 ? nullptr : (MODE == 3 ? packed : packed + base), c, nbi, nbj, koff, koff2);
         if (!BQ_LAUNCH_CHECK("box_copy_kernel")) return;
         base += total;
     }
@@ -317,6 +321,12 @@ void fl_box_unpack(float *field, int nbi, int nbj, int nk_field, int koff, const
 {
     if (packed) box_copy<1>(field, nbi, nbj, nk_field, koff, boxes, nboxes, const_cast<float *>(packed), "fl_box_unpack");
     else        box_copy<2>(field, nbi, nbj, nk_field, koff, boxes, nboxes, nullptr, "fl_box_unpack");
+}
+
+void fl_box_copy(const float *src, int nbi, int nbj, int nk_src, int koff_src, float *dst, int nk_dst, int koff_dst,
+                 const fl_box *boxes, int nboxes)
+{
+    box_copy<3>(const_cast<float *>(src), nbi, nbj, nk_src, koff_src, boxes, nboxes, dst, "fl_box_copy", nk_dst, koff_dst);
 }
 
 void fl_comm_set_custom_p2p(fl_p2p_cb p2p) { g_custom_p2p = p2p; }

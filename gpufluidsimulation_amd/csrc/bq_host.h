@@ -26,6 +26,10 @@ struct Runtime {
     int         opt_fused_housekeeping = 0; // FL_OPT_FUSED_HOUSEKEEPING bit mask
     int         opt_fast_lerp = 0;          // gather kernels: one fp32 fma per lerp instead of the double-evaluated one
     int         opt_map_quarter_fp32 = 0;   // FL_OPT_MAP_QUARTER_FP32: the caller vouches for the maps (gpu_maps_quarter_safe)
+    // map-value guard (fl_map_guard_*): gpu_solve_backwardDMC ORs word 0, gpu_solve_forward word 1 of this device array
+    // when a map value they store fails tile_value_ok; nullptr while the guard is off
+    int        *map_guard = nullptr;
+    bool        map_guard_on = false;
     int         opt_mgcg_graph = 1;         // replay the multigrid V-cycle from a captured hipGraph
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;

@@ -94,6 +94,8 @@ void fl_shutdown(void)
     bq::mgcg_release_graph();
     if (g_rt.scratch) (void)hipFree(g_rt.scratch);
     if (g_rt.pinned) (void)hipHostFree(g_rt.pinned);
+    if (g_rt.map_guard) (void)hipFree(g_rt.map_guard);
+    g_rt.map_guard = nullptr; g_rt.map_guard_on = false;
     (void)hipStreamDestroy(g_rt.compute);
     (void)hipStreamDestroy(g_rt.halo);
     (void)hipStreamDestroy(g_rt.copy);

@@ -79,15 +79,23 @@ void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx
     const WallPlan *plans[3] = { nullptr, nullptr, nullptr };
     const WallItem *its[3] = { nullptr, nullptr, nullptr };
     int n = 0;
-    for (const WallItem &it : items) { its[n] = &it; plans[n] = &wallPlan(it.kind, Dback, need); n++; }
-    // the assembled copies: the global planes [k0, k1) of the sampled field, NaN wherever nothing has been placed
-    size_t local_max = 0;
-    std::vector<size_t> send_off((size_t)nr + 1, 0), recv_off((size_t)nr + 1, 0);
+    for (const WallItem &it : items) {
+        const WallPlan &p = wallPlan(it.kind, Dback, need);
+        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
+        its[n] = &it; plans[n] = &p; n++;
+    }
+    if (!n) return;
+    auto dims = [&](FieldKind kind, int &nbi, int &nbj, int &nkf) {
+        nbi = g.ni + (kind == FIELD_U); nbj = g.nj + (kind == FIELD_V); nkf = g.nk + (kind == FIELD_W);
+    };
+    // the assembled copies: the global planes [k0, k1) of the sampled field, NaN wherever nothing has been placed.
+    // Send / receive buffers: field after field, inside a field peer after peer (both sides derive the same order)
+    size_t send_total = 0, recv_total = 0, send_base[3], recv_base[3];
     for (int a = 0; a < n; a++) {
         const WallPlan &p = *plans[a];
-        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
-        const FieldKind kind = its[a]->kind;
-        const size_t plane = (size_t)(g.ni + (kind == FIELD_U)) * (size_t)(g.nj + (kind == FIELD_V));
+        int nbi, nbj, nkf;
+        dims(its[a]->kind, nbi, nbj, nkf);
+        const size_t plane = (size_t)nbi * (size_t)nbj;
         Shadow &sh = wall_shadow_[a];
         const size_t count = plane * (size_t)(p.shadow_k1 - p.shadow_k0);
         if (sh.buf.count() < count || sh.plane != plane || sh.k0 != p.shadow_k0 || sh.k1 != p.shadow_k1) {
@@ -95,46 +103,38 @@ void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx
             fl_memset(sh.buf.get(), 0xFF, sh.buf.bytes());           // all-ones bytes: a NaN in every float
             sh.k0 = p.shadow_k0; sh.k1 = p.shadow_k1; sh.plane = plane;
         }
-        local_max = std::max(local_max, WallPlan::volume(p.local));
-        for (int q = 0; q < nr; q++) {
-            send_off[(size_t)q + 1] += WallPlan::volume(p.send[(size_t)q]);
-            recv_off[(size_t)q + 1] += WallPlan::volume(p.recv[(size_t)q]);
-        }
+        send_base[a] = send_total; recv_base[a] = recv_total;
+        send_total += WallPlan::volume(p.send_all);
+        recv_total += WallPlan::volume(p.recv_all);
     }
-    for (int q = 0; q < nr; q++) { send_off[(size_t)q + 1] += send_off[(size_t)q]; recv_off[(size_t)q + 1] += recv_off[(size_t)q]; }
-    const size_t send_total = send_off[(size_t)nr], recv_total = recv_off[(size_t)nr];
     if ((wall_send_.count() < send_total && !wall_send_.alloc(send_total + send_total / 8 + 64)) ||
-        (wall_recv_.count() < recv_total && !wall_recv_.alloc(recv_total + recv_total / 8 + 64)) ||
-        (wall_local_.count() < local_max && !wall_local_.alloc(local_max + local_max / 8 + 64))) return;
-    // gather: my own pieces straight into the copies, the pieces other ranks need into the send buffer (per peer:
-    // item after item, the order both sides derive from the same plan)
-    std::vector<size_t> cur(send_off.begin(), send_off.end() - 1);
+        (wall_recv_.count() < recv_total && !wall_recv_.alloc(recv_total + recv_total / 8 + 64))) return;
+    // my own pieces go straight into the copies, the pieces other ranks need into the send buffer
     for (int a = 0; a < n; a++) {
         const WallPlan &p = *plans[a];
-        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
-        const FieldKind kind = its[a]->kind;
-        const int nbi = g.ni + (kind == FIELD_U), nbj = g.nj + (kind == FIELD_V), nkf = g.nk + (kind == FIELD_W);
+        int nbi, nbj, nkf;
+        dims(its[a]->kind, nbi, nbj, nkf);
         const float *src = its[a]->src->get();
         Shadow &sh = wall_shadow_[a];
-        if (!p.local.empty()) {
-            fl_box_pack(src, nbi, nbj, nkf, slab.koff(), p.local.data(), (int)p.local.size(), wall_local_.get());
-            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size(), wall_local_.get());
-        }
-        for (int q = 0; q < nr; q++) {
-            const std::vector<fl_box> &v = p.send[(size_t)q];
-            if (v.empty()) continue;
-            fl_box_pack(src, nbi, nbj, nkf, slab.koff(), v.data(), (int)v.size(), wall_send_.get() + cur[(size_t)q]);
-            cur[(size_t)q] += WallPlan::volume(v);
-        }
+        if (!p.local.empty())
+            fl_box_copy(src, nbi, nbj, nkf, slab.koff(), sh.buf.get(), sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size());
+        if (!p.send_all.empty())
+            fl_box_pack(src, nbi, nbj, nkf, slab.koff(), p.send_all.data(), (int)p.send_all.size(), wall_send_.get() + send_base[a]);
     }
-    // one group of point-to-point messages with every rank that owes me planes or that I owe planes
+    // one group of point-to-point messages: per field and peer that owes me planes or that I owe planes
     {
         std::vector<int> peers; std::vector<float *> sp, rp; std::vector<size_t> sc, rc;
-        for (int q = 0; q < nr; q++) {
-            const size_t ns = send_off[(size_t)q + 1] - send_off[(size_t)q], nrv = recv_off[(size_t)q + 1] - recv_off[(size_t)q];
-            if (q == slab.rank || (ns == 0 && nrv == 0)) continue;
-            peers.push_back(q); sp.push_back(wall_send_.get() + send_off[(size_t)q]); sc.push_back(ns);
-            rp.push_back(wall_recv_.get() + recv_off[(size_t)q]); rc.push_back(nrv);
+        for (int a = 0; a < n; a++) {
+            const WallPlan &p = *plans[a];
+            size_t so = send_base[a], ro = recv_base[a];
+            for (int q = 0; q < nr; q++) {
+                const size_t ns = p.send_vol[(size_t)q], nrv = p.recv_vol[(size_t)q];
+                if (q != slab.rank && (ns || nrv)) {
+                    peers.push_back(q); sp.push_back(wall_send_.get() + so); sc.push_back(ns);
+                    rp.push_back(wall_recv_.get() + ro); rc.push_back(nrv);
+                }
+                so += ns; ro += nrv;
+            }
         }
         if (!peers.empty()) fl_p2p_exchange((int)peers.size(), peers.data(), sp.data(), sc.data(), rp.data(), rc.data());
         wall_bytes_moved += (long long)recv_total * 4;
@@ -144,24 +144,17 @@ void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx
     const bool can_window = overlap_exchanges && fuse_housekeeping && fl_get_option(FL_OPT_FUSED_HOUSEKEEPING) >= 0;
     const int ov = out_valid < 0 ? 0 : (out_valid > slab.G ? slab.G : out_valid);
     const int w0 = can_window ? slab.G - ov : 0, w1 = can_window ? g.nk - slab.G + (ov > 1 ? ov : 1) : g.nk;
-    std::vector<size_t> rcur(recv_off.begin(), recv_off.end() - 1);
     for (int a = 0; a < n; a++) {
         const WallPlan &p = *plans[a];
-        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
-        const FieldKind kind = its[a]->kind;
-        const int nbi = g.ni + (kind == FIELD_U), nbj = g.nj + (kind == FIELD_V);
+        int nbi, nbj, nkf;
+        dims(its[a]->kind, nbi, nbj, nkf);
         Shadow &sh = wall_shadow_[a];
-        for (int q = 0; q < nr; q++) {
-            const std::vector<fl_box> &v = p.recv[(size_t)q];
-            if (v.empty()) continue;
-            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, v.data(), (int)v.size(), wall_recv_.get() + rcur[(size_t)q]);
-            rcur[(size_t)q] += WallPlan::volume(v);
-        }
+        if (!p.recv_all.empty())
+            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.recv_all.data(), (int)p.recv_all.size(), wall_recv_.get() + recv_base[a]);
     }
     const bool windowed = can_window && (w0 > 0 || w1 < g.nk) && fl_set_plane_window(w0, w1) == 1;
     for (int a = 0; a < n; a++) {
         const WallPlan &p = *plans[a];
-        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
         const FieldKind kind = its[a]->kind;
         const int axis = kind == FIELD_U ? 0 : kind == FIELD_V ? 1 : kind == FIELD_W ? 2 : -1;
         Shadow &sh = wall_shadow_[a];
@@ -173,14 +166,11 @@ void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx
     if (windowed) fl_set_plane_window(-1, -1);
     for (int a = 0; a < n; a++) {
         const WallPlan &p = *plans[a];
-        if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
-        const FieldKind kind = its[a]->kind;
-        const int nbi = g.ni + (kind == FIELD_U), nbj = g.nj + (kind == FIELD_V);
+        int nbi, nbj, nkf;
+        dims(its[a]->kind, nbi, nbj, nkf);
         Shadow &sh = wall_shadow_[a];
-        if (!p.local.empty()) fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size(), nullptr);
-        for (int q = 0; q < nr; q++)
-            if (!p.recv[(size_t)q].empty())
-                fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.recv[(size_t)q].data(), (int)p.recv[(size_t)q].size(), nullptr);
+        if (!p.placed_all.empty())
+            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.placed_all.data(), (int)p.placed_all.size(), nullptr);
     }
 }
 

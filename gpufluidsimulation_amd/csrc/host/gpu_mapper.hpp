@@ -304,7 +304,7 @@ private:
     std::map<std::tuple<int, int, int>, WallPlan> wall_plans_;
     struct Shadow { DeviceField buf; int k0 = 0, k1 = 0; size_t plane = 0; };
     Shadow wall_shadow_[3];
-    DeviceField wall_send_, wall_recv_, wall_local_;
+    DeviceField wall_send_, wall_recv_;
     const WallPlan &wallPlan(FieldKind kind, int Dback, int need);
 };
 

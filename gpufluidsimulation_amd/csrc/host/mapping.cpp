@@ -54,8 +54,17 @@ bool MapperBaseGPU::init(int ni, int nj, int nk, float h, float coeff, gpuMapper
 // Mapping.cpp:347-352
 void MapperBaseGPU::updateMapping(DeviceField &U, DeviceField &V, DeviceField &W, float cfldt, float dt, int dcells)
 {
+    // both updates flag map values outside tile_value_ok's range as they store them (fl_map_guard_*): one 8-byte
+    // read-back afterwards tells whether the 9-point operators may run their weight-1/4 map lerps in fp32
+    fl_map_guard_reset(0);
+    fl_map_guard_reset(1);
     updateBackward(U, V, W, cfldt, dt, dcells);
     updateForward(U, V, W, cfldt, dt, dcells);
+    int ok[2] = { 0, 0 };
+    fl_map_guard_read(ok);
+    fl_map_guard_reset(-1);
+    maps->backQ4 = maps->backQ4 && ok[0] == 1;       // (border nodes and stale planes keep older values: stay conservative
+    maps->fwdQ4 = maps->fwdQ4 && ok[1] == 1;         //  until the next re-initialisation once a value has failed)
 }
 
 // Mapping.cpp:354-368.  The reference copies x_out -> Backward after every sub-step
@@ -99,7 +108,6 @@ void MapperBaseGPU::updateBackward(DeviceField &U, DeviceField &V, DeviceField &
         m.BackwardX.copy_from(*in[0]); m.BackwardY.copy_from(*in[1]); m.BackwardZ.copy_from(*in[2]);
     }
     m.Dback += dcells;
-    m.backQ4 = any ? gpu_maps_quarter_safe(m.BackwardX, m.BackwardY, m.BackwardZ, g.h, g.ni, g.nj, g.nk) == 1 : m.backQ4;
 }
 
 // Mapping.cpp:370-373.  In place; a node's trace starts at its own map value and samples the
@@ -118,7 +126,6 @@ void MapperBaseGPU::updateForward(DeviceField &U, DeviceField &V, DeviceField &W
     gs.producedAll({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, v);
     m.Dfwd += dcells;
     m.fwdIdentity = false;
-    m.fwdQ4 = gpu_maps_quarter_safe(m.ForwardX, m.ForwardY, m.ForwardZ, g.h, g.ni, g.nj, g.nk) == 1;
 }
 
 // Mapping.cpp:375-391.  gpu_compensate_velocity is issued as its four stages (GPU_kernel.cu:652-665)

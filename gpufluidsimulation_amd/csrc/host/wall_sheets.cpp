@@ -180,6 +180,16 @@ WallPlan make_wall_plan(int ni, int nj, int nkg, int dx, int dy, int dz, int ran
         if (first || p.box.z1 > plan.shadow_k1) plan.shadow_k1 = p.box.z1;
         first = false;
     }
+    plan.send_vol.assign((size_t)nranks, 0);
+    plan.recv_vol.assign((size_t)nranks, 0);
+    plan.placed_all = plan.local;
+    for (int q = 0; q < nranks; q++) {
+        plan.send_vol[(size_t)q] = WallPlan::volume(plan.send[(size_t)q]);
+        plan.recv_vol[(size_t)q] = WallPlan::volume(plan.recv[(size_t)q]);
+        plan.send_all.insert(plan.send_all.end(), plan.send[(size_t)q].begin(), plan.send[(size_t)q].end());
+        plan.recv_all.insert(plan.recv_all.end(), plan.recv[(size_t)q].begin(), plan.recv[(size_t)q].end());
+        plan.placed_all.insert(plan.placed_all.end(), plan.recv[(size_t)q].begin(), plan.recv[(size_t)q].end());
+    }
     return plan;
 }
 

@@ -29,6 +29,9 @@ struct WallPlan {
     std::vector<fl_box> local;                  // pieces this rank reads from its own local planes
     std::vector<std::vector<fl_box>> send;      // [peer]: pieces of MY owned planes that peer needs (in peer's order)
     std::vector<std::vector<fl_box>> recv;      // [peer]: pieces of peer's owned planes that I need
+    // the same, flattened peer after peer (one gather / scatter launch per field), and everything the copy receives
+    std::vector<fl_box> send_all, recv_all, placed_all;
+    std::vector<size_t> send_vol, recv_vol;     // [peer]: floats
     bool empty() const { return xlist.empty() && ylist.empty() && zlist.empty(); }
     static size_t volume(const std::vector<fl_box> &v)
     {

@@ -102,15 +102,22 @@ class HostStagedTransport:
         """fl_p2p_exchange: message m goes to / comes from rank peers[m] (wall sheets; any pair of ranks)"""
         torch, dist = self.torch, self.dist
         reqs, recvs, keep = [], [], []
+        counts = {}
+
+        def seq(peer, sending):             # k-th message to / from this peer inside one exchange: its own tag
+            k = counts.get((peer, sending), 0)
+            counts[(peer, sending)] = k + 1
+            return k
+        self._seq = seq
         for m in range(n):
             peer, ns, nr = peers[m], send_count[m], recv_count[m]
             if ns:
                 t = torch.from_numpy(self._get(send[m], 0, ns))
                 keep.append(t)
-                reqs.append(dist.isend(t, peer, group=self.group, tag=1000))
+                reqs.append(dist.isend(t, peer, group=self.group, tag=1000 + self._seq(peer, True)))
             if nr:
                 r = torch.empty(nr, dtype=torch.float32)
-                reqs.append(dist.irecv(r, peer, group=self.group, tag=1000))
+                reqs.append(dist.irecv(r, peer, group=self.group, tag=1000 + self._seq(peer, False)))
                 recvs.append((recv[m], r))
         for r in reqs:
             r.wait()

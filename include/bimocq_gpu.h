@@ -293,6 +293,11 @@ const char *fl_jacobi_kernel_name(void);
 /* precondition check of FL_OPT_MAP_QUARTER_FP32: 1 when every value of x, y, z is 0 or in [h/256, 1024 h]; blocking;
  * z-slab ranks get one common answer */
 int  gpu_maps_quarter_safe(const float *x, const float *y, const float *z, float h, int ni, int nj, int nk);
+/* the same check without a pass over the maps: while armed, gpu_solve_backwardDMC (word 0) and gpu_solve_forward (word 1)
+ * flag every value they store that fails the test.  _reset(which) arms the guard and clears a word (which < 0: off);
+ * _read fills ok[0], ok[1] (1 = nothing flagged since the reset); blocking, z-slab ranks get common answers */
+void fl_map_guard_reset(int which);
+void fl_map_guard_read(int ok[2]);
 /* maps <- (i*h, j*h, k*h): the host loop + H2D of MapperBaseGPU::init (Mapping.cpp:306-328) */
 void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk);
 /* device getCFL (BimocqGPUSolver.cpp:348-373): max(1e-4, max|u|,|v|,|w|); blocking */
@@ -445,6 +450,9 @@ typedef struct fl_box { int x0, x1, y0, y1, z0, z1; } fl_box;   /* half-open, GL
 void fl_box_pack(const float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed);
 /* the inverse, into `field`; packed == NULL fills the boxes with NaN (a cell the plan missed must not pass for data) */
 void fl_box_unpack(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, const float *packed);
+/* the boxes straight from one field to another with the same rows that holds other global planes: dst(cell) <- src(cell) */
+void fl_box_copy(const float *src, int nbi, int nbj, int nk_src, int koff_src, float *dst, int nk_dst, int koff_dst,
+                 const fl_box *boxes, int nboxes);
 /* n point-to-point messages in one RCCL group on the halo stream: send[m] (send_count[m] floats) goes to rank peers[m],
  * recv[m] (recv_count[m] floats) comes from it; a count may be 0.  Ordered after the compute work queued so far; the
  * compute stream waits for the transfers.  Peers need not be z-neighbours (xGMI is a full mesh: one link per pair). */

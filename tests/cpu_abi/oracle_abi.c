@@ -213,13 +213,30 @@ void fl_box_pack(const float *field, int nbi, int nbj, int nk_field, int koff, c
 { box_copy((float *)field, nbi, nbj, nk_field, koff, boxes, nboxes, packed, 0); }
 void fl_box_unpack(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, const float *packed)
 { box_copy(field, nbi, nbj, nk_field, koff, boxes, nboxes, (float *)packed, packed ? 1 : 2); }
+void fl_box_copy(const float *src, int nbi, int nbj, int nk_src, int koff_src, float *dst, int nk_dst, int koff_dst,
+                 const fl_box *boxes, int nboxes)
+{
+    for (int b = 0; b < nboxes; b++) {
+        const fl_box q = boxes[b];
+        if (q.x0 < 0 || q.y0 < 0 || q.z0 < koff_src || q.z0 < koff_dst || q.x1 > nbi || q.y1 > nbj || q.z1 > koff_src + nk_src || q.z1 > koff_dst + nk_dst) {
+            latch(FL_ERR_BAD_ARGUMENT, "fl_box_copy: box outside a field"); return;
+        }
+        for (int z = q.z0; z < q.z1; z++)
+            for (int y = q.y0; y < q.y1; y++)
+                for (int x = q.x0; x < q.x1; x++)
+                    dst[(size_t)x + (size_t)nbi * ((size_t)y + (size_t)nbj * (size_t)(z - koff_dst))] =
+                        src[(size_t)x + (size_t)nbi * ((size_t)y + (size_t)nbj * (size_t)(z - koff_src))];
+    }
+}
 void gpu_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const float *before, float *dst,
                                const float *mx, const float *my, const float *mz,
                                float h, int ni, int nj, int nk, int axis, float coeff,
                                const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl)
 { orc_accumulate_wall_fixup(src, src_koff, src_nk, before, dst, mx, my, mz, h, ni, nj, nk, axis, coeff, xlist, nxl, ylist, nyl, zlist, nzl); }
 
-/* the stand-in has one arithmetic path: the precondition check may simply say no */
+/* the stand-in has one arithmetic path: the precondition checks may simply say no */
+void fl_map_guard_reset(int which) { (void)which; }
+void fl_map_guard_read(int ok[2]) { if (ok) ok[0] = ok[1] = 0; }
 int gpu_maps_quarter_safe(const float *x, const float *y, const float *z, float h, int ni, int nj, int nk)
 { (void)x; (void)y; (void)z; (void)h; (void)ni; (void)nj; (void)nk; return 0; }
 void gpu_init_maps(float *x, float *y, float *z, float h, int ni, int nj, int nk)

@@ -572,7 +572,7 @@ def test_fused_housekeeping_bits(gm, ni, nj, nk, h):
     bq.check()
 
 
-@pytest.mark.parametrize("nx", [32, 33, 64, 65, 129, 256, 257, 36, 37])
+@pytest.mark.parametrize("nx", [32, 33, 64, 65, 129, 256, 257, 36, 37, 260, 384, 512, 513, 1024, 1025, 772])
 def test_clamp_extrema_box_row_widths(nx):
     """the limiter's marching kernel on rows of 4m floats and of 4m + 1 floats (the u component: unaligned float4
     accesses, the last column fetched by the row's last lane), and the plain kernel on everything else"""
@@ -646,4 +646,103 @@ def test_plane_windows_partition_the_operators(gm, ni, nj, nk, h):
     finally:
         hip.fl_set_option(OPT, 0)
         hip.fl_set_plane_window(-1, -1)
+    bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", [(32, 32, 32, 1.0 / 32), (40, 24, 16, 1.0 / 64)])
+@pytest.mark.parametrize("zero_border", [False, True])
+def test_map_quarter_fp32_option_changes_no_bit(gm, ni, nj, nk, h, zero_border):
+    """FL_OPT_MAP_QUARTER_FP32 (the weight-1/4 lerps of the structured map look-up as one fp32 fma) on maps that pass
+    gpu_maps_quarter_safe -- warped coordinates, optionally with the zeroed border the DMC update leaves --
+    against the oracle, for every operator that stages map tiles: one and two fields, all four staggerings."""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    h = float(np.float32(h))
+    n, nu, nv, nw = F.sizes(ni, nj, nk)
+    vel = F.velocity(ni, nj, nk, h)
+    fwd, back = F.warped_maps(ni, nj, nk, h, 0.8, 0.3), F.warped_maps(ni, nj, nk, h, -0.7, 1.1)
+    if zero_border:
+        for a in back:
+            a3 = a.reshape(nk, nj, ni)
+            keep = a3[2:-2, 2:-2, 2:-2].copy()
+            a3[...] = 0.0
+            a3[2:-2, 2:-2, 2:-2] = keep
+    m = gm(ni, nj, nk, h)
+    dfwd, dback, dvel = dev(*fwd), dev(*back), dev(*vel)
+    assert hip.gpu_maps_quarter_safe(*[x.ptr for x in dback], h, ni, nj, nk) == 1
+    assert hip.gpu_maps_quarter_safe(*[x.ptr for x in dfwd], h, ni, nj, nk) == 1
+    hip.fl_set_option(bq._lib.FL_OPT_MAP_QUARTER_FP32, 1)
+    try:
+        ref = [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+        oracle().orc_advect_velocity(*map(fp, ref), *map(fp, vel), *map(fp, back), h, ni, nj, nk, 0)
+        out = dev(*[np.zeros(c, np.float32) for c in (nu, nv, nw)])
+        m.advectVelocity(*out, *dvel, *dback, False)
+        for r, g in zip(ref, out):
+            assert F.same(r, g.numpy())
+        cur = [F.scalar(ni + 1, nj, nk, 1.1), F.scalar(ni, nj + 1, nk, 1.2), F.scalar(ni, nj, nk + 1, 1.3)]
+        ru, ri, rs = [a.copy() for a in cur], [a.copy() for a in vel], [np.zeros(c, np.float32) for c in (nu, nv, nw)]
+        oracle().orc_compensate_velocity(*map(fp, ru), *map(fp, ri), *map(fp, rs), *map(fp, fwd), *map(fp, back), h, ni, nj, nk, 0)
+        du, di = dev(*cur), dev(*vel)
+        m.compensateVelocity(*du, *di, *dfwd, *dback, False)
+        for r, g in zip(ru + ri, du + di):
+            assert F.same(r, g.numpy())
+        a_init, b_init = F.scalar(ni, nj, nk, 0.4), F.scalar(ni, nj, nk, 1.9, amp=2.0)
+        ra, rb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        oracle().orc_advect_field(fp(ra), fp(a_init), *map(fp, back), h, ni, nj, nk, 0)
+        oracle().orc_advect_field(fp(rb), fp(b_init), *map(fp, back), h, ni, nj, nk, 0)
+        da, db, dai, dbi = dev(np.zeros(n, np.float32), np.zeros(n, np.float32), a_init, b_init)
+        hip.gpu_advect_field2(da.ptr, dai.ptr, db.ptr, dbi.ptr, *[x.ptr for x in dback], h, ni, nj, nk, False)
+        assert F.same(ra, da.numpy()) and F.same(rb, db.numpy())
+        ea, eb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        oracle().orc_compensate_error_field(fp(ra), fp(a_init), fp(ea), *map(fp, fwd), h, ni, nj, nk, 0)
+        oracle().orc_compensate_error_field(fp(rb), fp(b_init), fp(eb), *map(fp, fwd), h, ni, nj, nk, 0)
+        dea, deb = dev(np.zeros(n, np.float32), np.zeros(n, np.float32))
+        hip.gpu_compensate_error_field2(da.ptr, dai.ptr, dea.ptr, db.ptr, dbi.ptr, deb.ptr, *[x.ptr for x in dfwd], h, ni, nj, nk, False)
+        assert F.same(ea, dea.numpy()) and F.same(eb, deb.numpy())
+        oracle().orc_accumulate_field(fp(ea), fp(ra), *map(fp, back), h, ni, nj, nk, 0, -0.5)
+        oracle().orc_accumulate_field(fp(eb), fp(rb), *map(fp, back), h, ni, nj, nk, 0, 2.0)
+        hip.gpu_accumulate_field2(dea.ptr, da.ptr, -0.5, deb.ptr, db.ptr, 2.0, *[x.ptr for x in dback], h, ni, nj, nk, False)
+        assert F.same(ra, da.numpy()) and F.same(rb, db.numpy())
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_MAP_QUARTER_FP32, 0)
+    bq.check()
+
+
+def test_map_value_guards_catch_what_the_fp32_lerps_cannot_take(gm):
+    """gpu_maps_quarter_safe and the guard fused into the map updates (fl_map_guard_*): a NaN, an Inf, a negative or a
+    tiny positive coordinate anywhere in a map says no; ordinary maps (zeros included) say yes"""
+    import ctypes as C
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    ni, nj, nk, h = 32, 32, 32, float(np.float32(1.0 / 32))
+    gm(ni, nj, nk, h)
+    base = F.warped_maps(ni, nj, nk, h, 0.8, 0.3)
+    for bad in (np.nan, np.inf, -1e-3, 1e-30, 40.0):
+        m = [a.copy() for a in base]
+        m[1][12345] = bad
+        d = dev(*m)
+        assert hip.gpu_maps_quarter_safe(*[x.ptr for x in d], h, ni, nj, nk) == 0, bad
+    d = dev(*base)
+    assert hip.gpu_maps_quarter_safe(*[x.ptr for x in d], h, ni, nj, nk) == 1
+    # the fused guard: a DMC sub-step and a forward update on ordinary data flag nothing ...
+    vel = F.velocity(ni, nj, nk, h)
+    dvel, din = dev(*vel), dev(*base)
+    dout = dev(*[np.zeros(ni * nj * nk, np.float32) for _ in range(3)])
+    ok = (C.c_int * 2)()
+    hip.fl_map_guard_reset(0); hip.fl_map_guard_reset(1)
+    hip.gpu_solve_backwardDMC(*[x.ptr for x in dvel], *[x.ptr for x in din], *[x.ptr for x in dout], h, ni, nj, nk, 0.5 * h)
+    hip.gpu_solve_forward(*[x.ptr for x in dvel], *[x.ptr for x in din], h, ni, nj, nk, 0.5 * h, h)
+    hip.fl_map_guard_read(ok)
+    assert list(ok) == [1, 1]
+    # ... a velocity field with a NaN poisons the backward map it touches, and the guard says so; the forward map cannot
+    # be poisoned: traceRK3 clamps every position it returns into [h, (n-1) h] (GPU_kernel.cu:88-89), a NaN included
+    v2 = [a.copy() for a in vel]
+    v2[0][(ni + 1) * nj * 16 + (ni + 1) * 16 + 16] = np.nan
+    dbad = dev(*v2)
+    hip.fl_map_guard_reset(0); hip.fl_map_guard_reset(1)
+    hip.gpu_solve_backwardDMC(*[x.ptr for x in dbad], *[x.ptr for x in din], *[x.ptr for x in dout], h, ni, nj, nk, 0.5 * h)
+    hip.gpu_solve_forward(*[x.ptr for x in dbad], *[x.ptr for x in din], h, ni, nj, nk, 0.5 * h, h)
+    hip.fl_map_guard_read(ok)
+    assert list(ok) == [0, 1]
+    hip.fl_map_guard_reset(-1)
     bq.check()
