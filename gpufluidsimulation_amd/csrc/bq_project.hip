@@ -622,6 +622,210 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
     }
 }
 
+// ---- the two-row fused kernel again, written for the instruction count --------------------------------------------
+// jacobi_march2r_kernel is bound by instruction ISSUE, not by memory: one wave per SIMD issues one VALU instruction
+// per ~4 cycles, and the compiler's rendering of that kernel spends ~680 instructions per plane (64-bit address
+// arithmetic for every load, ~120 register moves to rotate planes and to pair operands, selects for boundaries that a
+// wave almost never has).  Same algorithm, same expression per value, different plumbing:
+//   * loads and stores through buffer descriptors: per-thread row offsets computed once (VGPR), the plane offset in an
+//     SGPR -- no address arithmetic in the loop;
+//   * every plane set lives in a ring of four buffers indexed by (plane mod 4); the loop is unrolled four times so that
+//     all ring indices are compile-time: nothing is ever moved to rotate planes;
+//   * float4 columns as two float2 halves (clang ext vectors -> v_pk_add_f32 / v_pk_mul_f32);
+//   * boundary rows are a property of the BLOCK (template flag EDGE: only the first and last row blocks pay the
+//     selects), boundary planes one wave-uniform branch;
+//   * x-boundary columns are stored too: they hold L0's value (a sweep never changes them), which is what `out`
+//     already holds there (the fused kernels' precondition: both buffers carry the same boundary layer).
+// Rows of one wave (nx <= 256); wider rows keep jacobi_march2r_kernel<.., true>.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct R4 { v2f a, b; };                                    // (x, y), (z, w) of one float4 column
+
+// 16-byte buffer loads / stores straight from the LLVM intrinsics (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128
+// lowers to a ONE-dword load): resource descriptor in SGPRs, 32-bit byte offset per thread, plane offset in an SGPR
+__device__ v4f bq_buffer_load_x4(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void bq_buffer_store_x4(v4f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ __forceinline__ v4i make_rsrc4(const void *ptr, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)ptr;
+    return v4i{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ R4 ld_r4(v4i rs, unsigned voff, unsigned soff)
+{
+    const v4f v = bq_buffer_load_x4(rs, (int)voff, (int)soff, 0);
+    return R4{v2f{v.x, v.y}, v2f{v.z, v.w}};
+}
+__device__ float bq_buffer_load_x1(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ __forceinline__ float ld_f(v4i rs, unsigned voff, unsigned soff) { return bq_buffer_load_x1(rs, (int)voff, (int)soff, 0); }
+__device__ __forceinline__ void st_r4(R4 v, v4i rs, unsigned voff, unsigned soff)
+{
+    bq_buffer_store_x4(v4f{v.a.x, v.a.y, v.b.x, v.b.y}, rs, (int)voff, (int)soff, 0);
+}
+
+// jacobi_kernel's expression (GPU_kernel.cu:1833) on a float4 column: ((((((l + r) + f) + b) + d) + u) + alpha div) beta
+// WIDE (rows of several waves): the x-neighbour of a wave's first / last lane lives in another wave; `outside` is its
+// value, supplied by that lane itself (edgeL / edgeR mark the two lanes)
+template <bool WIDE = false>
+__device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, float alpha, float beta, bool xlo, bool xhi,
+                                     float outside = 0.f, bool edgeL = false, bool edgeR = false)
+{
+    float left = lane_up(ce.b.y), right = lane_down(ce.a.x);
+    if (WIDE) {
+        if (edgeL) left = outside;
+        if (edgeR) right = outside;
+    }
+    v2f s0 = v2f{left + ce.a.y, ce.a.x + ce.b.x};
+    v2f s1 = v2f{ce.a.y + ce.b.y, ce.b.x + right};
+    s0 = s0 + fr.a; s1 = s1 + fr.b;
+    s0 = s0 + bk.a; s1 = s1 + bk.b;
+    s0 = s0 + dn.a; s1 = s1 + dn.b;
+    s0 = s0 + up.a; s1 = s1 + up.b;
+    s0 = s0 + alpha * dv.a; s1 = s1 + alpha * dv.b;
+    s0 = s0 * beta; s1 = s1 * beta;
+    if (xlo) s0.x = ce.a.x;
+    if (xhi) s1.y = ce.b.y;
+    return R4{s0, s1};
+}
+
+template <bool EDGE, bool WIDE>
+__global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                            float *__restrict__ out, int nx, int ny, int nz,
+                                                            int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
+{
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
+    const int by = b % nby, bz = b / nby;
+    const int rows = 256 / cw;
+    // EDGE is a property of the block: it is launched as two grids (interior row blocks / the first and last one)
+    const int c = threadIdx.x % cw, r = threadIdx.x / cw;
+    const int xraw = 4 * c, j = 2 * (by * rows + r);
+    const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
+    const int r0 = bz < rg.nchA ? rg.k0a + bz * kchunk : rg.k0b + (bz - rg.nchA) * kchunk, r1 = bz < rg.nchA ? rg.k1a : rg.k1b;
+    const int kbeg = max(kA, r0), kend = min(min(kB, r1), r0 + kchunk);
+    if (kbeg >= kend) return;
+    const bool xok = xraw < nx;
+    const bool active0 = xok && j >= 1 && j <= ny - 2, active1 = xok && j + 1 >= 1 && j + 1 <= ny - 2;
+    const int x = xok ? xraw : nx - 4;                              // out-of-range lanes, rows, planes: clamped into the array
+    const bool xlo = x == 0, xhi = x + 3 == nx - 1;
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 4u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    unsigned vo[6];                                                 // byte offsets of this thread's column in rows j-2 .. j+3
+    bool rowb[4];                                                   // rows j-1 .. j+2 are boundary rows (keep L0)
+#pragma unroll
+    for (int a = 0; a < 6; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 2 + a, 0), ny - 1)) * 4u;
+#pragma unroll
+    for (int a = 0; a < 4; a++) rowb[a] = EDGE && (j - 1 + a <= 0 || j - 1 + a >= ny - 1);
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 4u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    // WIDE: the first / last lane of a wave looks after the column just outside its wave (xe) -- it needs that column's
+    // L0 on rows j-1 .. j+2 (x-neighbour of our own first sweep) and its L1 on rows j, j+1 (x-neighbour of our second
+    // sweep), which it evaluates itself from that column's own neighbours (outer x-neighbour xo, rows, planes, div).
+    // All other lanes run the same few scalar loads on their own column; what they get is not used.
+    const int lane = threadIdx.x & 63;
+    const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 4 < nx;
+    const int xe = edgeL ? xraw - 1 : (edgeR ? xraw + 4 : x), xo = edgeL ? xe - 1 : (edgeR ? xe + 1 : x);
+    const bool xe_boundary = xe <= 0 || xe >= nx - 1;
+    unsigned ve[4], vx[2];
+#pragma unroll
+    for (int a = 0; a < 4; a++) ve[a] = ((unsigned)min(max(xe, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 4u;
+#pragma unroll
+    for (int a = 0; a < 2; a++) vx[a] = ((unsigned)min(max(xo, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j + a, 0), ny - 1)) * 4u;
+    // E[.][0..3]: p(xe) on rows j-1 .. j+2, ring by plane like L0; Eo / Eb: p(xo) and div(xe) on rows j, j+1 of plane q
+    // (ring of 2: q live, q+1 arriving); X: the outside column's L1 on rows j, j+1 (ring of 2: plane q-1 live, q made)
+    float E[4][4], Eo[2][2], Eb[2][2], X[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) { X[0][a] = 0.f; X[1][a] = 0.f; }
+
+    // rings indexed by (t & 3), t = q - (kbeg - 1) the iteration number:
+    //   L0[.][0..3]  p on rows j-1 .. j+2 of a plane      (live: planes q-1, q, q+1; q+2 arriving)
+    //   H[.][0..1]   p on rows j-2, j+3 of a plane        (ring of 2: plane q live, q+1 arriving)
+    //   L1[.][0..3]  first sweep on rows j-1 .. j+2        (live: planes q-1, q-2 (rows j, j+1); q being made)
+    //   D[.][0..3]   div on rows j-1 .. j+2                (live: planes q, q-1 (rows j, j+1); q+1 arriving)
+    R4 L0[4][4], H[2][2], L1[4][4], D[4][4];
+    const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) L1[a][bb] = zero;
+    int q = kbeg - 1;
+    {
+        const unsigned pm = po(q - 1), pc = po(q), pn = po(q + 1);
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            L0[3][a] = ld_r4(rp, vo[a + 1], pm);                    // t = -1
+            L0[0][a] = ld_r4(rp, vo[a + 1], pc);                    // t = 0
+            L0[1][a] = ld_r4(rp, vo[a + 1], pn);                    // t = 1
+            D[0][a] = ld_r4(rd, vo[a + 1], pc);
+        }
+        H[0][0] = ld_r4(rp, vo[0], pc); H[0][1] = ld_r4(rp, vo[5], pc);
+        if (WIDE) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) { E[3][a] = ld_f(rp, ve[a], pm); E[0][a] = ld_f(rp, ve[a], pc); E[1][a] = ld_f(rp, ve[a], pn); }
+#pragma unroll
+            for (int a = 0; a < 2; a++) { Eo[0][a] = ld_f(rp, vx[a], pc); Eb[0][a] = ld_f(rd, ve[a + 1], pc); }
+        }
+    }
+    // one plane.  T = t & 3 (compile time)
+#define BQ_LEAN_PHASE(T)                                                                                            \
+    {                                                                                                               \
+        constexpr int im = (T + 3) & 3, ic = T, in_ = (T + 1) & 3, ia = (T + 2) & 3;      /* L0: q-1, q, q+1, q+2 */    \
+        constexpr int hc = T & 1, hn = (T + 1) & 1;                                                                \
+        constexpr int m1 = T, mp = (T + 3) & 3, mpp = (T + 2) & 3;                         /* L1: q, q-1, q-2 */        \
+        constexpr int dc = T, dn_ = (T + 1) & 3, dp = (T + 3) & 3;                         /* D: q, q+1, q-1 */         \
+        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[dn_][a] = ld_r4(rd, vo[a + 1], pb); } \
+        H[hn][0] = ld_r4(rp, vo[0], pb); H[hn][1] = ld_r4(rp, vo[5], pb);                                           \
+        if (WIDE) {                                                                                                 \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ld_f(rp, ve[a], pa);                              \
+            _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[hn][a] = ld_f(rp, vx[a], pb); Eb[hn][a] = ld_f(rd, ve[a + 1], pb); } \
+        }                                                                                                           \
+        const bool qb = q < kA || q >= kB;                                                                          \
+        if (qb) {                                               /* a boundary plane keeps L0 */                      \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) L1[m1][a] = L0[ic][a];                                      \
+        } else {                                                                                                    \
+            L1[m1][0] = jac_r4<WIDE>(L0[ic][0], H[hc][0], L0[ic][1], L0[im][0], L0[in_][0], D[dc][0], alpha, beta, xlo, xhi, E[ic][0], edgeL, edgeR);   \
+            L1[m1][1] = jac_r4<WIDE>(L0[ic][1], L0[ic][0], L0[ic][2], L0[im][1], L0[in_][1], D[dc][1], alpha, beta, xlo, xhi, E[ic][1], edgeL, edgeR);  \
+            L1[m1][2] = jac_r4<WIDE>(L0[ic][2], L0[ic][1], L0[ic][3], L0[im][2], L0[in_][2], D[dc][2], alpha, beta, xlo, xhi, E[ic][2], edgeL, edgeR);  \
+            L1[m1][3] = jac_r4<WIDE>(L0[ic][3], L0[ic][2], H[hc][1], L0[im][3], L0[in_][3], D[dc][3], alpha, beta, xlo, xhi, E[ic][3], edgeL, edgeR);   \
+            if (EDGE) {                                                                                             \
+                _Pragma("unroll") for (int a = 0; a < 4; a++)                                                        \
+                    if (rowb[a]) L1[m1][a] = L0[ic][a];                                                             \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (WIDE) {                                             /* the outside column's own first sweep, rows j, j+1 */ \
+            _Pragma("unroll") for (int rr = 0; rr < 2; rr++) {                                                       \
+                const float own = edgeL ? L0[ic][rr + 1].a.x : L0[ic][rr + 1].b.y;                                   \
+                const float l = edgeL ? Eo[hc][rr] : own, rg2 = edgeL ? own : Eo[hc][rr];                           \
+                const float v = (l + rg2 + E[ic][rr] + E[ic][rr + 2] + E[im][rr + 1] + E[in_][rr + 1] + alpha * Eb[hc][rr]) * beta; \
+                const bool keep = qb || xe_boundary || (EDGE && rowb[rr + 1]) || (j + rr <= 0 || j + rr >= ny - 1);  \
+                X[hc][rr] = keep ? E[ic][rr + 1] : v;                                                               \
+            }                                                                                                       \
+        }                                                                                                           \
+        const int k = q - 1;                                                                                        \
+        if (k >= kbeg && k < kend) {                                                                                \
+            const R4 o0 = jac_r4<WIDE>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[m1][1], D[dp][1], alpha, beta, xlo, xhi, X[hn][0], edgeL, edgeR); \
+            const R4 o1 = jac_r4<WIDE>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[m1][2], D[dp][2], alpha, beta, xlo, xhi, X[hn][1], edgeL, edgeR); \
+            const unsigned pk = pstride * (unsigned)k;                                                              \
+            if (active0) st_r4(o0, ro, vo[2], pk);                                                                  \
+            if (active1) st_r4(o1, ro, vo[3], pk);                                                                  \
+        }                                                                                                           \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        BQ_LEAN_PHASE(0)
+        if (q > kend) break;
+        BQ_LEAN_PHASE(1)
+        if (q > kend) break;
+        BQ_LEAN_PHASE(2)
+        if (q > kend) break;
+        BQ_LEAN_PHASE(3)
+        if (q > kend) break;
+    }
+#undef BQ_LEAN_PHASE
+}
+
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
 // update_residual_kernel / calc_poisson_value arithmetic (GPU_kernel.cu:1048-1060,1239-1249);
 // the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
@@ -829,6 +1033,14 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
         if (pays || rt().opt_jacobi_rows == 2) {
             const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kc)};
             const int nbz2 = rg.nchA + chunks_of(lenB, kc);
+            if (rt().opt_jacobi_rows != 3) {
+                // the lean rendering of the same kernel; FL_OPT_JACOBI_ROWS = 3 keeps the older one for A/B timing
+                if (wide) jacobi_lean2r_kernel<true, true><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                else      jacobi_lean2r_kernel<true, false><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                BQ_LAUNCH_CHECK("jacobi_lean2r_kernel");
+                g_last_pair_kernel = "jacobi_lean2r_kernel";
+                return true;
+            }
             if (wide) jacobi_march2r_kernel<4, true><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
             else      jacobi_march2r_kernel<4, false><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
             BQ_LAUNCH_CHECK("jacobi_march2r_kernel");

@@ -76,7 +76,7 @@ def test_512_production_kernels_equal_generic_kernels(tmp_path):
         finally:
             lib.fl_set_option(L_.FL_OPT_JACOBI_VARIANT, 0); lib.fl_set_option(L_.FL_OPT_JACOBI_FUSE, 1)
             lib.fl_set_option(L_.FL_OPT_STRUCTURED_MAPS, 1)
-    assert kernel == "jacobi_march2r_kernel", kernel                      # the WIDE two-row kernel did run
+    assert kernel == "jacobi_lean2r_kernel", kernel                       # the two-row fused kernel on rows of two waves did run
     for k in res["production"]:
         a, b = res["production"][k], res["generic"][k]
         assert np.isfinite(a).all(), k
