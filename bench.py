@@ -435,9 +435,12 @@ def main():
                             "frac_traffic": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                             "compulsory_bytes_per_launch": int(compulsory),
                             "working_set": ("infinity-cache" if resident else "hbm"),
-                            "bound_note": (f"p, p', div = {compulsory / 1e6:.0f} MB fit the 256 MiB Infinity Cache: the launch is bound "
-                                           "by the fabric/Infinity Cache, not by DRAM; the HBM peak is the yardstick BASELINE names"
-                                           if resident else f"p, p', div = {compulsory / 1e6:.0f} MB: HBM-resident"),
+                            "bound_note": ((f"p, p', div = {compulsory / 1e6:.0f} MB fit the 256 MiB Infinity Cache: the launch is bound "
+                                            "by the fabric/Infinity Cache, not by DRAM; the HBM peak is the yardstick BASELINE names"
+                                            if resident else f"p, p', div = {compulsory / 1e6:.0f} MB: HBM-resident")
+                                           + (f"; {spl:.2f} sweeps per launch: a fused launch moves ONE sweep's bytes, so `frac` falls as "
+                                              "more sweeps are fused while the time per sweep (us_per_sweep) improves -- the three-sweep "
+                                              "kernel is bound by instruction issue at one wave per SIMD, not by memory" if spl > 2.5 else "")),
                             "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
                                                   "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                   "note": "SURVEY 8(d): 12 B/voxel/SWEEP x sweeps per launch -- the bytes unfused "

@@ -7,6 +7,7 @@
 // registers, and moves everything as 16-byte vectors; see DESIGN.md "Jacobi kernel".
 // Summation order is the reference's (GPU_kernel.cu:1834), so results are bit-identical.
 #include "bq_device.hip.h"
+#include <type_traits>
 #include "bq_host.h"
 #include <algorithm>
 #include <vector>
@@ -688,7 +689,7 @@ __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, f
     return R4{s0, s1};
 }
 
-template <bool EDGE, bool WIDE>
+template <bool WIDE>
 __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                             float *__restrict__ out, int nx, int ny, int nz,
                                                             int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
@@ -699,7 +700,10 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
     const int by = b % nby, bz = b / nby;
     const int rows = 256 / cw;
     // EDGE is a property of the block: it is launched as two grids (interior row blocks / the first and last one)
-    const int c = threadIdx.x % cw, r = threadIdx.x / cw;
+    // a wave holds one row pair when rows are at least one wave long: the row index is then wave-uniform, and telling
+    // the compiler so turns the boundary-row selects into scalar branches that are almost never taken
+    const int c = threadIdx.x % cw;
+    const int r = cw >= 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cw) : (int)threadIdx.x / cw;
     const int xraw = 4 * c, j = 2 * (by * rows + r);
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
     const int r0 = bz < rg.nchA ? rg.k0a + bz * kchunk : rg.k0b + (bz - rg.nchA) * kchunk, r1 = bz < rg.nchA ? rg.k1a : rg.k1b;
@@ -716,7 +720,9 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
 #pragma unroll
     for (int a = 0; a < 6; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 2 + a, 0), ny - 1)) * 4u;
 #pragma unroll
-    for (int a = 0; a < 4; a++) rowb[a] = EDGE && (j - 1 + a <= 0 || j - 1 + a >= ny - 1);
+    for (int a = 0; a < 4; a++) rowb[a] = j - 1 + a <= 0 || j - 1 + a >= ny - 1;
+    // only the first and the last row block can hold a boundary row: everybody else runs the loop without the selects
+    const bool edge_block = 2 * by * rows - 1 <= 0 || 2 * (by * rows + rows - 1) + 2 >= ny - 1;
     const unsigned pstride = (unsigned)nx * (unsigned)ny * 4u;
     auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
     // WIDE: the first / last lane of a wave looks after the column just outside its wave (xe) -- it needs that column's
@@ -743,6 +749,8 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
     //   H[.][0..1]   p on rows j-2, j+3 of a plane        (ring of 2: plane q live, q+1 arriving)
     //   L1[.][0..3]  first sweep on rows j-1 .. j+2        (live: planes q-1, q-2 (rows j, j+1); q being made)
     //   D[.][0..3]   div on rows j-1 .. j+2                (live: planes q, q-1 (rows j, j+1); q+1 arriving)
+    auto run = [&](auto EDGE_T) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
     R4 L0[4][4], H[2][2], L1[4][4], D[4][4];
     const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
@@ -823,7 +831,124 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         BQ_LEAN_PHASE(3)
         if (q > kend) break;
     }
+    };
+    if (edge_block) run(std::true_type{}); else run(std::false_type{});
 #undef BQ_LEAN_PHASE
+}
+
+// ---- THREE sweeps per launch (rows of one wave, whole array) ---------------------------------------------------------
+// With the lean plumbing the two-sweep kernel is bound by the fabric again (6.9 TB/s of real traffic at 256^3); what is
+// left is to move fewer bytes per sweep.  Same scheme, one level deeper: a thread owns the float4 columns of rows j, j+1
+// and keeps, in rings of four planes with compile-time indices,
+//     L0 on rows j-2 .. j+3 (+ rows j-3, j+4 of the centre plane),  L1 on rows j-2 .. j+3,  L2 on rows j-1 .. j+2,
+//     div on rows j-2 .. j+3;
+// per plane q it makes L1(q) on six rows, L2(q-1) on four, L3(q-2) on its two -- 12 evaluations and 14 float4 loads for
+// two outputs of three sweeps (two sweeps: 6 and 10 for two).  ~400 registers: one wave per SIMD.  Every value is
+// jacobi_kernel's expression, planes and rows outside the interior keep their input through all three levels, so the
+// result is bit-identical to three single sweeps.  Preconditions as for the two-sweep kernels.
+__global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                            float *__restrict__ out, int nx, int ny, int nz,
+                                                            int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
+{
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
+    const int by = b % nby, bz = b / nby;
+    const int rows = 256 / cw;
+    const int c = threadIdx.x % cw;
+    const int r = cw >= 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cw) : (int)threadIdx.x / cw;   // (see the two-sweep kernel)
+    const int xraw = 4 * c, j = 2 * (by * rows + r);
+    const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;
+    const bool xok = xraw < nx;
+    const bool active0 = xok && j >= 1 && j <= ny - 2, active1 = xok && j + 1 >= 1 && j + 1 <= ny - 2;
+    const int x = xok ? xraw : nx - 4;
+    const bool xlo = x == 0, xhi = x + 3 == nx - 1;
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 4u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    unsigned vo[8];                                                 // rows j-3 .. j+4
+    bool rowb[6];                                                   // rows j-2 .. j+3 are boundary rows
+#pragma unroll
+    for (int a = 0; a < 8; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 3 + a, 0), ny - 1)) * 4u;
+#pragma unroll
+    for (int a = 0; a < 6; a++) rowb[a] = j - 2 + a <= 0 || j - 2 + a >= ny - 1;
+    const bool edge_block = 2 * by * rows - 2 <= 0 || 2 * (by * rows + rows - 1) + 3 >= ny - 1;
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 4u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    auto run = [&](auto EDGE_T) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
+    R4 L0[4][6], H[2][2], L1[4][6], L2[4][4], D[4][6];
+    const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+#pragma unroll
+        for (int bb = 0; bb < 6; bb++) { L1[a][bb] = zero; D[a][bb] = zero; }
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) L2[a][bb] = zero;
+    }
+    int q = kbeg - 2;
+    {
+        const unsigned pm = po(q - 1), pc = po(q), pn = po(q + 1);
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            L0[3][a] = ld_r4(rp, vo[a + 1], pm);
+            L0[0][a] = ld_r4(rp, vo[a + 1], pc);
+            L0[1][a] = ld_r4(rp, vo[a + 1], pn);
+            D[0][a] = ld_r4(rd, vo[a + 1], pc);
+        }
+        H[0][0] = ld_r4(rp, vo[0], pc); H[0][1] = ld_r4(rp, vo[7], pc);
+    }
+#define BQ_LEAN3_PHASE(T)                                                                                           \
+    {                                                                                                               \
+        constexpr int im = (T + 3) & 3, ic = T, in_ = (T + 1) & 3, ia = (T + 2) & 3;      /* L0: q-1, q, q+1, q+2 */    \
+        constexpr int hc = T & 1, hn = (T + 1) & 1;                                                                \
+        constexpr int a0 = T, a1 = (T + 3) & 3, a2 = (T + 2) & 3;                          /* L1: q, q-1, q-2 */        \
+        constexpr int b1 = (T + 3) & 3, b2 = (T + 2) & 3, b3 = (T + 1) & 3;                /* L2: q-1, q-2, q-3 */      \
+        constexpr int d0 = T, dn_ = (T + 1) & 3, d1 = (T + 3) & 3, d2 = (T + 2) & 3;       /* D: q, q+1, q-1, q-2 */    \
+        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        _Pragma("unroll") for (int a = 0; a < 6; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[dn_][a] = ld_r4(rd, vo[a + 1], pb); } \
+        H[hn][0] = ld_r4(rp, vo[0], pb); H[hn][1] = ld_r4(rp, vo[7], pb);                                           \
+        if (q < kA || q >= kB) {                                /* first sweep on plane q, rows j-2 .. j+3 */        \
+            _Pragma("unroll") for (int a = 0; a < 6; a++) L1[a0][a] = L0[ic][a];                                      \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < 6; a++) {                                                          \
+                const R4 fr = a == 0 ? H[hc][0] : L0[ic][a == 0 ? 0 : a - 1], bk = a == 5 ? H[hc][1] : L0[ic][a == 5 ? 5 : a + 1]; \
+                L1[a0][a] = jac_r4(L0[ic][a], fr, bk, L0[im][a], L0[in_][a], D[d0][a], alpha, beta, xlo, xhi);       \
+                if (EDGE && rowb[a]) L1[a0][a] = L0[ic][a];                                                         \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (q - 1 < kA || q - 1 >= kB) {                        /* second sweep on plane q-1, rows j-1 .. j+2 */     \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) L2[b1][a] = L1[a1][a + 1];                                  \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                          \
+                L2[b1][a] = jac_r4(L1[a1][a + 1], L1[a1][a], L1[a1][a + 2], L1[a2][a + 1], L1[a0][a + 1], D[d1][a + 1], alpha, beta, xlo, xhi); \
+                if (EDGE && rowb[a + 1]) L2[b1][a] = L1[a1][a + 1];                                                 \
+            }                                                                                                       \
+        }                                                                                                           \
+        const int k = q - 2;                                                                                        \
+        if (k >= kbeg && k < kend) {                            /* third sweep on plane q-2, rows j, j+1: stored */  \
+            const R4 o0 = jac_r4(L2[b2][1], L2[b2][0], L2[b2][2], L2[b3][1], L2[b1][1], D[d2][2], alpha, beta, xlo, xhi); \
+            const R4 o1 = jac_r4(L2[b2][2], L2[b2][1], L2[b2][3], L2[b3][2], L2[b1][2], D[d2][3], alpha, beta, xlo, xhi); \
+            const unsigned pk = pstride * (unsigned)k;                                                              \
+            if (active0) st_r4(o0, ro, vo[3], pk);                                                                  \
+            if (active1) st_r4(o1, ro, vo[4], pk);                                                                  \
+        }                                                                                                           \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        BQ_LEAN3_PHASE(0)
+        if (q > kend + 1) break;
+        BQ_LEAN3_PHASE(1)
+        if (q > kend + 1) break;
+        BQ_LEAN3_PHASE(2)
+        if (q > kend + 1) break;
+        BQ_LEAN3_PHASE(3)
+        if (q > kend + 1) break;
+    }
+    };
+    if (edge_block) run(std::true_type{}); else run(std::false_type{});
+#undef BQ_LEAN3_PHASE
 }
 
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
@@ -1035,8 +1160,8 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
             const int nbz2 = rg.nchA + chunks_of(lenB, kc);
             if (rt().opt_jacobi_rows != 3) {
                 // the lean rendering of the same kernel; FL_OPT_JACOBI_ROWS = 3 keeps the older one for A/B timing
-                if (wide) jacobi_lean2r_kernel<true, true><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
-                else      jacobi_lean2r_kernel<true, false><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                if (wide) jacobi_lean2r_kernel<true><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                else      jacobi_lean2r_kernel<false><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
                 BQ_LAUNCH_CHECK("jacobi_lean2r_kernel");
                 g_last_pair_kernel = "jacobi_lean2r_kernel";
                 return true;
@@ -1073,6 +1198,35 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     else      jacobi_march2_kernel<4, false><<<nby * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby, kchunk, alpha, beta, slab_of(nk), rg);
     BQ_LAUNCH_CHECK("jacobi_march2_kernel");
     g_last_pair_kernel = "jacobi_march2_kernel";
+    return true;
+}
+
+// Three sweeps in one launch (in -> out holds iterate +3), whole array, rows of one wave; false = not applicable
+static bool jacobi_sweep_triple(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
+{
+    if (ni < 3 || nj < 4 || nk < 3) return false;
+    const int variant = rt().opt_jacobi_variant;
+    if ((variant != 0 && variant != 3) || rt().opt_jacobi_rows == 1 || rt().opt_jacobi_rows == 3) return false;
+    if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
+    if (g_klo != 0 || g_khi < nk) return false;              // plane ranges: the two-sweep kernels
+    int cw = 16;
+    while (cw * 4 < ni) cw *= 2;
+    const int rows = 256 / cw;
+    const int nby2 = (nj + 2 * rows - 1) / (2 * rows);
+    int gcd = nby2, rem = 256;
+    while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+    const int quantum = 256 / gcd;                           // chunk counts that fill the 256 CUs in whole rounds
+    const int target = 32;
+    int nchunks = ((2 * nk + target) / (2 * target) + quantum / 2) / quantum * quantum;
+    if (nchunks < quantum) nchunks = quantum;
+    int kc = (nk + nchunks - 1) / nchunks;
+    if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
+    if (kc < 16 && rt().opt_jacobi_rows != 2) return false;  // chunks too short to pay for four warm-up planes
+    if (kc < 4) kc = 4;
+    const int nbz = (nk + kc - 1) / kc;
+    jacobi_lean3r_kernel<<<nby2 * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk));
+    BQ_LAUNCH_CHECK("jacobi_lean3r_kernel");
+    g_last_pair_kernel = "jacobi_lean3r_kernel";
     return true;
 }
 
@@ -1153,6 +1307,11 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *p_temp, int ni, int nj,
     ProfileSpan span;
     const bool prof = sweeps > 0 && profile_begin(span);      // FL_OPT_PROFILE_JACOBI (the z-slab projection runs through here)
     // FL_OPT_JACOBI_FUSE == 2: the caller vouches that p and p_temp carry the same boundary layer
+    // (FL_OPT_JACOBI_FUSE: 2 = pairs and triples, 4 = pairs only)
+    while (rt().opt_jacobi_fuse >= 2 && rt().opt_jacobi_fuse != 4 && s + 3 <= sweeps && jacobi_sweep_triple(in, div, out, ni, nj, nk, alpha, beta)) {
+        float *t = in; in = out; out = t;          // iterate +3 sits in the former `out`
+        s += 3; launches++;
+    }
     while (rt().opt_jacobi_fuse >= 2 && s + 2 <= sweeps && jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta)) {
         float *t = in; in = out; out = t;          // iterate +2 sits in the former `out`
         s += 2; launches++;

@@ -44,10 +44,11 @@ def main():
     res = {v: [] for v in variants}
     for rep in range(a.reps + 1):
         for v in variants:
-            # variant 4 = two sweeps per launch (fused kernel) with kchunk v[2]
-            fused = v[0] == 4
+            # variant 4 = fused kernels (three sweeps per launch where that kernel applies, else two) with kchunk v[2];
+            # variant 5 = two sweeps per launch only
+            fused = v[0] in (4, 5)
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0 if fused else v[0])
-            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2 if fused else 0)
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, (2 if v[0] == 4 else 4) if fused else 0)
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, v[1])   # fused: 1 = one-plane prefetch, else two planes ahead
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0 if fused else v[2])
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, v[2] if fused else 0)
