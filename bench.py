@@ -198,10 +198,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.transport == "rccl" and not force_fail:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:                                   # (the fallback test hook shares one GPU: no NCCL group possible)
-            dist.init_process_group("gloo")
+        # torch.distributed is the CONTROL plane only (rendezvous, the unique id, barriers, the max over ranks of the
+        # elapsed time): gloo.  The DATA plane -- ghost planes, wall sheets, the scalar all-reduces inside a step -- is
+        # the library's own RCCL communicator over xGMI (csrc/bq_halo.hip), created below from an id that travels over
+        # this group.  (One RCCL instance per process: torch's bundled copy is never initialised.)
+        dist.init_process_group("gloo")
 
     import gpufluidsimulation_amd as bq
     from gpufluidsimulation_amd import transport
@@ -234,7 +235,7 @@ def main():
             # RCCL neighbour exchange is the product path.  If its set-up fails on any rank (binding self-test,
             # unique id, communicator), all ranks agree over gloo to fall back to the host-staged transport, so that
             # a broken fabric yields a slow, clearly labelled number instead of none.
-            side = dist.new_group(backend="gloo")
+            side = None                         # (the default group is gloo already)
             failure = ""
             try:
                 if force_fail:
@@ -293,7 +294,7 @@ def main():
         lib.fl_sync()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(group=side) if (side is not None and args.transport == "host") else dist.barrier()
+            dist.barrier()
         lib.fl_sync()
 
     frame = 0
@@ -341,8 +342,8 @@ def main():
         lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
         extra = (extra_steps, el_extra, el_fast)
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.transport == "rccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=side if (side is not None and args.transport == "host") else None)
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
     voxels = nx * ny * nz_global                # the whole job's grid: every rank advances its slab of it once per step
@@ -454,7 +455,7 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     s.close()
     if dist is not None:
-        dist.barrier(group=side) if (side is not None and args.transport == "host") else dist.barrier()
+        dist.barrier()
         lib.fl_comm_destroy()
         dist.destroy_process_group()
     if rank == 0:

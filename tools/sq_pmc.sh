@@ -1,6 +1,9 @@
 #!/bin/bash
 # tools/sq_pmc.sh <tag> [kernel-substring ...] -- one SQ counter pass over a short bench run, per-kernel means.
-# (TA_* counters hung the profiler on this pool: SQ block only.)
+# SQ block only.  Round 1 also asked for six TA_* counters (_sum and plain forms) in ONE pass: rocprofv3 aborted with
+# "rocprofiler_create_counter_config ... error 38: Request exceeds the capabilities of the hardware to collect" (signal 6 with a
+# dispatch incomplete, gpurun_out/gpmc_a_2.log) -- too many counters for the TA block's slots, not a hang of the pool.  TA / TCP
+# counters go in their own passes of at most two per block: tools/ta_pmc.sh.
 set -e
 tag=${1:-q}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
