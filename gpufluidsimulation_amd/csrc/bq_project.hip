@@ -689,19 +689,19 @@ __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, f
     return R4{s0, s1};
 }
 
-template <bool WIDE>
+// PF: how many planes ahead the loads run (1 or 2).  The rings hold 3 + PF planes and the loop is unrolled 3 + PF times.
+template <bool WIDE, int PF>
 __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                             float *__restrict__ out, int nx, int ny, int nz,
                                                             int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
+    constexpr int P = 3 + PF;                                       // ring period
     const int nblk = gridDim.x;
     int b = blockIdx.x;
     if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
     const int by = b % nby, bz = b / nby;
     const int rows = 256 / cw;
-    // EDGE is a property of the block: it is launched as two grids (interior row blocks / the first and last one)
-    // a wave holds one row pair when rows are at least one wave long: the row index is then wave-uniform, and telling
-    // the compiler so turns the boundary-row selects into scalar branches that are almost never taken
+    // a wave holds one row pair when rows are at least one wave long: the row index is then wave-uniform
     const int c = threadIdx.x % cw;
     const int r = cw >= 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cw) : (int)threadIdx.x / cw;
     const int xraw = 4 * c, j = 2 * (by * rows + r);
@@ -738,83 +738,85 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
     for (int a = 0; a < 4; a++) ve[a] = ((unsigned)min(max(xe, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 4u;
 #pragma unroll
     for (int a = 0; a < 2; a++) vx[a] = ((unsigned)min(max(xo, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j + a, 0), ny - 1)) * 4u;
-    // E[.][0..3]: p(xe) on rows j-1 .. j+2, ring by plane like L0; Eo / Eb: p(xo) and div(xe) on rows j, j+1 of plane q
-    // (ring of 2: q live, q+1 arriving); X: the outside column's L1 on rows j, j+1 (ring of 2: plane q-1 live, q made)
-    float E[4][4], Eo[2][2], Eb[2][2], X[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++) { X[0][a] = 0.f; X[1][a] = 0.f; }
 
-    // rings indexed by (t & 3), t = q - (kbeg - 1) the iteration number:
-    //   L0[.][0..3]  p on rows j-1 .. j+2 of a plane      (live: planes q-1, q, q+1; q+2 arriving)
-    //   H[.][0..1]   p on rows j-2, j+3 of a plane        (ring of 2: plane q live, q+1 arriving)
-    //   L1[.][0..3]  first sweep on rows j-1 .. j+2        (live: planes q-1, q-2 (rows j, j+1); q being made)
-    //   D[.][0..3]   div on rows j-1 .. j+2                (live: planes q, q-1 (rows j, j+1); q+1 arriving)
+    // Rings indexed by the plane's slot (t + d) mod P, t = q - (kbeg - 1) the iteration number, d the plane's distance
+    // from q -- all compile-time inside the unrolled loop, so no value is ever moved to rotate planes:
+    //   L0[.][0..3]  p on rows j-1 .. j+2            (live: planes q-1 .. q+PF; q+1+PF arriving)
+    //   H[.][0..1]   p on rows j-2, j+3              (live: plane q .. q+PF-1; q+PF arriving)
+    //   L1[.][0..3]  first sweep on rows j-1 .. j+2  (q being made; q-1; q-2 (rows j, j+1))
+    //   D[.][0..3]   div on rows j-1 .. j+2          (q-1 (rows j, j+1) .. q+PF-1; q+PF arriving)
+    //   WIDE: E[.][0..3] p(xe) on rows j-1 .. j+2 like L0; Eo / Eb p(xo) / div(xe) on rows j, j+1 like H; X the outside
+    //   column's L1 on rows j, j+1 (q being made, q-1 live)
     auto run = [&](auto EDGE_T) {
     constexpr bool EDGE = decltype(EDGE_T)::value;
-    R4 L0[4][4], H[2][2], L1[4][4], D[4][4];
+    R4 L0[P][4], H[P][2], L1[P][4], D[P][4];
+    float E[P][4], Eo[P][2], Eb[P][2], X[P][2];
     const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < P; a++) {
 #pragma unroll
         for (int bb = 0; bb < 4; bb++) L1[a][bb] = zero;
+        X[a][0] = 0.f; X[a][1] = 0.f;
+    }
     int q = kbeg - 1;
-    {
-        const unsigned pm = po(q - 1), pc = po(q), pn = po(q + 1);
+#pragma unroll
+    for (int d = -1; d <= PF; d++) {                                // prologue: planes q-1 .. q+PF
+        constexpr int dummy = 0; (void)dummy;
+        const int sl_ = (d + P) % P;
+        const unsigned pp = po(q + d);
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            L0[3][a] = ld_r4(rp, vo[a + 1], pm);                    // t = -1
-            L0[0][a] = ld_r4(rp, vo[a + 1], pc);                    // t = 0
-            L0[1][a] = ld_r4(rp, vo[a + 1], pn);                    // t = 1
-            D[0][a] = ld_r4(rd, vo[a + 1], pc);
+            L0[sl_][a] = ld_r4(rp, vo[a + 1], pp);
+            if (WIDE) E[sl_][a] = ld_f(rp, ve[a], pp);
         }
-        H[0][0] = ld_r4(rp, vo[0], pc); H[0][1] = ld_r4(rp, vo[5], pc);
-        if (WIDE) {
+        if (d >= 0 && d < PF) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) { E[3][a] = ld_f(rp, ve[a], pm); E[0][a] = ld_f(rp, ve[a], pc); E[1][a] = ld_f(rp, ve[a], pn); }
+            for (int a = 0; a < 4; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
+            H[sl_][0] = ld_r4(rp, vo[0], pp); H[sl_][1] = ld_r4(rp, vo[5], pp);
+            if (WIDE) {
 #pragma unroll
-            for (int a = 0; a < 2; a++) { Eo[0][a] = ld_f(rp, vx[a], pc); Eb[0][a] = ld_f(rd, ve[a + 1], pc); }
+                for (int a = 0; a < 2; a++) { Eo[sl_][a] = ld_f(rp, vx[a], pp); Eb[sl_][a] = ld_f(rd, ve[a + 1], pp); }
+            }
         }
     }
-    // one plane.  T = t & 3 (compile time)
+#define BQ_SL(T, d) (((T) + (d) + P) % P)
 #define BQ_LEAN_PHASE(T)                                                                                            \
     {                                                                                                               \
-        constexpr int im = (T + 3) & 3, ic = T, in_ = (T + 1) & 3, ia = (T + 2) & 3;      /* L0: q-1, q, q+1, q+2 */    \
-        constexpr int hc = T & 1, hn = (T + 1) & 1;                                                                \
-        constexpr int m1 = T, mp = (T + 3) & 3, mpp = (T + 2) & 3;                         /* L1: q, q-1, q-2 */        \
-        constexpr int dc = T, dn_ = (T + 1) & 3, dp = (T + 3) & 3;                         /* D: q, q+1, q-1 */         \
-        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
-        _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[dn_][a] = ld_r4(rd, vo[a + 1], pb); } \
-        H[hn][0] = ld_r4(rp, vo[0], pb); H[hn][1] = ld_r4(rp, vo[5], pb);                                           \
+        constexpr int im = BQ_SL(T, -1), ic = BQ_SL(T, 0), in_ = BQ_SL(T, 1), ia = BQ_SL(T, 1 + PF), ha = BQ_SL(T, PF); \
+        constexpr int mp = BQ_SL(T, -1), mpp = BQ_SL(T, -2);                                                        \
+        const unsigned pa = po(q + 1 + PF), pb = po(q + PF);                                                        \
+        _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[ha][a] = ld_r4(rd, vo[a + 1], pb); } \
+        H[ha][0] = ld_r4(rp, vo[0], pb); H[ha][1] = ld_r4(rp, vo[5], pb);                                           \
         if (WIDE) {                                                                                                 \
             _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ld_f(rp, ve[a], pa);                              \
-            _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[hn][a] = ld_f(rp, vx[a], pb); Eb[hn][a] = ld_f(rd, ve[a + 1], pb); } \
+            _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[ha][a] = ld_f(rp, vx[a], pb); Eb[ha][a] = ld_f(rd, ve[a + 1], pb); } \
         }                                                                                                           \
         const bool qb = q < kA || q >= kB;                                                                          \
         if (qb) {                                               /* a boundary plane keeps L0 */                      \
-            _Pragma("unroll") for (int a = 0; a < 4; a++) L1[m1][a] = L0[ic][a];                                      \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) L1[ic][a] = L0[ic][a];                                      \
         } else {                                                                                                    \
-            L1[m1][0] = jac_r4<WIDE>(L0[ic][0], H[hc][0], L0[ic][1], L0[im][0], L0[in_][0], D[dc][0], alpha, beta, xlo, xhi, E[ic][0], edgeL, edgeR);   \
-            L1[m1][1] = jac_r4<WIDE>(L0[ic][1], L0[ic][0], L0[ic][2], L0[im][1], L0[in_][1], D[dc][1], alpha, beta, xlo, xhi, E[ic][1], edgeL, edgeR);  \
-            L1[m1][2] = jac_r4<WIDE>(L0[ic][2], L0[ic][1], L0[ic][3], L0[im][2], L0[in_][2], D[dc][2], alpha, beta, xlo, xhi, E[ic][2], edgeL, edgeR);  \
-            L1[m1][3] = jac_r4<WIDE>(L0[ic][3], L0[ic][2], H[hc][1], L0[im][3], L0[in_][3], D[dc][3], alpha, beta, xlo, xhi, E[ic][3], edgeL, edgeR);   \
+            L1[ic][0] = jac_r4<WIDE>(L0[ic][0], H[ic][0], L0[ic][1], L0[im][0], L0[in_][0], D[ic][0], alpha, beta, xlo, xhi, E[ic][0], edgeL, edgeR);   \
+            L1[ic][1] = jac_r4<WIDE>(L0[ic][1], L0[ic][0], L0[ic][2], L0[im][1], L0[in_][1], D[ic][1], alpha, beta, xlo, xhi, E[ic][1], edgeL, edgeR);  \
+            L1[ic][2] = jac_r4<WIDE>(L0[ic][2], L0[ic][1], L0[ic][3], L0[im][2], L0[in_][2], D[ic][2], alpha, beta, xlo, xhi, E[ic][2], edgeL, edgeR);  \
+            L1[ic][3] = jac_r4<WIDE>(L0[ic][3], L0[ic][2], H[ic][1], L0[im][3], L0[in_][3], D[ic][3], alpha, beta, xlo, xhi, E[ic][3], edgeL, edgeR);   \
             if (EDGE) {                                                                                             \
                 _Pragma("unroll") for (int a = 0; a < 4; a++)                                                        \
-                    if (rowb[a]) L1[m1][a] = L0[ic][a];                                                             \
+                    if (rowb[a]) L1[ic][a] = L0[ic][a];                                                             \
             }                                                                                                       \
         }                                                                                                           \
         if (WIDE) {                                             /* the outside column's own first sweep, rows j, j+1 */ \
             _Pragma("unroll") for (int rr = 0; rr < 2; rr++) {                                                       \
                 const float own = edgeL ? L0[ic][rr + 1].a.x : L0[ic][rr + 1].b.y;                                   \
-                const float l = edgeL ? Eo[hc][rr] : own, rg2 = edgeL ? own : Eo[hc][rr];                           \
-                const float v = (l + rg2 + E[ic][rr] + E[ic][rr + 2] + E[im][rr + 1] + E[in_][rr + 1] + alpha * Eb[hc][rr]) * beta; \
-                const bool keep = qb || xe_boundary || (EDGE && rowb[rr + 1]) || (j + rr <= 0 || j + rr >= ny - 1);  \
-                X[hc][rr] = keep ? E[ic][rr + 1] : v;                                                               \
+                const float l = edgeL ? Eo[ic][rr] : own, rg2 = edgeL ? own : Eo[ic][rr];                           \
+                const float v = (l + rg2 + E[ic][rr] + E[ic][rr + 2] + E[im][rr + 1] + E[in_][rr + 1] + alpha * Eb[ic][rr]) * beta; \
+                const bool keep = qb || xe_boundary || (j + rr <= 0 || j + rr >= ny - 1);                           \
+                X[ic][rr] = keep ? E[ic][rr + 1] : v;                                                               \
             }                                                                                                       \
         }                                                                                                           \
         const int k = q - 1;                                                                                        \
         if (k >= kbeg && k < kend) {                                                                                \
-            const R4 o0 = jac_r4<WIDE>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[m1][1], D[dp][1], alpha, beta, xlo, xhi, X[hn][0], edgeL, edgeR); \
-            const R4 o1 = jac_r4<WIDE>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[m1][2], D[dp][2], alpha, beta, xlo, xhi, X[hn][1], edgeL, edgeR); \
+            const R4 o0 = jac_r4<WIDE>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[ic][1], D[mp][1], alpha, beta, xlo, xhi, X[mp][0], edgeL, edgeR); \
+            const R4 o1 = jac_r4<WIDE>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[ic][2], D[mp][2], alpha, beta, xlo, xhi, X[mp][1], edgeL, edgeR); \
             const unsigned pk = pstride * (unsigned)k;                                                              \
             if (active0) st_r4(o0, ro, vo[2], pk);                                                                  \
             if (active1) st_r4(o1, ro, vo[3], pk);                                                                  \
@@ -830,6 +832,10 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         if (q > kend) break;
         BQ_LEAN_PHASE(3)
         if (q > kend) break;
+        if constexpr (P > 4) {
+            BQ_LEAN_PHASE(4)
+            if (q > kend) break;
+        }
     }
     };
     if (edge_block) run(std::true_type{}); else run(std::false_type{});
@@ -1160,8 +1166,17 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
             const int nbz2 = rg.nchA + chunks_of(lenB, kc);
             if (rt().opt_jacobi_rows != 3) {
                 // the lean rendering of the same kernel; FL_OPT_JACOBI_ROWS = 3 keeps the older one for A/B timing
-                if (wide) jacobi_lean2r_kernel<true><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
-                else      jacobi_lean2r_kernel<false><<<nby2 * nbz2, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                // loads run one plane ahead while p, p', div sit in the 256 MiB Infinity Cache, two planes ahead when they
+                // come from HBM (512^3: 199.8 -> 195.6 us per sweep; 256^3 15.75 vs 15.95 the other way round).
+                // FL_OPT_JACOBI_KCHUNK = 1 / 2 forces a distance (it has no other meaning for the fused kernels)
+                const bool in_cache = 12.0 * (double)ni * (double)nj * (double)nk <= 256.0 * 1048576.0;
+                const int pf = rt().opt_jacobi_kchunk == 1 ? 1 : rt().opt_jacobi_kchunk == 2 ? 2 : (in_cache ? 1 : 2);
+                const dim3 gr(nby2 * nbz2);
+                hipStream_t st = rt().compute;
+                if (wide) { if (pf == 1) jacobi_lean2r_kernel<true, 1><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                            else         jacobi_lean2r_kernel<true, 2><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg); }
+                else      { if (pf == 1) jacobi_lean2r_kernel<false, 1><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
+                            else         jacobi_lean2r_kernel<false, 2><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg); }
                 BQ_LAUNCH_CHECK("jacobi_lean2r_kernel");
                 g_last_pair_kernel = "jacobi_lean2r_kernel";
                 return true;

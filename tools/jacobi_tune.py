@@ -50,7 +50,7 @@ def main():
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0 if fused else v[0])
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, (2 if v[0] == 4 else 4) if fused else 0)
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, v[1])   # fused: 1 = one-plane prefetch, else two planes ahead
-            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0 if fused else v[2])
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, (v[3] if len(v) > 3 else 0) if fused else v[2])   # fused: 4th field = prefetch distance (1; default 2)
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, v[2] if fused else 0)
             lib.fl_event_record(e0)
             lib.gpu_jacobi_sweeps(p.ptr, d.ptr, t.ptr, nx, ny, nz, a.sweeps, -1.0, 1.0 / 6.0)
@@ -62,7 +62,7 @@ def main():
     print(f"grid {nx}x{ny}x{nz}, {a.sweeps} sweeps/launch-loop, median of {a.reps}")
     for v in variants:
         us = statistics.median(res[v])
-        print(f"variant={v[0]} rows={v[1]} kchunk={v[2]:4d}: {us:8.2f} us/sweep  {12.0 * n / us / 1e3:8.1f} GB/s  "
+        print(f"variant={v[0]} rows={v[1]} kchunk={v[2]:4d}{(' pf=' + str(v[3])) if len(v) > 3 else ''}: {us:8.2f} us/sweep  {12.0 * n / us / 1e3:8.1f} GB/s  "
               f"{12.0 * n / us / 1e3 / 8000:6.3f} of 8 TB/s   (min {min(res[v]):.2f})")
 
 
