@@ -659,9 +659,11 @@ __device__ __forceinline__ R4 ld_r4(v4i rs, unsigned voff, unsigned soff)
 }
 __device__ float bq_buffer_load_x1(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ __forceinline__ float ld_f(v4i rs, unsigned voff, unsigned soff) { return bq_buffer_load_x1(rs, (int)voff, (int)soff, 0); }
+// AUX: cache policy bits of the store (2 = nt: a streaming store, for arrays that will not be read again from the caches)
+template <int AUX = 0>
 __device__ __forceinline__ void st_r4(R4 v, v4i rs, unsigned voff, unsigned soff)
 {
-    bq_buffer_store_x4(v4f{v.a.x, v.a.y, v.b.x, v.b.y}, rs, (int)voff, (int)soff, 0);
+    bq_buffer_store_x4(v4f{v.a.x, v.a.y, v.b.x, v.b.y}, rs, (int)voff, (int)soff, AUX);
 }
 
 // jacobi_kernel's expression (GPU_kernel.cu:1833) on a float4 column: ((((((l + r) + f) + b) + d) + u) + alpha div) beta
@@ -689,13 +691,18 @@ __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, f
     return R4{s0, s1};
 }
 
-// PF: how many planes ahead the loads run (1 or 2).  The rings hold 3 + PF planes and the loop is unrolled 3 + PF times.
+// PF: how many planes ahead the loads run (1 or 2; 3 and 4 measured no better anywhere, tools/r02_m.sh).  The rings hold 3 + PF planes and the loop is unrolled 3 + PF times.
 template <bool WIDE, int PF>
 __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                             float *__restrict__ out, int nx, int ny, int nz,
                                                             int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
     constexpr int P = 3 + PF;                                       // ring period
+    // PF = 2 is the form for arrays that come from HBM (larger than the Infinity Cache): streaming stores, and the
+    // edge lanes' scalar loads executed under their own exec mask.  In-cache sizes run faster without either
+    // (512x512x80: 20.0 us per sweep without, 23.6 with the masked loads; 256^3: 15.9 vs 20.3 with streaming stores).
+    constexpr bool HBM = PF >= 2;
+    constexpr int ST = HBM ? 2 : 0;
     const int nblk = gridDim.x;
     int b = blockIdx.x;
     if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
@@ -728,9 +735,11 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
     // WIDE: the first / last lane of a wave looks after the column just outside its wave (xe) -- it needs that column's
     // L0 on rows j-1 .. j+2 (x-neighbour of our own first sweep) and its L1 on rows j, j+1 (x-neighbour of our second
     // sweep), which it evaluates itself from that column's own neighbours (outer x-neighbour xo, rows, planes, div).
-    // All other lanes run the same few scalar loads on their own column; what they get is not used.
+    // What the other lanes hold in E/Eo/Eb/X is never used: they run the same eight scalar loads per plane on their own
+    // column, or (HBM-resident arrays) skip them under the exec mask -- 512^3: 201 -> 173 us per sweep.
     const int lane = threadIdx.x & 63;
     const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 4 < nx;
+    const bool edge = edgeL || edgeR;
     const int xe = edgeL ? xraw - 1 : (edgeR ? xraw + 4 : x), xo = edgeL ? xe - 1 : (edgeR ? xe + 1 : x);
     const bool xe_boundary = xe <= 0 || xe >= nx - 1;
     unsigned ve[4], vx[2];
@@ -765,15 +774,16 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         const int sl_ = (d + P) % P;
         const unsigned pp = po(q + d);
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            L0[sl_][a] = ld_r4(rp, vo[a + 1], pp);
-            if (WIDE) E[sl_][a] = ld_f(rp, ve[a], pp);
+        for (int a = 0; a < 4; a++) L0[sl_][a] = ld_r4(rp, vo[a + 1], pp);
+        if (WIDE && (!HBM || edge)) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) E[sl_][a] = ld_f(rp, ve[a], pp);
         }
         if (d >= 0 && d < PF) {
 #pragma unroll
             for (int a = 0; a < 4; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
             H[sl_][0] = ld_r4(rp, vo[0], pp); H[sl_][1] = ld_r4(rp, vo[5], pp);
-            if (WIDE) {
+            if (WIDE && (!HBM || edge)) {
 #pragma unroll
                 for (int a = 0; a < 2; a++) { Eo[sl_][a] = ld_f(rp, vx[a], pp); Eb[sl_][a] = ld_f(rd, ve[a + 1], pp); }
             }
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         const unsigned pa = po(q + 1 + PF), pb = po(q + PF);                                                        \
         _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[ha][a] = ld_r4(rd, vo[a + 1], pb); } \
         H[ha][0] = ld_r4(rp, vo[0], pb); H[ha][1] = ld_r4(rp, vo[5], pb);                                           \
-        if (WIDE) {                                                                                                 \
+        if (WIDE && (!HBM || edge)) {                           /* HBM: executed by the two edge lanes only */       \
             _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ld_f(rp, ve[a], pa);                              \
             _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[ha][a] = ld_f(rp, vx[a], pb); Eb[ha][a] = ld_f(rd, ve[a + 1], pb); } \
         }                                                                                                           \
@@ -818,8 +828,8 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
             const R4 o0 = jac_r4<WIDE>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[ic][1], D[mp][1], alpha, beta, xlo, xhi, X[mp][0], edgeL, edgeR); \
             const R4 o1 = jac_r4<WIDE>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[ic][2], D[mp][2], alpha, beta, xlo, xhi, X[mp][1], edgeL, edgeR); \
             const unsigned pk = pstride * (unsigned)k;                                                              \
-            if (active0) st_r4(o0, ro, vo[2], pk);                                                                  \
-            if (active1) st_r4(o1, ro, vo[3], pk);                                                                  \
+            if (active0) st_r4<ST>(o0, ro, vo[2], pk);                                                              \
+            if (active1) st_r4<ST>(o1, ro, vo[3], pk);                                                              \
         }                                                                                                           \
         q++;                                                                                                        \
     }
@@ -834,6 +844,14 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         if (q > kend) break;
         if constexpr (P > 4) {
             BQ_LEAN_PHASE(4)
+            if (q > kend) break;
+        }
+        if constexpr (P > 5) {
+            BQ_LEAN_PHASE(5)
+            if (q > kend) break;
+        }
+        if constexpr (P > 6) {
+            BQ_LEAN_PHASE(6)
             if (q > kend) break;
         }
     }
@@ -1170,13 +1188,14 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
                 // come from HBM (512^3: 199.8 -> 195.6 us per sweep; 256^3 15.75 vs 15.95 the other way round).
                 // FL_OPT_JACOBI_KCHUNK = 1 / 2 forces a distance (it has no other meaning for the fused kernels)
                 const bool in_cache = 12.0 * (double)ni * (double)nj * (double)nk <= 256.0 * 1048576.0;
-                const int pf = rt().opt_jacobi_kchunk == 1 ? 1 : rt().opt_jacobi_kchunk == 2 ? 2 : (in_cache ? 1 : 2);
+                const int forced = rt().opt_jacobi_kchunk;
+                const int pf = forced == 1 || forced == 2 ? forced : (in_cache ? 1 : 2);
                 const dim3 gr(nby2 * nbz2);
                 hipStream_t st = rt().compute;
-                if (wide) { if (pf == 1) jacobi_lean2r_kernel<true, 1><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
-                            else         jacobi_lean2r_kernel<true, 2><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg); }
-                else      { if (pf == 1) jacobi_lean2r_kernel<false, 1><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg);
-                            else         jacobi_lean2r_kernel<false, 2><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg); }
+#define BQ_LEAN2R(W, F) jacobi_lean2r_kernel<W, F><<<gr, 256, 0, st>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk), rg)
+                if (wide) { if (pf == 1) BQ_LEAN2R(true, 1); else BQ_LEAN2R(true, 2); }
+                else      { if (pf == 1) BQ_LEAN2R(false, 1); else BQ_LEAN2R(false, 2); }
+#undef BQ_LEAN2R
                 BQ_LAUNCH_CHECK("jacobi_lean2r_kernel");
                 g_last_pair_kernel = "jacobi_lean2r_kernel";
                 return true;

@@ -209,6 +209,33 @@ def test_fused_two_sweep_kernel(hip, ni, nj, nk, sweeps, rows):
     bq.check()
 
 
+@pytest.mark.parametrize("ni,nj,nk", [(64, 48, 40), (256, 32, 24), (36, 5, 3), (512, 9, 24), (260, 20, 12), (1024, 5, 9)])
+@pytest.mark.parametrize("pf", [1, 2])
+def test_fused_two_sweep_kernel_prefetch_distances(hip, ni, nj, nk, pf):
+    """jacobi_lean2r_kernel<WIDE, PF>: loads 1 or 2 planes ahead (2: with streaming stores) (rings of 3 + PF planes, loop unrolled 3 + PF times);
+    every distance gives the bits of single oracle sweeps, on rows of one wave and of 2-4 waves, with chunks shorter
+    than the ring."""
+    import gpufluidsimulation_amd as bq
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    a, b = p0.copy(), p0.copy()
+    for _ in range(4):
+        oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+        a, b = b, a
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 4)          # pairs only
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, pf)
+    dp, dd, dt = dev(p0, div, p0)
+    where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 4, ALPHA, BETA)
+    name = hip.fl_jacobi_kernel_name().decode()
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0)
+    assert name == "jacobi_lean2r_kernel"
+    assert F.same(a, (dt if where else dp).numpy()), (ni, nj, nk, pf)
+    bq.check()
+
+
 @pytest.mark.parametrize("ni,nj,nk", [(24, 20, 16), (64, 48, 40), (256, 32, 24)])
 @pytest.mark.parametrize("variant", [0, 1, 3])
 def test_jacobi_sweep_range(hip, ni, nj, nk, variant):
