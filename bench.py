@@ -64,6 +64,8 @@ def parse():
                          "one density_render_%%04d[.k%%05d].bqd per frame [and slab]) INSIDE the timed region")
     ap.add_argument("--jacobi-iters", type=int, default=200)
     ap.add_argument("--halfrdx", type=float, default=0.5)
+    ap.add_argument("--fl-opt", action="append", default=[], metavar="ID=VALUE",
+                    help="fl_set_option(ID, VALUE) before the run (A/B timing of library options; repeatable)")
     ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi",
                     help="jacobi: BASELINE's headline config; mgcg: the fp64 multigrid-CG projection the reference's "
                          "shipped binary runs (SURVEY 8f N1), --mg-iters outer iterations, single GPU")
@@ -309,6 +311,9 @@ def main():
         if args.dump:
             s.waitOutput()
 
+    for kv in args.fl_opt:
+        k, v = kv.split("=")
+        lib.fl_set_option(int(k), int(v))
     run(args.warmup)
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
     barrier()

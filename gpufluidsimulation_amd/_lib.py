@@ -120,6 +120,7 @@ FL_OPT_PROFILE_JACOBI, FL_OPT_JACOBI_KCHUNK, FL_OPT_JACOBI_ROWS, FL_OPT_STRUCTUR
 FL_OPT_JACOBI_FUSE, FL_OPT_JACOBI_KCHUNK2, FL_OPT_MGCG_GRAPH, FL_OPT_FAST_LERP = 8, 9, 10, 11
 FL_OPT_FUSED_HOUSEKEEPING = 12
 FL_OPT_MAP_QUARTER_FP32 = 13
+FL_OPT_MGCG_TILE = 14
 
 
 class BimocqLibraryMissing(RuntimeError):

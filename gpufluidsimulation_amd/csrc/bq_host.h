@@ -31,6 +31,7 @@ struct Runtime {
     int        *map_guard = nullptr;
     bool        map_guard_on = false;
     int         opt_mgcg_graph = 1;         // replay the multigrid V-cycle from a captured hipGraph
+    int         opt_mgcg_tile = 1;          // FL_OPT_MGCG_TILE: LDS tile smoother on the coarse levels of the V-cycle
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;
     // this rank owns global planes [slab_own0, slab_own1) (reductions count only those)

@@ -330,6 +330,86 @@ __global__ __launch_bounds__(THREADS) void mg_smooth2_kernel(const double *__res
     }
 }
 
+// ---- S sweeps per launch on the coarse levels (LDS tiles) ---------------------------------------------
+// Levels 1 .. 5 of a 256^3 V-cycle (127^3 .. 7^3) are 176 launches of mg_smooth_kernel per cycle, 2 - 12 us each and
+// mostly launch latency: 43 ms of a 229 ms step.  Here a workgroup stages a 16^3 region of x in LDS (thread (tx, ty)
+// owns the z-column at (tx, ty): x/y neighbours come from LDS, z neighbours from its own registers, rhs stays in
+// registers), runs S sweeps on it and stores the central (16 - 2S)^3 cells -- the cells whose S-sweep dependency cone
+// lies inside the region.  Cells outside the array read 0 and, like the array's boundary cells, are never updated, so
+// the cone argument only has to hold towards region faces that lie inside the array.  Every value is produced by
+// mg_smooth_kernel's expression on the same operands: S launches of that kernel give the same bits.
+// Precondition as for mg_smooth2_kernel: in and out carry the same boundary layer.  V_Cycle guarantees it by clearing
+// both buffers first; ZIN / ZB fold those clears in: ZIN = the input is all zeros (x is not read), ZB = the boundary
+// cells of `out` are written (0 -- what the cleared buffer holds there) along with the interior.
+template <int S, bool ZIN, bool ZB>
+__global__ __launch_bounds__(256) void mg_smooth_tile_kernel(const double *__restrict__ x, const double *__restrict__ rhs,
+                                                             double *__restrict__ out, double alpha, double beta, int ni, int nj, int nk)
+{
+    constexpr int R = 16, T = R - 2 * S;
+    __shared__ double xs[R * R * R];                                                     // [z][y][x]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int gx = (int)blockIdx.x * T - S + tx, gy = (int)blockIdx.y * T - S + ty, gz0 = (int)blockIdx.z * T - S;
+    const bool inxy = gx >= 0 && gx < ni && gy >= 0 && gy < nj;
+    // swept: interior of the array and not on a face of the region (its four x/y neighbours are in the region)
+    const bool sweptxy = gx >= 1 && gx <= ni - 2 && gy >= 1 && gy <= nj - 2 && tx >= 1 && tx <= R - 2 && ty >= 1 && ty <= R - 2;
+    const int sk = ni * nj;
+    // every address is clamped into the array: what a clamped load returns is replaced by 0 (x) or never used (rhs)
+    const int colc = min(max(gx, 0), ni - 1) + ni * min(max(gy, 0), nj - 1);
+    double v[R], bb[R];
+    unsigned upd = 0;                                                                    // bit z: this cell is swept
+#pragma unroll
+    for (int z = 0; z < R; z++) {
+        const int gz = gz0 + z;
+        const int idc = colc + sk * min(max(gz, 0), nk - 1);
+        if (!ZIN) { const double t = x[idc]; v[z] = (inxy && gz >= 0 && gz < nk) ? t : 0.0; } else v[z] = 0.0;
+        bb[z] = (z >= 1 && z <= R - 2) ? rhs[idc] : 0.0;
+        if (sweptxy && z >= 1 && z <= R - 2 && gz >= 1 && gz <= nk - 2) upd |= 1u << z;
+    }
+    double *mine = xs + (ty * R + tx);
+    if (!ZIN) {
+#pragma unroll
+        for (int z = 0; z < R; z++) mine[z * R * R] = v[z];
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        if (ZIN && s == 0) {
+            // a sweep of the zero field: ((0 + 0 + 0 + 0 + 0 + 0) + alpha b) beta, no neighbour needed
+#pragma unroll
+            for (int z = 1; z < R - 1; z++) {
+                const double t = ((0.0 + 0.0 + 0.0 + 0.0 + 0.0 + 0.0) + alpha * bb[z]) * beta;
+                v[z] = ((upd >> z) & 1u) ? t : v[z];
+            }
+        } else {
+            __syncthreads();
+            // No branch per cell: threads on a region face read their neighbours' slots of the adjacent row / plane
+            // (inside xs for 1 <= z <= 14) and discard the result
+            double below = v[0];                                                         // the old value of the cell underneath
+#pragma unroll
+            for (int z = 1; z < R - 1; z++) {
+                const double *c = mine + z * R * R;
+                const double cur = v[z];
+                const double t = ((c[-1] + c[1] + c[-R] + c[R] + below + v[z + 1]) + alpha * bb[z]) * beta;
+                v[z] = ((upd >> z) & 1u) ? t : cur;
+                below = cur;
+            }
+        }
+        if (s + 1 < S) {
+            if (!(ZIN && s == 0)) __syncthreads();                                       // everybody has read the old values
+#pragma unroll
+            for (int z = (ZIN && s == 0) ? 0 : 1; z < ((ZIN && s == 0) ? R : R - 1); z++) mine[z * R * R] = v[z];
+        }
+    }
+    if (tx < S || tx >= R - S || ty < S || ty >= R - S || !inxy) return;
+    const int col = gx + ni * gy;
+#pragma unroll
+    for (int z = S; z < R - S; z++) {
+        const int gz = gz0 + z;
+        if (gz < 0 || gz >= nk) continue;
+        if ((upd >> z) & 1u) out[col + sk * gz] = v[z];
+        else if (ZB) out[col + sk * gz] = 0.0;
+    }
+}
+
 // GPU_kernel.cu:22-25 on float operands (M2)
 __device__ __forceinline__ float lerp_f(float a, float b, float c)
 {
@@ -455,6 +535,35 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
     BQ_LAUNCH_CHECK("mg_smooth_kernel");
 }
 
+// The coarse levels of V_Cycle through mg_smooth_tile_kernel: `iter` sweeps of x (newest iterate ends in x, as in
+// mg_smooth), with the clears that V_Cycle issues before the call folded in -- temp is never read before it is written
+// and x_is_zero says that x would have been cleared too.  false = not applicable (the caller clears and calls mg_smooth).
+static bool mg_smooth_tiled(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk,
+                            int iter, bool x_is_zero)
+{
+    if (!rt().opt_mgcg_tile || iter < 4 || iter % 4 != 0) return false;
+    // 63^3 and coarser by default; FL_OPT_MGCG_TILE = 2 also takes 127^3 (measured slower there: 4096 workgroups that
+    // each recompute 3x the cells they store, against sweeps that already stream from the Infinity Cache)
+    const long long limit = rt().opt_mgcg_tile >= 2 ? (1ll << 21) : (1ll << 19);
+    if ((long long)ni * nj * nk >= limit || ni < 3 || nj < 3 || nk < 3) return false;
+    hipStream_t st = rt().compute;
+    const int S = iter % 8 == 0 ? 4 : 2, T = 16 - 2 * S, launches = iter / S;            // an even number of launches
+    const dim3 grid((ni + T - 1) / T, (nj + T - 1) / T, (nk + T - 1) / T);
+    const double *in = x;
+    double *out = temp;
+    for (int l = 0; l < launches; l++) {
+        // launch 0 writes all of temp, launch 1 all of x when x was to be cleared: boundary cells included
+        const bool zin = l == 0 && x_is_zero, zb = l == 0 || (l == 1 && x_is_zero);
+#define MG_TILE(SS, ZI, ZBB) mg_smooth_tile_kernel<SS, ZI, ZBB><<<grid, 256, 0, st>>>(in, b, out, alpha, beta, ni, nj, nk)
+        if (S == 4) { if (zin) MG_TILE(4, true, true); else if (zb) MG_TILE(4, false, true); else MG_TILE(4, false, false); }
+        else        { if (zin) MG_TILE(2, true, true); else if (zb) MG_TILE(2, false, true); else MG_TILE(2, false, false); }
+#undef MG_TILE
+        const double *t = in; in = out; out = (double *)t;
+    }
+    BQ_LAUNCH_CHECK("mg_smooth_tile_kernel");
+    return true;
+}
+
 static void mg_residual(double *r, const double *b, const double *x, int ni, int nj, int nk)
 {
     mg_residual_kernel<<<grid_of(ni, nj, nk), kBlk, 0, rt().compute>>>(r, b, x, ni, nj, nk);
@@ -491,25 +600,26 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
     // ever touches the first L[l].number of them, so that is what is cleared.  (What stays behind in the
     // rest of temp0 is later seen only at boundary indices of the level-0 product dir*A(dir), where dir
     // is 0: no value depends on it.)
-    for (int l = 0; l < levelnum - 1; l++) {
+    // smoothing call of V_Cycle: clear temp0 (and x on the way down), `iter` sweeps
+    auto smooth_level = [&](int l, int iter, bool clear_x) {
+        if (mg_smooth_tiled(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return;
         mg_zero(temp0, (size_t)L[l].number);
-        mg_zero(L[l].x, (size_t)L[l].number);
-        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, 32);
+        if (clear_x) mg_zero(L[l].x, (size_t)L[l].number);
+        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter);
+    };
+    for (int l = 0; l < levelnum - 1; l++) {
+        smooth_level(l, 32, true);
         mg_residual(L[l].r, L[l].b, L[l].x, L[l].ni, L[l].nj, L[l].nk);
         mg_restrict_kernel<<<grid_of(L[l + 1].ni, L[l + 1].nj, L[l + 1].nk), kBlk, 0, st>>>(
             L[l].r, L[l + 1].b, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
         BQ_LAUNCH_CHECK("mg_restrict_kernel");
     }
-    const int c = levelnum - 1;
-    mg_zero(temp0, (size_t)L[c].number);
-    mg_zero(L[c].x, (size_t)L[c].number);
-    mg_smooth(L[c].x, L[c].b, temp0, L[c].alpha * scale[c], L[c].beta, L[c].ni, L[c].nj, L[c].nk, 32);
+    smooth_level(levelnum - 1, 32, true);
     for (int l = levelnum - 2; l >= 0; --l) {
         mg_prolong_kernel<<<grid_of(L[l].ni, L[l].nj, L[l].nk), kBlk, 0, st>>>(
             L[l].x, L[l + 1].x, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
         BQ_LAUNCH_CHECK("mg_prolong_kernel");
-        mg_zero(temp0, (size_t)L[l].number);
-        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, 4);
+        smooth_level(l, 4, false);
     }
     mg_add_kernel<<<blocks1d(n0), 256, 0, st>>>(x, L[0].x, 1.0, n0);
     BQ_LAUNCH_CHECK("mg_add_kernel");
@@ -524,7 +634,7 @@ struct VCycleGraph {
     hipGraphExec_t exec = nullptr;
     const double *b = nullptr; double *x = nullptr, *residual = nullptr, *temp0 = nullptr;
     SCoarseLevelInfo levels[LEVEL_COUNT];
-    int levelnum = 0, fuse = 0, rows = 0, kchunk2 = 0;
+    int levelnum = 0, fuse = 0, rows = 0, kchunk2 = 0, tile = 0;
 };
 static VCycleGraph g_vcg;
 
@@ -532,7 +642,8 @@ static bool vcg_matches(const double *b, double *x, double *residual, const SCoa
 {
     const VCycleGraph &c = g_vcg;
     if (!c.exec || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
-    if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk2 != rt().opt_jacobi_kchunk2) return false;
+    if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk2 != rt().opt_jacobi_kchunk2 ||
+        c.tile != rt().opt_mgcg_tile) return false;
     for (int l = 0; l < levelnum; l++) {
         const SCoarseLevelInfo &p = c.levels[l], &q = L[l];
         if (p.ni != q.ni || p.nj != q.nj || p.nk != q.nk || p.number != q.number || p.alpha != q.alpha || p.beta != q.beta ||
@@ -559,6 +670,7 @@ static void v_cycle_replayed(const double *b, double *x, double *residual, const
         if (!ok) { g_vcg.exec = nullptr; return; }           // the error is latched
         g_vcg.b = b; g_vcg.x = x; g_vcg.residual = residual; g_vcg.temp0 = temp0; g_vcg.levelnum = levelnum;
         g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2;
+        g_vcg.tile = rt().opt_mgcg_tile;
         for (int l = 0; l < levelnum; l++) g_vcg.levels[l] = L[l];
     }
     BQ_HIP(hipGraphLaunch(g_vcg.exec, st));

@@ -251,6 +251,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_FAST_LERP:       g_rt.opt_fast_lerp = value != 0; break;
     case FL_OPT_FUSED_HOUSEKEEPING: g_rt.opt_fused_housekeeping = value & 15; break;
     case FL_OPT_MAP_QUARTER_FP32: g_rt.opt_map_quarter_fp32 = value != 0; break;
+    case FL_OPT_MGCG_TILE:       g_rt.opt_mgcg_tile = value < 0 ? 0 : value; break;
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -271,6 +272,7 @@ int fl_get_option(int option)
     case FL_OPT_FAST_LERP:       return g_rt.opt_fast_lerp;
     case FL_OPT_FUSED_HOUSEKEEPING: return g_rt.opt_fused_housekeeping;
     case FL_OPT_MAP_QUARTER_FP32: return g_rt.opt_map_quarter_fp32;
+    case FL_OPT_MGCG_TILE:       return g_rt.opt_mgcg_tile;
     default: return -1;
     }
 }

@@ -272,6 +272,10 @@ enum {
     FL_OPT_FAST_LERP       = 11,/* 0 (default): the reference's double-evaluated lerp, results bit-identical to the
                                  * oracle.  1: every lerp of the gather kernels is one fp32 fma, fmaf(c, b-a, a) -- NOT the
                                  * reference arithmetic; deviation measured per grid size   */
+    FL_OPT_MGCG_TILE       = 14,/* multigrid V-cycle, levels below 2^19 cells (63^3 and coarser; 2: below 2^21): 1 (default) smooths them with
+                                 * the LDS tile kernel -- 4 (the 32-sweep calls) or 2 (the 4-sweep calls) sweeps per launch on a
+                                 * 16^3 region per workgroup, and the clears of x / temp0 folded into the first two launches;
+                                 * 0: one launch per sweep (mg_smooth_kernel).  Same values either way.          */
     FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
                                  * contract.  1: the caller vouches that every value of the map arrays it passes to the
                                  * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map
