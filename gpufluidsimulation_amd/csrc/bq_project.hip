@@ -698,9 +698,8 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
                                                             int cw, int nby, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
     constexpr int P = 3 + PF;                                       // ring period
-    // PF = 2 is the form for arrays that come from HBM (larger than the Infinity Cache): streaming stores, and the
-    // edge lanes' scalar loads executed under their own exec mask.  In-cache sizes run faster without either
-    // (512x512x80: 20.0 us per sweep without, 23.6 with the masked loads; 256^3: 15.9 vs 20.3 with streaming stores).
+    // PF = 2 is the form for arrays that come from HBM (larger than the Infinity Cache): loads two planes ahead and
+    // streaming stores (512^3: 174.6 -> 162.8 us per sweep; in-cache sizes lose with them: 256^3 15.9 -> 20.3).
     constexpr bool HBM = PF >= 2;
     constexpr int ST = HBM ? 2 : 0;
     const int nblk = gridDim.x;
@@ -735,8 +734,9 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
     // WIDE: the first / last lane of a wave looks after the column just outside its wave (xe) -- it needs that column's
     // L0 on rows j-1 .. j+2 (x-neighbour of our own first sweep) and its L1 on rows j, j+1 (x-neighbour of our second
     // sweep), which it evaluates itself from that column's own neighbours (outer x-neighbour xo, rows, planes, div).
-    // What the other lanes hold in E/Eo/Eb/X is never used: they run the same eight scalar loads per plane on their own
-    // column, or (HBM-resident arrays) skip them under the exec mask -- 512^3: 201 -> 173 us per sweep.
+    // The other 62 lanes run the same eight scalar loads per plane, but with an offset beyond the descriptor's range: the
+    // range check answers 0 and nothing goes to the caches (512^3: 200 -> 175 us per sweep against loading their own
+    // column; an exec-masked branch around the loads does the same at 512^3 but costs 7 % in-cache).
     const int lane = threadIdx.x & 63;
     const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 4 < nx;
     const bool edge = edgeL || edgeR;
@@ -747,6 +747,13 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
     for (int a = 0; a < 4; a++) ve[a] = ((unsigned)min(max(xe, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 4u;
 #pragma unroll
     for (int a = 0; a < 2; a++) vx[a] = ((unsigned)min(max(xo, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j + a, 0), ny - 1)) * 4u;
+    if (WIDE && !edge) {
+        // an offset beyond the descriptor's range: the load returns 0 without touching the caches (2 GiB + any plane
+        // offset of an array below 2 GiB neither wraps nor lands inside it)
+#pragma unroll
+        for (int a = 0; a < 4; a++) ve[a] = 0x80000000u;
+        vx[0] = vx[1] = 0x80000000u;
+    }
 
     // Rings indexed by the plane's slot (t + d) mod P, t = q - (kbeg - 1) the iteration number, d the plane's distance
     // from q -- all compile-time inside the unrolled loop, so no value is ever moved to rotate planes:
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         const unsigned pp = po(q + d);
 #pragma unroll
         for (int a = 0; a < 4; a++) L0[sl_][a] = ld_r4(rp, vo[a + 1], pp);
-        if (WIDE && (!HBM || edge)) {
+        if (WIDE) {
 #pragma unroll
             for (int a = 0; a < 4; a++) E[sl_][a] = ld_f(rp, ve[a], pp);
         }
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
 #pragma unroll
             for (int a = 0; a < 4; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
             H[sl_][0] = ld_r4(rp, vo[0], pp); H[sl_][1] = ld_r4(rp, vo[5], pp);
-            if (WIDE && (!HBM || edge)) {
+            if (WIDE) {
 #pragma unroll
                 for (int a = 0; a < 2; a++) { Eo[sl_][a] = ld_f(rp, vx[a], pp); Eb[sl_][a] = ld_f(rd, ve[a + 1], pp); }
             }
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         const unsigned pa = po(q + 1 + PF), pb = po(q + PF);                                                        \
         _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[ha][a] = ld_r4(rd, vo[a + 1], pb); } \
         H[ha][0] = ld_r4(rp, vo[0], pb); H[ha][1] = ld_r4(rp, vo[5], pb);                                           \
-        if (WIDE && (!HBM || edge)) {                           /* HBM: executed by the two edge lanes only */       \
+        if (WIDE) {                                                                                                 \
             _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ld_f(rp, ve[a], pa);                              \
             _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[ha][a] = ld_f(rp, vx[a], pb); Eb[ha][a] = ld_f(rd, ve[a + 1], pb); } \
         }                                                                                                           \
