@@ -24,7 +24,7 @@ HOST_OBJS   := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(HOST_SRCS))
 
 all: $(PKG)/libbimocq_hip.so $(PKG)/libbimocq_host.so oracle example
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_buffer.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -400,7 +400,7 @@ def main():
                                                        "one fp32 fma; NOT the reference arithmetic (DESIGN.md section 12: deviation "
                                                        "from the exact fields measured per grid size, tolerance 1e-5 RMS)"}}
     if launches.value > 0 and mg:
-        # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_smooth2_kernel: one launch reads x and
+        # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_lean2r_kernel (mg_smooth2_kernel with FL_OPT_JACOBI_ROWS = 3): one launch reads x and
         # rhs and writes x' once (24 B/cell compulsory), which is 24 B/cell/sweep x 2 sweeps in SURVEY 8(d)'s per-sweep
         # accounting
         us = ms.value * 1e3 / launches.value
@@ -409,7 +409,7 @@ def main():
         compulsory = 24.0 * cells
         alg = compulsory * spl
         ach = compulsory / (us * 1e-6) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": "mg_smooth2_kernel (level 0)", "achieved": round(ach, 1),
+        line["roofline"] = {"bound": "hbm", "kernel": ("mg_smooth2_kernel" if lib.fl_get_option(bq._lib.FL_OPT_JACOBI_ROWS) in (3, 8) else "mg_lean2r_kernel") + " (level 0)", "achieved": round(ach, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                             "frac_traffic": None, "compulsory_bytes_per_launch": int(compulsory),
                             "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),

@@ -13,6 +13,8 @@
 // 256^3 the three level-0 arrays (402 MB) exceed the 256 MiB Infinity Cache, so the level-0 sweeps are
 // HBM-bound; levels >= 1 (<= 50 MB) live in the cache.
 #include "bq_device.hip.h"
+#include "bq_buffer.hip.h"
+#include <type_traits>
 #include "bq_host.h"
 
 #include <cstdint>
@@ -330,6 +332,222 @@ __global__ __launch_bounds__(THREADS) void mg_smooth2_kernel(const double *__res
     }
 }
 
+// ---- two sweeps per launch, lean form (the fp64 twin of jacobi_lean2r_kernel, bq_project.hip) ----------------------
+// mg_smooth2_kernel rotates its plane registers by moves, computes 64-bit addresses per load and owns one row per
+// thread: 130 us per launch at 256^3 = 402 MB of compulsory traffic at 3.1 TB/s.  This is the two-row kernel of the
+// fp32 projection on double2 columns: loads and stores through buffer descriptors (row offset in a VGPR, plane offset
+// in an SGPR), plane rings with compile-time indices (loop unrolled 3 + PF times, nothing is moved), a thread owns the
+// double2 columns of rows j, j+1 and keeps L0 on rows j-1 .. j+2 (+ j-2, j+3 of the centre plane); rows of 2-4 waves
+// (nx = 256 doubles is two waves) let the first / last lane of a wave keep the column just outside the wave in a ring
+// of its own.  Every value is mg_smooth_kernel's expression on the same operands.  Preconditions as for
+// mg_smooth2_kernel, plus: x-boundary columns are stored with their L0 value (what `out` already holds there).
+struct D2 { double a, b; };                                 // two consecutive cells of a row
+__device__ __forceinline__ D2 ld_d2(v4i rs, unsigned voff, unsigned soff)
+{
+    const v2d v = __builtin_bit_cast(v2d, bq_buffer_load_x4(rs, (int)voff, (int)soff, 0));
+    return D2{v.x, v.y};
+}
+__device__ __forceinline__ double ld_d(v4i rs, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, bq_buffer_load_x2(rs, (int)voff, (int)soff, 0));
+}
+template <int AUX = 0>
+__device__ __forceinline__ void st_d2(D2 v, v4i rs, unsigned voff, unsigned soff)
+{
+    bq_buffer_store_x4(__builtin_bit_cast(v4f, v2d{v.a, v.b}), rs, (int)voff, (int)soff, AUX);
+}
+// smoothing_jacobi_kernel's expression (:1443-1461) on a double2 column; WIDE: `outside` replaces the neighbour lane's
+// value at a wave's first / last lane
+template <bool WIDE>
+__device__ __forceinline__ D2 jac_d2(D2 ce, D2 fr, D2 bk, D2 dn, D2 up, D2 dv, double alpha, double beta, bool xlo, bool xhi,
+                                     double outside, bool edgeL, bool edgeR)
+{
+    double left = lane_up(ce.b), right = lane_down(ce.a);
+    if (WIDE) {
+        if (edgeL) left = outside;
+        if (edgeR) right = outside;
+    }
+    D2 o;
+    o.a = ((left + ce.b + fr.a + bk.a + dn.a + up.a) + alpha * dv.a) * beta;
+    o.b = ((ce.a + right + fr.b + bk.b + dn.b + up.b) + alpha * dv.b) * beta;
+    if (xlo) o.a = ce.a;
+    if (xhi) o.b = ce.b;
+    return o;
+}
+
+template <bool WIDE, int PF>
+__global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict__ p, const double *__restrict__ div,
+                                                        double *__restrict__ out, int nx, int ny, int nz,
+                                                        int cw, int nby, int kchunk, double alpha, double beta)
+{
+    constexpr int P = 3 + PF;                                       // ring period
+    // PF = 2: loads two planes ahead and streaming stores, the form for arrays that come from HBM
+    constexpr bool HBM = PF >= 2;
+    constexpr int ST = HBM ? 2 : 0;
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
+    const int by = b % nby, bz = b / nby;
+    const int rows = 256 / cw;
+    // a wave holds one row pair when rows are at least one wave long: the row index is then wave-uniform
+    const int c = threadIdx.x % cw;
+    const int r = cw >= 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cw) : (int)threadIdx.x / cw;
+    const int xraw = 2 * c, j = 2 * (by * rows + r);
+    const int kA = 1, kB = nz - 1;
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;
+    const bool xok = xraw < nx;
+    const bool active0 = xok && j >= 1 && j <= ny - 2, active1 = xok && j + 1 >= 1 && j + 1 <= ny - 2;
+    const int x = xok ? xraw : nx - 2;                              // out-of-range lanes, rows, planes: clamped into the array
+    const bool xlo = x == 0, xhi = x + 1 == nx - 1;
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 8u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    unsigned vo[6];                                                 // byte offsets of this thread's column in rows j-2 .. j+3
+    bool rowb[4];                                                   // rows j-1 .. j+2 are boundary rows (keep L0)
+#pragma unroll
+    for (int a = 0; a < 6; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 2 + a, 0), ny - 1)) * 8u;
+#pragma unroll
+    for (int a = 0; a < 4; a++) rowb[a] = j - 1 + a <= 0 || j - 1 + a >= ny - 1;
+    // only the first and the last row block can hold a boundary row: everybody else runs the loop without the selects
+    const bool edge_block = 2 * by * rows - 1 <= 0 || 2 * (by * rows + rows - 1) + 2 >= ny - 1;
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 8u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    // WIDE: the first / last lane of a wave looks after the column just outside its wave (xe) -- it needs that column's
+    // L0 on rows j-1 .. j+2 (x-neighbour of our own first sweep) and its L1 on rows j, j+1 (x-neighbour of our second
+    // sweep), which it evaluates itself from that column's own neighbours (outer x-neighbour xo, rows, planes, div).
+    // The other 62 lanes run the same eight scalar loads per plane with an offset beyond the descriptor's range: the range
+    // check answers 0 and nothing goes to the caches.
+    const int lane = threadIdx.x & 63;
+    const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 2 < nx;
+    const bool edge = edgeL || edgeR;
+    const int xe = edgeL ? xraw - 1 : (edgeR ? xraw + 2 : x), xo = edgeL ? xe - 1 : (edgeR ? xe + 1 : x);
+    const bool xe_boundary = xe <= 0 || xe >= nx - 1;
+    unsigned ve[4], vx[2];
+#pragma unroll
+    for (int a = 0; a < 4; a++) ve[a] = ((unsigned)min(max(xe, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 8u;
+#pragma unroll
+    for (int a = 0; a < 2; a++) vx[a] = ((unsigned)min(max(xo, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j + a, 0), ny - 1)) * 8u;
+    if (WIDE && !edge) {
+        // an offset beyond the descriptor's range: the load returns 0 without touching the caches (2 GiB + any plane
+        // offset of an array below 2 GiB neither wraps nor lands inside it)
+#pragma unroll
+        for (int a = 0; a < 4; a++) ve[a] = 0x80000000u;
+        vx[0] = vx[1] = 0x80000000u;
+    }
+
+    // Rings indexed by the plane's slot (t + d) mod P, t = q - (kbeg - 1) the iteration number, d the plane's distance
+    // from q -- all compile-time inside the unrolled loop, so no value is ever moved to rotate planes:
+    //   L0[.][0..3]  p on rows j-1 .. j+2            (live: planes q-1 .. q+PF; q+1+PF arriving)
+    //   H[.][0..1]   p on rows j-2, j+3              (live: plane q .. q+PF-1; q+PF arriving)
+    //   L1[.][0..3]  first sweep on rows j-1 .. j+2  (q being made; q-1; q-2 (rows j, j+1))
+    //   D[.][0..3]   div on rows j-1 .. j+2          (q-1 (rows j, j+1) .. q+PF-1; q+PF arriving)
+    //   WIDE: E[.][0..3] p(xe) on rows j-1 .. j+2 like L0; Eo / Eb p(xo) / div(xe) on rows j, j+1 like H; X the outside
+    //   column's L1 on rows j, j+1 (q being made, q-1 live)
+    auto run = [&](auto EDGE_T) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
+    D2 L0[P][4], H[P][2], L1[P][4], D[P][4];
+    double E[P][4], Eo[P][2], Eb[P][2], X[P][2];
+    const D2 zero = D2{0.0, 0.0};
+#pragma unroll
+    for (int a = 0; a < P; a++) {
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) L1[a][bb] = zero;
+        X[a][0] = 0.0; X[a][1] = 0.0;
+    }
+    int q = kbeg - 1;
+#pragma unroll
+    for (int d = -1; d <= PF; d++) {                                // prologue: planes q-1 .. q+PF
+        constexpr int dummy = 0; (void)dummy;
+        const int sl_ = (d + P) % P;
+        const unsigned pp = po(q + d);
+#pragma unroll
+        for (int a = 0; a < 4; a++) L0[sl_][a] = ld_d2(rp, vo[a + 1], pp);
+        if (WIDE) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) E[sl_][a] = ld_d(rp, ve[a], pp);
+        }
+        if (d >= 0 && d < PF) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) D[sl_][a] = ld_d2(rd, vo[a + 1], pp);
+            H[sl_][0] = ld_d2(rp, vo[0], pp); H[sl_][1] = ld_d2(rp, vo[5], pp);
+            if (WIDE) {
+#pragma unroll
+                for (int a = 0; a < 2; a++) { Eo[sl_][a] = ld_d(rp, vx[a], pp); Eb[sl_][a] = ld_d(rd, ve[a + 1], pp); }
+            }
+        }
+    }
+#define MG_SL(T, d) (((T) + (d) + P) % P)
+#define MG_LEAN_PHASE(T)                                                                                            \
+    {                                                                                                               \
+        constexpr int im = MG_SL(T, -1), ic = MG_SL(T, 0), in_ = MG_SL(T, 1), ia = MG_SL(T, 1 + PF), ha = MG_SL(T, PF); \
+        constexpr int mp = MG_SL(T, -1), mpp = MG_SL(T, -2);                                                        \
+        const unsigned pa = po(q + 1 + PF), pb = po(q + PF);                                                        \
+        _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_d2(rp, vo[a + 1], pa); D[ha][a] = ld_d2(rd, vo[a + 1], pb); } \
+        H[ha][0] = ld_d2(rp, vo[0], pb); H[ha][1] = ld_d2(rp, vo[5], pb);                                           \
+        if (WIDE) {                                                                                                 \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ld_d(rp, ve[a], pa);                              \
+            _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[ha][a] = ld_d(rp, vx[a], pb); Eb[ha][a] = ld_d(rd, ve[a + 1], pb); } \
+        }                                                                                                           \
+        const bool qb = q < kA || q >= kB;                                                                          \
+        if (qb) {                                               /* a boundary plane keeps L0 */                      \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) L1[ic][a] = L0[ic][a];                                      \
+        } else {                                                                                                    \
+            L1[ic][0] = jac_d2<WIDE>(L0[ic][0], H[ic][0], L0[ic][1], L0[im][0], L0[in_][0], D[ic][0], alpha, beta, xlo, xhi, E[ic][0], edgeL, edgeR);   \
+            L1[ic][1] = jac_d2<WIDE>(L0[ic][1], L0[ic][0], L0[ic][2], L0[im][1], L0[in_][1], D[ic][1], alpha, beta, xlo, xhi, E[ic][1], edgeL, edgeR);  \
+            L1[ic][2] = jac_d2<WIDE>(L0[ic][2], L0[ic][1], L0[ic][3], L0[im][2], L0[in_][2], D[ic][2], alpha, beta, xlo, xhi, E[ic][2], edgeL, edgeR);  \
+            L1[ic][3] = jac_d2<WIDE>(L0[ic][3], L0[ic][2], H[ic][1], L0[im][3], L0[in_][3], D[ic][3], alpha, beta, xlo, xhi, E[ic][3], edgeL, edgeR);   \
+            if (EDGE) {                                                                                             \
+                _Pragma("unroll") for (int a = 0; a < 4; a++)                                                        \
+                    if (rowb[a]) L1[ic][a] = L0[ic][a];                                                             \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (WIDE) {                                             /* the outside column's own first sweep, rows j, j+1 */ \
+            _Pragma("unroll") for (int rr = 0; rr < 2; rr++) {                                                       \
+                const double own = edgeL ? L0[ic][rr + 1].a : L0[ic][rr + 1].b;                                       \
+                const double l = edgeL ? Eo[ic][rr] : own, rg2 = edgeL ? own : Eo[ic][rr];                           \
+                const double v = (l + rg2 + E[ic][rr] + E[ic][rr + 2] + E[im][rr + 1] + E[in_][rr + 1] + alpha * Eb[ic][rr]) * beta; \
+                const bool keep = qb || xe_boundary || (j + rr <= 0 || j + rr >= ny - 1);                           \
+                X[ic][rr] = keep ? E[ic][rr + 1] : v;                                                               \
+            }                                                                                                       \
+        }                                                                                                           \
+        const int k = q - 1;                                                                                        \
+        if (k >= kbeg && k < kend) {                                                                                \
+            const D2 o0 = jac_d2<WIDE>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[ic][1], D[mp][1], alpha, beta, xlo, xhi, X[mp][0], edgeL, edgeR); \
+            const D2 o1 = jac_d2<WIDE>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[ic][2], D[mp][2], alpha, beta, xlo, xhi, X[mp][1], edgeL, edgeR); \
+            const unsigned pk = pstride * (unsigned)k;                                                              \
+            if (active0) st_d2<ST>(o0, ro, vo[2], pk);                                                              \
+            if (active1) st_d2<ST>(o1, ro, vo[3], pk);                                                              \
+        }                                                                                                           \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        MG_LEAN_PHASE(0)
+        if (q > kend) break;
+        MG_LEAN_PHASE(1)
+        if (q > kend) break;
+        MG_LEAN_PHASE(2)
+        if (q > kend) break;
+        MG_LEAN_PHASE(3)
+        if (q > kend) break;
+        if constexpr (P > 4) {
+            MG_LEAN_PHASE(4)
+            if (q > kend) break;
+        }
+        if constexpr (P > 5) {
+            MG_LEAN_PHASE(5)
+            if (q > kend) break;
+        }
+        if constexpr (P > 6) {
+            MG_LEAN_PHASE(6)
+            if (q > kend) break;
+        }
+    }
+    };
+    if (edge_block) run(std::true_type{}); else run(std::false_type{});
+#undef MG_LEAN_PHASE
+}
+
+
 // ---- S sweeps per launch on the coarse levels (LDS tiles) ---------------------------------------------
 // Levels 1 .. 5 of a 256^3 V-cycle (127^3 .. 7^3) are 176 launches of mg_smooth_kernel per cycle, 2 - 12 us each and
 // mostly launch latency: 43 ms of a 229 ms step.  Here a workgroup stages a 16^3 region of x in LDS (thread (tx, ty)
@@ -502,6 +720,42 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
     const bool big = (long long)ni * nj * nk >= (1ll << 21);
     if (((rt().opt_jacobi_fuse == 1 && big) || rt().opt_jacobi_fuse >= 2) && ni >= 8) {
         const int vec = (ni % 2 == 0 && (((uintptr_t)x | (uintptr_t)temp | (uintptr_t)b) & 15u) == 0) ? 2 : 1;
+        // the lean two-row kernel: double2 columns, rows of at most 4 waves, arrays below 2 GiB (32-bit byte offsets).
+        // FL_OPT_JACOBI_ROWS = 3 / 8 keep mg_smooth2_kernel (A/B timing)
+        if (vec == 2 && ni >= 8 && ni <= 512 && nj >= 4 && (double)ni * nj * nk * 8.0 < 2147483648.0 &&
+            rt().opt_jacobi_rows != 3 && rt().opt_jacobi_rows != 8) {
+            int cw = 16;
+            while (cw * 2 < ni) cw *= 2;
+            const bool wide = cw > 64;
+            const int rows2 = 256 / cw;
+            const int nby2 = (nj + 2 * rows2 - 1) / (2 * rows2);
+            int gcd = nby2, rem = 256;
+            while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+            const int quantum = 256 / gcd;                              // chunk counts that fill the 256 CUs in whole rounds
+            const int target = wide ? 80 : 32;
+            int nchunks = ((2 * nk + target) / (2 * target) + quantum / 2) / quantum * quantum;
+            if (nchunks < quantum) nchunks = quantum;
+            int kc = (nk + nchunks - 1) / nchunks;
+            if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
+            if (kc < 4) kc = 4;
+            const int nbz = (nk + kc - 1) / kc;
+            const bool in_cache = 24.0 * (double)ni * nj * nk <= 256.0 * 1048576.0;
+            const int forced = rt().opt_jacobi_kchunk;
+            const int pf = forced == 1 || forced == 2 ? forced : (in_cache ? 1 : 2);
+            ProfileSpan span;
+            const bool prof = big && iter >= 4 && profile_begin(span);
+            const int s_begin = s;
+            for (; s + 4 <= iter; s += 4)
+                for (int h = 0; h < 2; h++) {
+#define MG_L2(W, F) mg_lean2r_kernel<W, F><<<nby2 * nbz, 256, 0, rt().compute>>>(in, b, out, ni, nj, nk, cw, nby2, kc, alpha, beta)
+                    if (wide) { if (pf == 1) MG_L2(true, 1); else MG_L2(true, 2); }
+                    else      { if (pf == 1) MG_L2(false, 1); else MG_L2(false, 2); }
+#undef MG_L2
+                    double *t = in; in = out; out = t;
+                }
+            if (prof) profile_end(span, (s - s_begin) / 2, s - s_begin);
+            BQ_LAUNCH_CHECK("mg_lean2r_kernel");
+        }
         const int lanes = (ni + vec - 1) / vec;
         const int lpr = ((lanes + 63) / 64) * 64;
         const int threads = rt().opt_jacobi_rows == 8 ? 512 : 256;      // FL_OPT_JACOBI_ROWS: waves per block (4 or 8)

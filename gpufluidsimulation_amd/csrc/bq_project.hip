@@ -7,6 +7,7 @@
 // registers, and moves everything as 16-byte vectors; see DESIGN.md "Jacobi kernel".
 // Summation order is the reference's (GPU_kernel.cu:1834), so results are bit-identical.
 #include "bq_device.hip.h"
+#include "bq_buffer.hip.h"
 #include <type_traits>
 #include "bq_host.h"
 #include <algorithm>
@@ -638,26 +639,13 @@ __global__ __launch_bounds__(WAVES * 64) void jacobi_march2r_kernel(const float 
 //   * x-boundary columns are stored too: they hold L0's value (a sweep never changes them), which is what `out`
 //     already holds there (the fused kernels' precondition: both buffers carry the same boundary layer).
 // Rows of one wave (nx <= 256); wider rows keep jacobi_march2r_kernel<.., true>.
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef int v4i __attribute__((ext_vector_type(4)));
 struct R4 { v2f a, b; };                                    // (x, y), (z, w) of one float4 column
 
-// 16-byte buffer loads / stores straight from the LLVM intrinsics (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128
-// lowers to a ONE-dword load): resource descriptor in SGPRs, 32-bit byte offset per thread, plane offset in an SGPR
-__device__ v4f bq_buffer_load_x4(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ void bq_buffer_store_x4(v4f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
-__device__ __forceinline__ v4i make_rsrc4(const void *ptr, unsigned bytes)
-{
-    const unsigned long long a = (unsigned long long)ptr;
-    return v4i{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
 __device__ __forceinline__ R4 ld_r4(v4i rs, unsigned voff, unsigned soff)
 {
     const v4f v = bq_buffer_load_x4(rs, (int)voff, (int)soff, 0);
     return R4{v2f{v.x, v.y}, v2f{v.z, v.w}};
 }
-__device__ float bq_buffer_load_x1(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ __forceinline__ float ld_f(v4i rs, unsigned voff, unsigned soff) { return bq_buffer_load_x1(rs, (int)voff, (int)soff, 0); }
 // AUX: cache policy bits of the store (2 = nt: a streaming store, for arrays that will not be read again from the caches)
 template <int AUX = 0>

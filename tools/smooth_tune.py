@@ -18,13 +18,15 @@ def main():
     host = np.random.default_rng(1).standard_normal(cells)
     lib.fl_memcpy_h2d(bufs[1], host.ctypes.data, cells * 8)
     e0, e1 = lib.fl_event_create(), lib.fl_event_create()
-    variants = [(0, 0, 0)] + [(1, w, k) for w in (4, 8) for k in (8, 16, 32, 64, 128)]
+    # (fuse, rows option, kchunk2, prefetch distance); rows 0 = the lean two-row kernel, 3 = mg_smooth2_kernel with 4 waves
+    variants = [(0, 0, 0, 0), (1, 3, 64, 0), (1, 8, 64, 0)] + [(1, 0, k, pf) for pf in (1, 2) for k in (0, 32, 43, 64, 86, 128)]
     res = {v: [] for v in variants}
     for rep in range(a.reps + 1):
         for v in variants:
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, v[0])
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, v[1])
             lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, v[2])
+            lib.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, v[3])
             lib.fl_event_record(e0)
             lib.gpu_smoothing_jacobi(bufs[0], bufs[1], bufs[2], -1.0, 1.0 / 6.0, n, n, n, a.sweeps)
             lib.fl_event_record(e1)
@@ -33,7 +35,8 @@ def main():
     bq.check()
     for v in variants:
         us = statistics.median(res[v])
-        print(f"fuse={v[0]} waves/block={v[1]:2d} kchunk={v[2]:3d}: {us:8.2f} us/sweep  {24.0 * cells / us / 1e6:6.2f} TB/s algorithmic")
+        print(f"fuse={v[0]} rows-option={v[1]:2d} kchunk={v[2]:3d} pf={v[3]}: {us:8.2f} us/sweep  {24.0 * cells / us / 1e6:6.2f} TB/s algorithmic"
+              f"  ({24.0 * cells / (us * (2 if v[0] else 1)) / 1e6:5.2f} TB/s of compulsory traffic per launch)")
 
 if __name__ == "__main__":
     main()
