@@ -192,7 +192,8 @@ def main():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
     force_fail = os.environ.get("BENCH_FORCE_RCCL_FAILURE") == "1"      # test hook for the fallback below
     if local_rank >= torch.cuda.device_count():
-        if args.transport != "host" and not force_fail:
+        # (BQ_RCCL_LIBRARY: the tests' multi-process stand-in for RCCL lets ranks share a GPU, real RCCL does not)
+        if args.transport != "host" and not force_fail and not os.environ.get("BQ_RCCL_LIBRARY"):
             sys.exit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
         local_rank %= torch.cuda.device_count()         # debug transport: several ranks may share a GPU
     torch.cuda.set_device(local_rank)

@@ -12,6 +12,7 @@
 #include "bq_host.h"
 
 #include <dlfcn.h>
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -70,7 +71,11 @@ static bool load_rccl()
     if (g_rccl.handle) return true;
     const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
     void *h = nullptr;
-    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    // BQ_RCCL_LIBRARY: load this library instead (another RCCL build; the tests' multi-process stand-in for one-GPU boxes,
+    // tests/fake_rccl).  No fallback to the default names when it is set.
+    const char *forced = getenv("BQ_RCCL_LIBRARY");
+    if (forced && *forced) h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    else for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { latch(FL_ERR_COMM, "dlopen(librccl)", dlerror()); return false; }
     g_rccl.handle = h;
 #define BQ_SYM(field, name) *(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) { latch(FL_ERR_COMM, "dlsym", name); return false; }

@@ -1,0 +1,98 @@
+"""The library's RCCL code path with MORE THAN ONE RANK on a one-GPU box.
+
+Real RCCL refuses two ranks on one device, so the neighbour exchange (fl_halo_exchange), the wall-sheet messages between
+arbitrary ranks (fl_p2p_exchange) and the in-stream all-reduces of csrc/bq_halo.hip could otherwise only be run with a
+single rank (fl_comm_selftest).  tests/fake_rccl is a stand-in for librccl.so over POSIX shared memory (it checks that
+every receive meets a send of the same size from the same peer in issue order, and times out loudly on a deadlock);
+BQ_RCCL_LIBRARY makes the library load it.  What these tests establish: the bootstrap (unique id over gloo ->
+fl_comm_init on every rank), the grouped send/receive protocol of 2-, 3- and 4-rank runs, and `bench.py --gpus N` on
+the RCCL branch -- all bit-identical to the single-domain oracle / the single-GPU run.  What they cannot: xGMI, real
+asynchrony (the stand-in synchronises the stream it is given)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def fake():
+    from build_fake_rccl import build
+    import oracle_lib
+    oracle_lib.build()
+    return build()
+
+
+def launch_worker(fake, nproc, *args, timeout=900):
+    env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1", BQ_RCCL_LIBRARY=fake)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--backend", "gpu", "--transport", "rccl", *map(str, args)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("[rank") or "fake_rccl" in l]
+    return r.returncode, "\n".join(lines[-30:]) or r.stdout[-3000:]
+
+
+def test_two_ranks_over_the_rccl_branch(fake):
+    """default mode (zeroed DMC border -> wall sheets travel through fl_p2p_exchange), overlapped exchanges"""
+    rc, out = launch_worker(fake, 2, "--steps", 4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+
+
+def test_three_ranks_over_the_rccl_branch(fake):
+    """a middle rank with two neighbours; wall sheets between non-neighbours (rank 2 needs planes of rank 0)"""
+    rc, out = launch_worker(fake, 3, "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
+def test_four_ranks_without_overlap_and_with_viscosity(fake):
+    rc, out = launch_worker(fake, 4, "--dims", 24, 20, 48, "--ghost", 6, "--steps", 3, "--iters", 12, "--dt-cells", 1.0,
+                            "--overlap", 0, "--viscosity", 2e-3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 4
+
+
+def test_bench_gpus_2_runs_the_rccl_branch(fake, tmp_path):
+    """`python bench.py --gpus 2` (self-launched ranks, default --transport rccl): the line says RCCL saw two ranks, and
+    the per-slab dumps of the run stitch to the single-GPU dump byte for byte"""
+    import numpy as np
+    from gpufluidsimulation_amd.solver import read_density_dump
+    env = dict(os.environ, OMP_NUM_THREADS="4", BQ_RCCL_LIBRARY=fake)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    common = ["--size", "64", "--steps", "3", "--warmup", "0", "--jacobi-iters", "40", "--no-cpu-baseline", "--no-extra"]
+
+    def run(*args):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0]), r.stderr
+
+    a, _ = run(*common, "--dump", one)
+    b, err = run("--gpus", "2", *common, "--dump", two)
+    assert "falling back" not in err, err[-2000:]
+    assert b["n_gpus"] == 2 and b["config"]["comm_size"] == 2 and "rccl" in b["config"]["parallelism"].lower()
+    assert "FALLBACK" not in b["config"]["parallelism"]
+    for f in sorted(os.listdir(one)):
+        _, rec = read_density_dump(os.path.join(one, f))
+        parts = sorted(p for p in os.listdir(two) if p.startswith(f[:-4] + ".k"))
+        assert len(parts) == 2
+        stitched = np.concatenate([read_density_dump(os.path.join(two, p))[1] for p in parts])
+        assert len(rec) > 100 and stitched.tobytes() == rec.tobytes(), f
