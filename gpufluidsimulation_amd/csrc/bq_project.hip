@@ -657,7 +657,9 @@ __device__ __forceinline__ void st_r4(R4 v, v4i rs, unsigned voff, unsigned soff
 // jacobi_kernel's expression (GPU_kernel.cu:1833) on a float4 column: ((((((l + r) + f) + b) + d) + u) + alpha div) beta
 // WIDE (rows of several waves): the x-neighbour of a wave's first / last lane lives in another wave; `outside` is its
 // value, supplied by that lane itself (edgeL / edgeR mark the two lanes)
-template <bool WIDE = false>
+// PRE: dv already holds alpha * div (the product is formed once per loaded div value and reused by every level that needs
+// it -- the same float either way)
+template <bool WIDE = false, bool PRE = false>
 __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, float alpha, float beta, bool xlo, bool xhi,
                                      float outside = 0.f, bool edgeL = false, bool edgeR = false)
 {
@@ -672,7 +674,8 @@ __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, f
     s0 = s0 + bk.a; s1 = s1 + bk.b;
     s0 = s0 + dn.a; s1 = s1 + dn.b;
     s0 = s0 + up.a; s1 = s1 + up.b;
-    s0 = s0 + alpha * dv.a; s1 = s1 + alpha * dv.b;
+    if (PRE) { s0 = s0 + dv.a; s1 = s1 + dv.b; }
+    else     { s0 = s0 + alpha * dv.a; s1 = s1 + alpha * dv.b; }
     s0 = s0 * beta; s1 = s1 * beta;
     if (xlo) s0.x = ce.a.x;
     if (xhi) s1.y = ce.b.y;
@@ -800,10 +803,12 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         if (qb) {                                               /* a boundary plane keeps L0 */                      \
             _Pragma("unroll") for (int a = 0; a < 4; a++) L1[ic][a] = L0[ic][a];                                      \
         } else {                                                                                                    \
-            L1[ic][0] = jac_r4<WIDE>(L0[ic][0], H[ic][0], L0[ic][1], L0[im][0], L0[in_][0], D[ic][0], alpha, beta, xlo, xhi, E[ic][0], edgeL, edgeR);   \
-            L1[ic][1] = jac_r4<WIDE>(L0[ic][1], L0[ic][0], L0[ic][2], L0[im][1], L0[in_][1], D[ic][1], alpha, beta, xlo, xhi, E[ic][1], edgeL, edgeR);  \
-            L1[ic][2] = jac_r4<WIDE>(L0[ic][2], L0[ic][1], L0[ic][3], L0[im][2], L0[in_][2], D[ic][2], alpha, beta, xlo, xhi, E[ic][2], edgeL, edgeR);  \
-            L1[ic][3] = jac_r4<WIDE>(L0[ic][3], L0[ic][2], H[ic][1], L0[im][3], L0[in_][3], D[ic][3], alpha, beta, xlo, xhi, E[ic][3], edgeL, edgeR);   \
+            /* alpha * div once per value: rows j, j+1 reuse the product in the second sweep */                      \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) { D[ic][a].a = alpha * D[ic][a].a; D[ic][a].b = alpha * D[ic][a].b; } \
+            L1[ic][0] = jac_r4<WIDE, true>(L0[ic][0], H[ic][0], L0[ic][1], L0[im][0], L0[in_][0], D[ic][0], alpha, beta, xlo, xhi, E[ic][0], edgeL, edgeR);   \
+            L1[ic][1] = jac_r4<WIDE, true>(L0[ic][1], L0[ic][0], L0[ic][2], L0[im][1], L0[in_][1], D[ic][1], alpha, beta, xlo, xhi, E[ic][1], edgeL, edgeR);  \
+            L1[ic][2] = jac_r4<WIDE, true>(L0[ic][2], L0[ic][1], L0[ic][3], L0[im][2], L0[in_][2], D[ic][2], alpha, beta, xlo, xhi, E[ic][2], edgeL, edgeR);  \
+            L1[ic][3] = jac_r4<WIDE, true>(L0[ic][3], L0[ic][2], H[ic][1], L0[im][3], L0[in_][3], D[ic][3], alpha, beta, xlo, xhi, E[ic][3], edgeL, edgeR);   \
             if (EDGE) {                                                                                             \
                 _Pragma("unroll") for (int a = 0; a < 4; a++)                                                        \
                     if (rowb[a]) L1[ic][a] = L0[ic][a];                                                             \
@@ -820,8 +825,8 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
         }                                                                                                           \
         const int k = q - 1;                                                                                        \
         if (k >= kbeg && k < kend) {                                                                                \
-            const R4 o0 = jac_r4<WIDE>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[ic][1], D[mp][1], alpha, beta, xlo, xhi, X[mp][0], edgeL, edgeR); \
-            const R4 o1 = jac_r4<WIDE>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[ic][2], D[mp][2], alpha, beta, xlo, xhi, X[mp][1], edgeL, edgeR); \
+            const R4 o0 = jac_r4<WIDE, true>(L1[mp][1], L1[mp][0], L1[mp][2], L1[mpp][1], L1[ic][1], D[mp][1], alpha, beta, xlo, xhi, X[mp][0], edgeL, edgeR); \
+            const R4 o1 = jac_r4<WIDE, true>(L1[mp][2], L1[mp][1], L1[mp][3], L1[mpp][2], L1[ic][2], D[mp][2], alpha, beta, xlo, xhi, X[mp][1], edgeL, edgeR); \
             const unsigned pk = pstride * (unsigned)k;                                                              \
             if (active0) st_r4<ST>(o0, ro, vo[2], pk);                                                              \
             if (active1) st_r4<ST>(o1, ro, vo[3], pk);                                                              \
@@ -931,9 +936,11 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
         if (q < kA || q >= kB) {                                /* first sweep on plane q, rows j-2 .. j+3 */        \
             _Pragma("unroll") for (int a = 0; a < 6; a++) L1[a0][a] = L0[ic][a];                                      \
         } else {                                                                                                    \
+            /* alpha * div once per value: this plane's first sweep and the later sweeps on it reuse the product */   \
+            _Pragma("unroll") for (int a = 0; a < 6; a++) { D[d0][a].a = alpha * D[d0][a].a; D[d0][a].b = alpha * D[d0][a].b; } \
             _Pragma("unroll") for (int a = 0; a < 6; a++) {                                                          \
                 const R4 fr = a == 0 ? H[hc][0] : L0[ic][a == 0 ? 0 : a - 1], bk = a == 5 ? H[hc][1] : L0[ic][a == 5 ? 5 : a + 1]; \
-                L1[a0][a] = jac_r4(L0[ic][a], fr, bk, L0[im][a], L0[in_][a], D[d0][a], alpha, beta, xlo, xhi);       \
+                L1[a0][a] = jac_r4<false, true>(L0[ic][a], fr, bk, L0[im][a], L0[in_][a], D[d0][a], alpha, beta, xlo, xhi); \
                 if (EDGE && rowb[a]) L1[a0][a] = L0[ic][a];                                                         \
             }                                                                                                       \
         }                                                                                                           \
@@ -941,14 +948,14 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
             _Pragma("unroll") for (int a = 0; a < 4; a++) L2[b1][a] = L1[a1][a + 1];                                  \
         } else {                                                                                                    \
             _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                          \
-                L2[b1][a] = jac_r4(L1[a1][a + 1], L1[a1][a], L1[a1][a + 2], L1[a2][a + 1], L1[a0][a + 1], D[d1][a + 1], alpha, beta, xlo, xhi); \
+                L2[b1][a] = jac_r4<false, true>(L1[a1][a + 1], L1[a1][a], L1[a1][a + 2], L1[a2][a + 1], L1[a0][a + 1], D[d1][a + 1], alpha, beta, xlo, xhi); \
                 if (EDGE && rowb[a + 1]) L2[b1][a] = L1[a1][a + 1];                                                 \
             }                                                                                                       \
         }                                                                                                           \
         const int k = q - 2;                                                                                        \
         if (k >= kbeg && k < kend) {                            /* third sweep on plane q-2, rows j, j+1: stored */  \
-            const R4 o0 = jac_r4(L2[b2][1], L2[b2][0], L2[b2][2], L2[b3][1], L2[b1][1], D[d2][2], alpha, beta, xlo, xhi); \
-            const R4 o1 = jac_r4(L2[b2][2], L2[b2][1], L2[b2][3], L2[b3][2], L2[b1][2], D[d2][3], alpha, beta, xlo, xhi); \
+            const R4 o0 = jac_r4<false, true>(L2[b2][1], L2[b2][0], L2[b2][2], L2[b3][1], L2[b1][1], D[d2][2], alpha, beta, xlo, xhi); \
+            const R4 o1 = jac_r4<false, true>(L2[b2][2], L2[b2][1], L2[b2][3], L2[b3][2], L2[b1][2], D[d2][3], alpha, beta, xlo, xhi); \
             const unsigned pk = pstride * (unsigned)k;                                                              \
             if (active0) st_r4(o0, ro, vo[3], pk);                                                                  \
             if (active1) st_r4(o1, ro, vo[4], pk);                                                                  \
