@@ -668,6 +668,9 @@ __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, f
         if (edgeL) left = outside;
         if (edgeR) right = outside;
     }
+    // (the compiler forms two v_pk_add_f32 here and assembles their operand pairs {left, x0}, {x1, x2}, {x3, right} with
+    // six moves; four scalar adds with the neighbour lanes taken through the adds' own DPP operand (inline asm) are 4
+    // instructions instead of 10, but measured no faster: 13.25 vs 13.23 us per sweep in the three-sweep kernel)
     v2f s0 = v2f{left + ce.a.y, ce.a.x + ce.b.x};
     v2f s1 = v2f{ce.a.y + ce.b.y, ce.b.x + right};
     s0 = s0 + fr.a; s1 = s1 + fr.b;
@@ -870,10 +873,12 @@ __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restr
 // two outputs of three sweeps (two sweeps: 6 and 10 for two).  ~400 registers: one wave per SIMD.  Every value is
 // jacobi_kernel's expression, planes and rows outside the interior keep their input through all three levels, so the
 // result is bit-identical to three single sweeps.  Preconditions as for the two-sweep kernels.
+template <int PF>
 __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                             float *__restrict__ out, int nx, int ny, int nz,
                                                             int cw, int nby, int kchunk, float alpha, float beta, Slab sl)
 {
+    constexpr int P = 3 + PF;                                       // ring period; loads run PF planes ahead
     const int nblk = gridDim.x;
     int b = blockIdx.x;
     if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
@@ -902,37 +907,42 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
     auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
     auto run = [&](auto EDGE_T) {
     constexpr bool EDGE = decltype(EDGE_T)::value;
-    R4 L0[4][6], H[2][2], L1[4][6], L2[4][4], D[4][6];
+    // rings indexed by (iteration + distance) mod P, all compile-time inside the unrolled loop:
+    //   L0: planes q-1, q, q+1 .. q+PF live, q+1+PF arriving;  H (rows j-3, j+4) and D: q .. q+PF-1 (D also q-1, q-2), q+PF arriving;
+    //   L1: q (being made), q-1, q-2;  L2: q-1 (being made), q-2, q-3
+    R4 L0[P][6], H[P][2], L1[P][6], L2[P][4], D[P][6];
     const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
+    for (int a = 0; a < P; a++) {
 #pragma unroll
         for (int bb = 0; bb < 6; bb++) { L1[a][bb] = zero; D[a][bb] = zero; }
 #pragma unroll
         for (int bb = 0; bb < 4; bb++) L2[a][bb] = zero;
     }
     int q = kbeg - 2;
-    {
-        const unsigned pm = po(q - 1), pc = po(q), pn = po(q + 1);
+#define BQ_SL3(T, d) ((((T) + (d)) % P + P) % P)
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-            L0[3][a] = ld_r4(rp, vo[a + 1], pm);
-            L0[0][a] = ld_r4(rp, vo[a + 1], pc);
-            L0[1][a] = ld_r4(rp, vo[a + 1], pn);
-            D[0][a] = ld_r4(rd, vo[a + 1], pc);
+    for (int d = -1; d <= PF; d++) {                                // prologue: planes q-1 .. q+PF
+        const int sl_ = BQ_SL3(0, d);
+        const unsigned pp = po(q + d);
+#pragma unroll
+        for (int a = 0; a < 6; a++) L0[sl_][a] = ld_r4(rp, vo[a + 1], pp);
+        if (d >= 0 && d < PF) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
+            H[sl_][0] = ld_r4(rp, vo[0], pp); H[sl_][1] = ld_r4(rp, vo[7], pp);
         }
-        H[0][0] = ld_r4(rp, vo[0], pc); H[0][1] = ld_r4(rp, vo[7], pc);
     }
 #define BQ_LEAN3_PHASE(T)                                                                                           \
     {                                                                                                               \
-        constexpr int im = (T + 3) & 3, ic = T, in_ = (T + 1) & 3, ia = (T + 2) & 3;      /* L0: q-1, q, q+1, q+2 */    \
-        constexpr int hc = T & 1, hn = (T + 1) & 1;                                                                \
-        constexpr int a0 = T, a1 = (T + 3) & 3, a2 = (T + 2) & 3;                          /* L1: q, q-1, q-2 */        \
-        constexpr int b1 = (T + 3) & 3, b2 = (T + 2) & 3, b3 = (T + 1) & 3;                /* L2: q-1, q-2, q-3 */      \
-        constexpr int d0 = T, dn_ = (T + 1) & 3, d1 = (T + 3) & 3, d2 = (T + 2) & 3;       /* D: q, q+1, q-1, q-2 */    \
-        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
-        _Pragma("unroll") for (int a = 0; a < 6; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[dn_][a] = ld_r4(rd, vo[a + 1], pb); } \
-        H[hn][0] = ld_r4(rp, vo[0], pb); H[hn][1] = ld_r4(rp, vo[7], pb);                                           \
+        constexpr int im = BQ_SL3(T, -1), ic = BQ_SL3(T, 0), in_ = BQ_SL3(T, 1), ia = BQ_SL3(T, 1 + PF);  /* L0 */    \
+        constexpr int hc = BQ_SL3(T, 0), ha = BQ_SL3(T, PF);                                                        \
+        constexpr int a0 = BQ_SL3(T, 0), a1 = BQ_SL3(T, -1), a2 = BQ_SL3(T, -2);             /* L1: q, q-1, q-2 */    \
+        constexpr int b1 = BQ_SL3(T, -1), b2 = BQ_SL3(T, -2), b3 = BQ_SL3(T, -3);            /* L2: q-1, q-2, q-3 */  \
+        constexpr int d0 = BQ_SL3(T, 0), d1 = BQ_SL3(T, -1), d2 = BQ_SL3(T, -2);                                    \
+        const unsigned pa = po(q + 1 + PF), pb = po(q + PF);                                                        \
+        _Pragma("unroll") for (int a = 0; a < 6; a++) { L0[ia][a] = ld_r4(rp, vo[a + 1], pa); D[ha][a] = ld_r4(rd, vo[a + 1], pb); } \
+        H[ha][0] = ld_r4(rp, vo[0], pb); H[ha][1] = ld_r4(rp, vo[7], pb);                                           \
         if (q < kA || q >= kB) {                                /* first sweep on plane q, rows j-2 .. j+3 */        \
             _Pragma("unroll") for (int a = 0; a < 6; a++) L1[a0][a] = L0[ic][a];                                      \
         } else {                                                                                                    \
@@ -971,10 +981,15 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
         if (q > kend + 1) break;
         BQ_LEAN3_PHASE(3)
         if (q > kend + 1) break;
+        if constexpr (P > 4) {
+            BQ_LEAN3_PHASE(4)
+            if (q > kend + 1) break;
+        }
     }
     };
     if (edge_block) run(std::true_type{}); else run(std::false_type{});
 #undef BQ_LEAN3_PHASE
+#undef BQ_SL3
 }
 
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
@@ -1260,7 +1275,9 @@ static bool jacobi_sweep_triple(const float *in, const float *div, float *out, i
     if (kc < 16 && rt().opt_jacobi_rows != 2) return false;  // chunks too short to pay for four warm-up planes
     if (kc < 4) kc = 4;
     const int nbz = (nk + kc - 1) / kc;
-    jacobi_lean3r_kernel<<<nby2 * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk));
+    // FL_OPT_JACOBI_KCHUNK = 1 / 2: how many planes ahead the loads run
+    if (rt().opt_jacobi_kchunk == 2) jacobi_lean3r_kernel<2><<<nby2 * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk));
+    else                             jacobi_lean3r_kernel<1><<<nby2 * nbz, 256, 0, rt().compute>>>(in, div, out, ni, nj, nk, cw, nby2, kc, alpha, beta, slab_of(nk));
     BQ_LAUNCH_CHECK("jacobi_lean3r_kernel");
     g_last_pair_kernel = "jacobi_lean3r_kernel";
     return true;
