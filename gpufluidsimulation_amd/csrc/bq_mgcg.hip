@@ -397,9 +397,12 @@ __global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict
     const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
     if (kbeg >= kend) return;
     const bool xok = xraw < nx;
-    const bool active0 = xok && j >= 1 && j <= ny - 2, active1 = xok && j + 1 >= 1 && j + 1 <= ny - 2;
-    const int x = xok ? xraw : nx - 2;                              // out-of-range lanes, rows, planes: clamped into the array
-    const bool xlo = x == 0, xhi = x + 1 == nx - 1;
+    // odd rows: the last lane of a row holds the single boundary column nx-1 in .a (its .b is the next row's first cell:
+    // loaded, never used, never stored -- the lane stores nothing, `out` already holds the boundary column)
+    const bool xlast = xok && xraw == nx - 1;
+    const bool active0 = xok && !xlast && j >= 1 && j <= ny - 2, active1 = xok && !xlast && j + 1 >= 1 && j + 1 <= ny - 2;
+    const int x = xok ? xraw : 0;                                   // out-of-range lanes, rows, planes: clamped into the array
+    const bool xlo = x == 0 || xlast, xhi = x + 1 == nx - 1;
     const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 8u;
     const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
     unsigned vo[6];                                                 // byte offsets of this thread's column in rows j-2 .. j+3
@@ -718,11 +721,15 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
     // k-marching pipeline is too short per block and the plain kernel wins: 11.5 vs 13.5 us, 2.5 vs 3.8 us).
     // FL_OPT_JACOBI_FUSE = 2 forces the fused kernel wherever it applies (tests).
     const bool big = (long long)ni * nj * nk >= (1ll << 21);
-    if (((rt().opt_jacobi_fuse == 1 && big) || rt().opt_jacobi_fuse >= 2) && ni >= 8) {
+    // the lean two-row kernel also pays one level down (127^3: 2.05 M cells)
+    const bool mid = (long long)ni * nj * nk >= (1ll << 20);
+    if (((rt().opt_jacobi_fuse == 1 && (big || mid)) || rt().opt_jacobi_fuse >= 2) && ni >= 8) {
         const int vec = (ni % 2 == 0 && (((uintptr_t)x | (uintptr_t)temp | (uintptr_t)b) & 15u) == 0) ? 2 : 1;
         // the lean two-row kernel: double2 columns, rows of at most 4 waves, arrays below 2 GiB (32-bit byte offsets).
         // FL_OPT_JACOBI_ROWS = 3 / 8 keep mg_smooth2_kernel (A/B timing)
-        if (vec == 2 && ni >= 8 && ni <= 512 && nj >= 4 && (double)ni * nj * nk * 8.0 < 2147483648.0 &&
+        // (odd rows: 16-byte loads at 8-byte-aligned addresses, which the memory pipeline splits -- the same mode the
+        // gather kernels' dwordx2 loads at 4-byte alignment rely on)
+        if ((vec == 2 || ni % 2 == 1) && ni >= 8 && ni <= 512 && nj >= 4 && (double)ni * nj * nk * 8.0 < 2147483648.0 &&
             rt().opt_jacobi_rows != 3 && rt().opt_jacobi_rows != 8) {
             int cw = 16;
             while (cw * 2 < ni) cw *= 2;
@@ -759,7 +766,7 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
         const int lanes = (ni + vec - 1) / vec;
         const int lpr = ((lanes + 63) / 64) * 64;
         const int threads = rt().opt_jacobi_rows == 8 ? 512 : 256;      // FL_OPT_JACOBI_ROWS: waves per block (4 or 8)
-        if (lpr <= threads) {
+        if (lpr <= threads && (big || rt().opt_jacobi_fuse >= 2)) {      // (slower than one launch per sweep below 2 M cells)
             const int rows = threads / lpr;
             const int nby = (nj + rows - 1) / rows;
             int kchunk = rt().opt_jacobi_kchunk2 > 0 ? rt().opt_jacobi_kchunk2 : 64;

@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--sweeps", type=int, default=32)
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--variants", type=str, default="", help="fuse:rows:kchunk2:pf,...")
     a = ap.parse_args()
     lib = bq.hip_lib(); assert lib.fl_init(0) == 0
     n = a.n; cells = n ** 3
@@ -20,6 +21,8 @@ def main():
     e0, e1 = lib.fl_event_create(), lib.fl_event_create()
     # (fuse, rows option, kchunk2, prefetch distance); rows 0 = the lean two-row kernel, 3 = mg_smooth2_kernel with 4 waves
     variants = [(0, 0, 0, 0), (1, 3, 64, 0), (1, 8, 64, 0)] + [(1, 0, k, pf) for pf in (1, 2) for k in (0, 32, 43, 64, 86, 128)]
+    if a.variants:
+        variants = [tuple(int(x) for x in v.split(':')) for v in a.variants.split(',')]
     res = {v: [] for v in variants}
     for rep in range(a.reps + 1):
         for v in variants:
