@@ -118,6 +118,61 @@ __global__ __launch_bounds__(256) void mg_calc_sum_kernel(const double *__restri
     }
 }
 
+// The same sums in two launches.  One workgroup whose thread t walks its own 2 KB of partials reads 64 cache lines per
+// load instruction: 36 us for the 65 536 partials of a 256^3 dot product, 101 times per step.  Here workgroup g takes the
+// reference's threads 16 g .. 16 g + 15: their 16 x per_thread partials are loaded coalesced into LDS (in tiles of 256
+// columns), 16 lanes add their row in the reference's order, and a second launch runs the 16 x 16 tree on the 256 row sums.
+__global__ __launch_bounds__(256) void mg_calc_sum_rows_kernel(const double *__restrict__ v, double *__restrict__ rows,
+                                                               size_t count, size_t per_thread)
+{
+    __shared__ double tile[16][257];                        // (+1: the 16 summing lanes read one column of 16 rows at a time)
+    const int t0 = blockIdx.x * 16;
+    double s = 0;
+    for (size_t c0 = 0; c0 < per_thread; c0 += 256) {
+        const size_t w = per_thread - c0 < 256 ? per_thread - c0 : 256;
+        __syncthreads();
+        for (int r = 0; r < 16; r++) {
+            const size_t id = (size_t)(t0 + r) * per_thread + c0 + threadIdx.x;
+            if (threadIdx.x < w) tile[r][threadIdx.x] = id < count ? v[id] : 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const size_t start = (size_t)(t0 + threadIdx.x) * per_thread + c0;
+            // partials beyond `count` are not added (the reference's bound check): n of this tile's w columns are
+            const size_t n = start >= count ? 0 : (count - start < w ? count - start : w);
+            const double *row = tile[threadIdx.x];
+            size_t q = 0;
+            for (; q + 8 <= n; q += 8) {                    // the LDS reads of a group are independent, the adds stay in order
+                double t[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) t[e] = row[q + e];
+#pragma unroll
+                for (int e = 0; e < 8; e++) s += t[e];
+            }
+            for (; q < n; q++) s += row[q];
+        }
+    }
+    if (threadIdx.x < 16) rows[t0 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void mg_calc_sum_tree_kernel(const double *__restrict__ rows, double *__restrict__ output, int iter_index)
+{
+    __shared__ double sh[16];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        double a = rows[t * 16];
+#pragma unroll
+        for (int q = 1; q < 16; q++) a = a + rows[t * 16 + q];
+        sh[t] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sh[0];
+#pragma unroll
+        for (int q = 1; q < 16; q++) a = a + sh[q];
+        output[iter_index] = a;
+    }
+}
+
 // calc_max (:1185-1237): max(v, 0) over the array -- order-free, so split over many blocks
 __global__ __launch_bounds__(256) void mg_max_partial_kernel(const double *__restrict__ v, size_t count, double *__restrict__ part)
 {
@@ -638,21 +693,35 @@ __device__ __forceinline__ float lerp_f(float a, float b, float c)
     return (float)((1.0 - (double)c) * (double)a + (double)cb);
 }
 
-// sample_buffer<double> (:1527-1549): no clamping (M4); `count` = elements of the array
-__device__ __forceinline__ double sample_t(const double *b, int nx, int ny, long long count, float px, float py, float pz)
+// sample_buffer<double> (:1527-1549): no clamping (M4); `count` = elements of the array.  IDX: the index type -- int for
+// arrays below 2^31 elements (every flat index of a sample then fits, negative ones included), long long otherwise
+template <typename IDX>
+__device__ __forceinline__ double sample_t(const double *b, int nx, int ny, IDX count, float px, float py, float pz)
 {
     const int i = (int)floorf(px), j = (int)floorf(py), k = (int)floorf(pz);
     const float a = px - (float)i, bb = py - (float)j, c = pz - (float)k;
-    const long long sj = nx, sk = (long long)nx * ny;
-    const long long base = (long long)i + sj * j + sk * k;
+    const IDX sj = nx, sk = (IDX)nx * ny;
+    const IDX base = (IDX)i + sj * j + sk * k;
+    // the eight loads are issued unconditionally from addresses clamped into the array and the out-of-array ones replaced
+    // by 0 afterwards: a branch per load (what `cond ? b[id] : 0` compiles to) serialises eight memory latencies
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const long long id = base + (q & 1) + ((q >> 1) & 1) * sj + ((q >> 2) & 1) * sk;
-        v[q] = (id >= 0 && id < count) ? (float)b[id] : 0.f;
+        const IDX id = base + (q & 1) + ((q >> 1) & 1) * sj + ((q >> 2) & 1) * sk;
+        const IDX idc = id < 0 ? 0 : (id < count ? id : count - 1);
+        const float t = (float)b[idc];
+        v[q] = (id >= 0 && id < count) ? t : 0.f;
     }
     return (double)lerp_f(lerp_f(lerp_f(v[0], v[1], a), lerp_f(v[2], v[3], a), bb),
                           lerp_f(lerp_f(v[4], v[5], a), lerp_f(v[6], v[7], a), bb), c);
+}
+
+// the trilinear sample of sample_t from a 3x3x3 block of cells held in registers (restriction: the eight samples of a
+// coarse cell overlap in 27 fine cells); (ox, oy, oz) in {0, 1}: which 2x2x2 corner of the block
+__device__ __forceinline__ double sample_block(const float (&blk)[3][3][3], int ox, int oy, int oz, float a, float bb, float c)
+{
+    return (double)lerp_f(lerp_f(lerp_f(blk[oz][oy][ox], blk[oz][oy][ox + 1], a), lerp_f(blk[oz][oy + 1][ox], blk[oz][oy + 1][ox + 1], a), bb),
+                          lerp_f(lerp_f(blk[oz + 1][oy][ox], blk[oz + 1][oy][ox + 1], a), lerp_f(blk[oz + 1][oy + 1][ox], blk[oz + 1][oy + 1][ox + 1], a), bb), c);
 }
 
 // restriction_kernel, double (:1551-1603): every coarse cell = mean of 8 samples at the fine cell centres
@@ -664,14 +733,36 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restri
     const float x0 = (float)(2 * i + 0.5), x1 = (float)(2 * i + 1.5);
     const float y0 = (float)(2 * j + 0.5), y1 = (float)(2 * j + 1.5);
     const float z0 = (float)(2 * k + 0.5), z1 = (float)(2 * k + 1.5);
-    const double v0 = sample_t(residual, ni, nj, count, x0, y0, z0);
-    const double v1 = sample_t(residual, ni, nj, count, x0, y0, z1);
-    const double v2 = sample_t(residual, ni, nj, count, x0, y1, z0);
-    const double v3 = sample_t(residual, ni, nj, count, x0, y1, z1);
-    const double v4 = sample_t(residual, ni, nj, count, x1, y0, z0);
-    const double v5 = sample_t(residual, ni, nj, count, x1, y0, z1);
-    const double v6 = sample_t(residual, ni, nj, count, x1, y1, z0);
-    const double v7 = sample_t(residual, ni, nj, count, x1, y1, z1);
+    // sample_t's cell and weights for each of the six coordinates; the eight samples read the 3x3x3 block of fine cells
+    // that starts at (floor x0, floor y0, floor z0) -- floor x1 = floor x0 + 1 for every index a float holds exactly
+    const int i0 = (int)floorf(x0), j0 = (int)floorf(y0), k0 = (int)floorf(z0);
+    const int i1 = (int)floorf(x1), j1 = (int)floorf(y1), k1 = (int)floorf(z1);
+    const float ax0 = x0 - (float)i0, ax1 = x1 - (float)i1, ay0 = y0 - (float)j0, ay1 = y1 - (float)j1, az0 = z0 - (float)k0, az1 = z1 - (float)k1;
+    if (i1 != i0 + 1 || j1 != j0 + 1 || k1 != k0 + 1) {            // (grids beyond 2^22 cells per axis: the general form)
+        const double v0 = sample_t<long long>(residual, ni, nj, count, x0, y0, z0), v1 = sample_t<long long>(residual, ni, nj, count, x0, y0, z1);
+        const double v2 = sample_t<long long>(residual, ni, nj, count, x0, y1, z0), v3 = sample_t<long long>(residual, ni, nj, count, x0, y1, z1);
+        const double v4 = sample_t<long long>(residual, ni, nj, count, x1, y0, z0), v5 = sample_t<long long>(residual, ni, nj, count, x1, y0, z1);
+        const double v6 = sample_t<long long>(residual, ni, nj, count, x1, y1, z0), v7 = sample_t<long long>(residual, ni, nj, count, x1, y1, z1);
+        coarse[id3(i, j, k, ci, cj)] = (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7) / 8;
+        return;
+    }
+    const long long sj = ni, sk = (long long)ni * nj;
+    const long long base = (long long)i0 + sj * j0 + sk * k0;
+    float blk[3][3][3];
+#pragma unroll
+    for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const long long id = base + dx + dy * sj + dz * sk;             // flat, unclamped (M4): >= 0 here
+                const float t = (float)residual[id < count ? id : count - 1];
+                blk[dz][dy][dx] = id < count ? t : 0.f;
+            }
+    const double v0 = sample_block(blk, 0, 0, 0, ax0, ay0, az0), v1 = sample_block(blk, 0, 0, 1, ax0, ay0, az1);
+    const double v2 = sample_block(blk, 0, 1, 0, ax0, ay1, az0), v3 = sample_block(blk, 0, 1, 1, ax0, ay1, az1);
+    const double v4 = sample_block(blk, 1, 0, 0, ax1, ay0, az0), v5 = sample_block(blk, 1, 0, 1, ax1, ay0, az1);
+    const double v6 = sample_block(blk, 1, 1, 0, ax1, ay1, az0), v7 = sample_block(blk, 1, 1, 1, ax1, ay1, az1);
     coarse[id3(i, j, k, ci, cj)] = (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7) / 8;
 }
 
@@ -684,7 +775,65 @@ __global__ __launch_bounds__(256) void mg_prolong_kernel(double *__restrict__ x,
     const float px = (float)((double)((float)i / 2.f) - 0.5);
     const float py = (float)((double)((float)j / 2.f) - 0.5);
     const float pz = (float)((double)((float)k / 2.f) - 0.5);
-    x[id3(i, j, k, ni, nj)] += sample_t(coarse, ci, cj, (long long)ci * cj * ck, px, py, pz);
+    const long long ccount = (long long)ci * cj * ck;
+    const double add = ccount <= 0x7fffffffll ? sample_t<int>(coarse, ci, cj, (int)ccount, px, py, pz)
+                                              : sample_t<long long>(coarse, ci, cj, ccount, px, py, pz);
+    x[id3(i, j, k, ni, nj)] += add;
+}
+
+// The same update with one thread per 2x2x2 block of fine cells.  The fine cells 2m+1 and 2m+2 both sample the coarse cells
+// m, m+1 (px = m with weight 0, px = m + 0.5 with weight 1/2), so a block shares its eight coarse values and most of its
+// lerps: 8 loads and 24 lerps for eight fine cells instead of 64 and 56.  Every lerp is sample_t's, on the same operands
+// (weights computed from px exactly as there), so each fine cell receives the same bits.  Arrays below 2^31 elements.
+__global__ __launch_bounds__(256) void mg_prolong_block_kernel(double *__restrict__ x, const double *__restrict__ coarse,
+                                                               int ni, int nj, int nk, int ci, int cj, int ck)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x, n = blockIdx.y * 4 + threadIdx.y, l = blockIdx.z;
+    if (2 * m + 1 > ni - 2 || 2 * n + 1 > nj - 2 || 2 * l + 1 > nk - 2) return;
+    const int count = ci * cj * ck, sj = ci, sk = ci * cj;
+    const int base = m + sj * n + sk * l;                               // flat, unclamped (M4); >= 0
+    float v[2][2][2];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int id = base + (q & 1) + ((q >> 1) & 1) * sj + ((q >> 2) & 1) * sk;
+        const float t = (float)coarse[id < count ? id : count - 1];
+        v[(q >> 2) & 1][(q >> 1) & 1][q & 1] = id < count ? t : 0.f;
+    }
+    // weights of the two fine cells of each axis, from their positions as prolongation_kernel forms them
+    float w[3][2];
+    bool ok[3][2];
+    const int first[3] = { 2 * m + 1, 2 * n + 1, 2 * l + 1 }, lim[3] = { ni - 2, nj - 2, nk - 2 }, cell[3] = { m, n, l };
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int f = first[a] + h;
+            const float p = (float)((double)((float)f / 2.f) - 0.5);
+            w[a][h] = p - (float)cell[a];                               // floorf(p) == cell[a] for both fine cells
+            ok[a][h] = f <= lim[a] && (int)floorf(p) == cell[a];
+        }
+    float lx[2][2][2];                                                  // [z corner][y corner][fine x]
+#pragma unroll
+    for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+        for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) lx[cz][cy][h] = lerp_f(v[cz][cy][0], v[cz][cy][1], w[0][h]);
+    float ly[2][2][2];                                                  // [z corner][fine y][fine x]
+#pragma unroll
+    for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+        for (int hy = 0; hy < 2; hy++)
+#pragma unroll
+            for (int hx = 0; hx < 2; hx++) ly[cz][hy][hx] = lerp_f(lx[cz][0][hx], lx[cz][1][hx], w[1][hy]);
+#pragma unroll
+    for (int hz = 0; hz < 2; hz++)
+#pragma unroll
+        for (int hy = 0; hy < 2; hy++)
+#pragma unroll
+            for (int hx = 0; hx < 2; hx++)
+                if (ok[0][hx] && ok[1][hy] && ok[2][hz])
+                    x[id3(first[0] + hx, first[1] + hy, first[2] + hz, ni, nj)] += (double)lerp_f(ly[0][hy][hx], ly[1][hy][hx], w[2][hz]);
 }
 
 // gradient_kernel, double p (:1009-1023): the three components in one launch
@@ -835,7 +984,14 @@ static void mg_dot(const double *v0, const double *v1, double *partials, double 
 {
     const unsigned nb = blocks1d(count);
     mg_dot_kernel<<<nb, 256, 0, rt().compute>>>(v0, v1, partials, count);
-    mg_calc_sum_kernel<<<1, 256, 0, rt().compute>>>(partials, result, nb, (nb + 255) / 256, iter_index);
+    const size_t per_thread = (nb + 255) / 256;
+    double *rows = per_thread >= 16 ? (double *)scratch(256 * sizeof(double)) : nullptr;
+    if (rows) {
+        mg_calc_sum_rows_kernel<<<16, 256, 0, rt().compute>>>(partials, rows, nb, per_thread);
+        mg_calc_sum_tree_kernel<<<1, 64, 0, rt().compute>>>(rows, result, iter_index);
+    } else {
+        mg_calc_sum_kernel<<<1, 256, 0, rt().compute>>>(partials, result, nb, per_thread, iter_index);
+    }
     BQ_LAUNCH_CHECK("mg_dot");
 }
 
@@ -877,6 +1033,13 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
     }
     smooth_level(levelnum - 1, 32, true);
     for (int l = levelnum - 2; l >= 0; --l) {
+        // one thread per 2x2x2 block of fine cells where the coarse array is below 2^31 elements and every fine index is
+        // exact in float (always, at these sizes); FL_OPT_MGCG_TILE = 0 keeps the one-cell form
+        if (rt().opt_mgcg_tile && (long long)L[l + 1].ni * L[l + 1].nj * L[l + 1].nk < (1ll << 31) && L[l].ni < (1 << 22) &&
+            L[l].nj < (1 << 22) && L[l].nk < (1 << 22) && L[l].ni >= 3 && L[l].nj >= 3 && L[l].nk >= 3)
+            mg_prolong_block_kernel<<<grid_of((L[l].ni - 1) / 2, (L[l].nj - 1) / 2, (L[l].nk - 1) / 2), kBlk, 0, st>>>(
+                L[l].x, L[l + 1].x, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
+        else
         mg_prolong_kernel<<<grid_of(L[l].ni, L[l].nj, L[l].nk), kBlk, 0, st>>>(
             L[l].x, L[l + 1].x, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
         BQ_LAUNCH_CHECK("mg_prolong_kernel");
