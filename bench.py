@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--halfrdx", type=float, default=0.5)
     ap.add_argument("--fl-opt", action="append", default=[], metavar="ID=VALUE",
                     help="fl_set_option(ID, VALUE) before the run (A/B timing of library options; repeatable)")
+    ap.add_argument("--scheme", choices=["bimocq", "reflection"], default="bimocq",
+                    help="bimocq: BASELINE's headline solver; reflection: the MacCormack + reflection scheme the reference's binary "
+                         "ships as its default (main.cpp:51), single GPU")
     ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi",
                     help="jacobi: BASELINE's headline config; mgcg: the fp64 multigrid-CG projection the reference's "
                          "shipped binary runs (SURVEY 8f N1), --mg-iters outer iterations, single GPU")
@@ -267,7 +270,7 @@ def main():
         keep = transport.NullTransport(lib, erank, emul)
         s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=erank, nranks=emul, ghost=args.ghost)
     else:
-        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank)
+        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, scheme=3 if args.scheme == "reflection" else 0)
     comm_size = int(lib.fl_comm_size())
 
     # ---- the scene ------------------------------------------------------------------------------------
@@ -283,6 +286,10 @@ def main():
     mg = args.projection == "mgcg"
     if mg and multi:
         sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
+    if args.scheme == "reflection" and multi:
+        sys.exit("--scheme reflection is single-GPU")
+    if args.scheme == "reflection":
+        args.no_extra = True                    # the extra legs compare BiMocq state-elision variants
     s.setProjection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
     # The headline number is measured with the reference's FULL per-step sequence (BQ_OPT_FULL_STATE = 1): every
     # buffer the reference updates is updated, including the *Prev state that nothing reads when blend == 1.  The
@@ -364,12 +371,13 @@ def main():
         border_txt = {1: ", DMC map border kept (BQ_OPT_KEEP_DMC_BORDER = 1: slab ranks bit-identical to one GPU in this mode)",
                       0: ", DMC map border zeroed as in the reference (BQ_OPT_KEEP_DMC_BORDER = 0)"}.get(kb, "")
     line = {
-        "metric": f"Mvoxels/s per step (bimocq3D {scene_txt}" + (", multigrid-CG projection)" if mg else ")"),
+        "metric": f"Mvoxels/s per step (bimocq3D {scene_txt}" + (", MacCormack-reflection scheme" if args.scheme == "reflection" else "")
+                  + (", multigrid-CG projection)" if mg else ")"),
         "value": round(value, 2), "unit": "Mvoxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
         "dtype": "f64" if mg else "f32", "data": "synthetic",
-        "config": {"workload": f"bimocq3D {grid_txt} {scene_txt}, "
+        "config": {"workload": f"bimocq3D {grid_txt} {scene_txt}, " + ("MAC_REFLECTION scheme (two projections per step), " if args.scheme == "reflection" else "")
                                + (f"fp64 multigrid-CG projection ({args.mg_iters} outer iterations, 6 levels), fp32 advection, "
                                   if mg else f"{args.jacobi_iters} Jacobi iters, fp32, ")
                                + f"halfrdx {args.halfrdx}, reinit every step"

@@ -1507,7 +1507,10 @@ void gpu_projection_jacobi(float *u, float *v, float *w, float *div, float *p, f
         // equal boundary shells (checked above): two sweeps may share a launch -- unless residual norms are wanted
         // for the iterate in between
         const bool pair_ok = may_fuse && it + 2 < iter && !(dbg && (it + 1) % stride == 0);
-        if (pair_ok && jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta)) {
+        const bool triple_ok = pair_ok && it + 3 < iter && !(dbg && (it + 2) % stride == 0) && rt().opt_jacobi_fuse != 4;
+        if (triple_ok && jacobi_sweep_triple(in, div, out, ni, nj, nk, alpha, beta)) {
+            it += 3;
+        } else if (pair_ok && jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta)) {
             it += 2;
         } else {
             jacobi_sweep(in, div, out, ni, nj, nk, alpha, beta);

@@ -254,7 +254,7 @@ enum {
     FL_OPT_JACOBI_KCHUNK   = 5, /* planes marched per block in the tiled kernel (0 = auto)         */
     FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread: tiled kernel 1, 2, 4; fused kernel 1, 2 (0 = auto) */
     FL_OPT_STRUCTURED_MAPS = 7, /* 9-point kernels: compile-time taps when h is a power of two (1)  */
-    FL_OPT_JACOBI_FUSE     = 8, /* two sweeps per launch: 0 never, 1 in gpu_projection_jacobi after it has checked that p and
+    FL_OPT_JACOBI_FUSE     = 8, /* two or three sweeps per launch (4: at most two): 0 never, 1 in gpu_projection_jacobi after it has checked that p and
                                    p_temp carry the same boundary shell (default), 2 there without the check and also in
                                    gpu_jacobi_sweeps (caller vouches for equal boundary shells) */
     FL_OPT_JACOBI_KCHUNK2  = 9, /* planes marched per block in the fused kernel (0 = auto)           */
