@@ -430,7 +430,8 @@ __device__ __forceinline__ D2 jac_d2(D2 ce, D2 fr, D2 bk, D2 dn, D2 up, D2 dv, d
     return o;
 }
 
-template <bool WIDE, int PF>
+// ZIN: the input field is all zeros and is not read (V_Cycle's first sweep of a level starts from a cleared x)
+template <bool WIDE, int PF, bool ZIN = false>
 __global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict__ p, const double *__restrict__ div,
                                                         double *__restrict__ out, int nx, int ny, int nz,
                                                         int cw, int nby, int kchunk, double alpha, double beta)
@@ -519,18 +520,18 @@ __global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict
         const int sl_ = (d + P) % P;
         const unsigned pp = po(q + d);
 #pragma unroll
-        for (int a = 0; a < 4; a++) L0[sl_][a] = ld_d2(rp, vo[a + 1], pp);
+        for (int a = 0; a < 4; a++) L0[sl_][a] = ZIN ? zero : ld_d2(rp, vo[a + 1], pp);
         if (WIDE) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) E[sl_][a] = ld_d(rp, ve[a], pp);
+            for (int a = 0; a < 4; a++) E[sl_][a] = ZIN ? 0.0 : ld_d(rp, ve[a], pp);
         }
         if (d >= 0 && d < PF) {
 #pragma unroll
             for (int a = 0; a < 4; a++) D[sl_][a] = ld_d2(rd, vo[a + 1], pp);
-            H[sl_][0] = ld_d2(rp, vo[0], pp); H[sl_][1] = ld_d2(rp, vo[5], pp);
+            H[sl_][0] = ZIN ? zero : ld_d2(rp, vo[0], pp); H[sl_][1] = ZIN ? zero : ld_d2(rp, vo[5], pp);
             if (WIDE) {
 #pragma unroll
-                for (int a = 0; a < 2; a++) { Eo[sl_][a] = ld_d(rp, vx[a], pp); Eb[sl_][a] = ld_d(rd, ve[a + 1], pp); }
+                for (int a = 0; a < 2; a++) { Eo[sl_][a] = ZIN ? 0.0 : ld_d(rp, vx[a], pp); Eb[sl_][a] = ld_d(rd, ve[a + 1], pp); }
             }
         }
     }
@@ -540,11 +541,11 @@ __global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict
         constexpr int im = MG_SL(T, -1), ic = MG_SL(T, 0), in_ = MG_SL(T, 1), ia = MG_SL(T, 1 + PF), ha = MG_SL(T, PF); \
         constexpr int mp = MG_SL(T, -1), mpp = MG_SL(T, -2);                                                        \
         const unsigned pa = po(q + 1 + PF), pb = po(q + PF);                                                        \
-        _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ld_d2(rp, vo[a + 1], pa); D[ha][a] = ld_d2(rd, vo[a + 1], pb); } \
-        H[ha][0] = ld_d2(rp, vo[0], pb); H[ha][1] = ld_d2(rp, vo[5], pb);                                           \
+        _Pragma("unroll") for (int a = 0; a < 4; a++) { L0[ia][a] = ZIN ? zero : ld_d2(rp, vo[a + 1], pa); D[ha][a] = ld_d2(rd, vo[a + 1], pb); } \
+        H[ha][0] = ZIN ? zero : ld_d2(rp, vo[0], pb); H[ha][1] = ZIN ? zero : ld_d2(rp, vo[5], pb);                 \
         if (WIDE) {                                                                                                 \
-            _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ld_d(rp, ve[a], pa);                              \
-            _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[ha][a] = ld_d(rp, vx[a], pb); Eb[ha][a] = ld_d(rd, ve[a + 1], pb); } \
+            _Pragma("unroll") for (int a = 0; a < 4; a++) E[ia][a] = ZIN ? 0.0 : ld_d(rp, ve[a], pa);                  \
+            _Pragma("unroll") for (int a = 0; a < 2; a++) { Eo[ha][a] = ZIN ? 0.0 : ld_d(rp, vx[a], pb); Eb[ha][a] = ld_d(rd, ve[a + 1], pb); } \
         }                                                                                                           \
         const bool qb = q < kA || q >= kB;                                                                          \
         if (qb) {                                               /* a boundary plane keeps L0 */                      \
@@ -857,13 +858,44 @@ static inline unsigned blocks1d(size_t count) { return (unsigned)((count + 255) 
 
 static void mg_zero(double *p, size_t count) { BQ_HIP(hipMemsetAsync(p, 0, count * sizeof(double), rt().compute)); }
 
+// zeros on the six faces of an array: what a smoothing call needs of a cleared ping-pong buffer when every interior cell
+// is about to be overwritten anyway (1.5 % of the bytes of clearing it)
+__global__ __launch_bounds__(256) void mg_zero_shell_kernel(double *__restrict__ p, int ni, int nj, int nk)
+{
+    const long long fz = (long long)ni * nj, fy = (long long)ni * nk, fx = (long long)nj * nk;
+    const long long total = 2 * (fz + fy + fx);
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        long long e = t;
+        int i, j, k;
+        if (e < 2 * fz)            { k = e < fz ? 0 : nk - 1; e %= fz; j = (int)(e / ni); i = (int)(e % ni); }
+        else if ((e -= 2 * fz) < 2 * fy) { j = e < fy ? 0 : nj - 1; e %= fy; k = (int)(e / ni); i = (int)(e % ni); }
+        else                       { e -= 2 * fy; i = e < fx ? 0 : ni - 1; e %= fx; k = (int)(e / nj); j = (int)(e % nj); }
+        p[id3(i, j, k, ni, nj)] = 0.0;
+    }
+}
+static void mg_zero_shell(double *p, int ni, int nj, int nk)
+{
+    const long long total = 2 * ((long long)ni * nj + (long long)ni * nk + (long long)nj * nk);
+    mg_zero_shell_kernel<<<(unsigned)std::min<long long>((total + 255) / 256, 2048), 256, 0, rt().compute>>>(p, ni, nj, nk);
+    BQ_LAUNCH_CHECK("mg_zero_shell_kernel");
+}
+
 // smoothing_jacobi (:1464-1483): odd counts are rounded up, so the newest iterate always ends in x
-static void mg_smooth(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
+// clear: the clears V_Cycle issues before the call, left to this function -- bit 0: temp counts as cleared, bit 1: x does.
+// Where the lean kernel runs at least two launches they shrink to zeroed faces (every interior cell of both buffers is
+// overwritten before it is read) and the first launch does not read x; otherwise both arrays are cleared in full.
+static void mg_smooth(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter, int clear = 0)
 {
     if (iter % 2 == 1) iter += 1;
-    if (ni < 3 || nj < 3 || nk < 3) return;             // no interior: every sweep is a no-op
+    const size_t cells = (size_t)ni * nj * nk;
+    if (ni < 3 || nj < 3 || nk < 3) {                   // no interior: every sweep is a no-op
+        if (clear & 1) mg_zero(temp, cells);
+        if (clear & 2) mg_zero(x, cells);
+        return;
+    }
     double *in = x, *out = temp;
     int s = 0;
+    bool cleared = clear == 0;
     // two sweeps per launch where the fused kernel applies (FL_OPT_JACOBI_FUSE != 0): rows of at most 256
     // lanes; double2 lanes when the rows are 16-byte aligned (even nx), else one cell per lane
     // Worth it on large levels only (measured at 256^3: 60 vs 92 us per sweep; at 127^3 and below the
@@ -898,20 +930,33 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
             const bool in_cache = 24.0 * (double)ni * nj * nk <= 256.0 * 1048576.0;
             const int forced = rt().opt_jacobi_kchunk;
             const int pf = forced == 1 || forced == 2 ? forced : (in_cache ? 1 : 2);
+            bool zin = false;
+            if (!cleared && iter >= 4) {
+                if (clear & 1) mg_zero_shell(temp, ni, nj, nk);
+                if (clear & 2) { mg_zero_shell(x, ni, nj, nk); zin = true; }
+                cleared = true;
+            }
             ProfileSpan span;
             const bool prof = big && iter >= 4 && profile_begin(span);
             const int s_begin = s;
             for (; s + 4 <= iter; s += 4)
                 for (int h = 0; h < 2; h++) {
-#define MG_L2(W, F) mg_lean2r_kernel<W, F><<<nby2 * nbz, 256, 0, rt().compute>>>(in, b, out, ni, nj, nk, cw, nby2, kc, alpha, beta)
-                    if (wide) { if (pf == 1) MG_L2(true, 1); else MG_L2(true, 2); }
-                    else      { if (pf == 1) MG_L2(false, 1); else MG_L2(false, 2); }
+#define MG_L2(W, F, Z) mg_lean2r_kernel<W, F, Z><<<nby2 * nbz, 256, 0, rt().compute>>>(in, b, out, ni, nj, nk, cw, nby2, kc, alpha, beta)
+                    if (zin) {
+                        if (wide) { if (pf == 1) MG_L2(true, 1, true); else MG_L2(true, 2, true); }
+                        else      { if (pf == 1) MG_L2(false, 1, true); else MG_L2(false, 2, true); }
+                        zin = false;
+                    } else {
+                        if (wide) { if (pf == 1) MG_L2(true, 1, false); else MG_L2(true, 2, false); }
+                        else      { if (pf == 1) MG_L2(false, 1, false); else MG_L2(false, 2, false); }
+                    }
 #undef MG_L2
                     double *t = in; in = out; out = t;
                 }
             if (prof) profile_end(span, (s - s_begin) / 2, s - s_begin);
             BQ_LAUNCH_CHECK("mg_lean2r_kernel");
         }
+        if (!cleared) { if (clear & 1) mg_zero(temp, cells); if (clear & 2) mg_zero(x, cells); cleared = true; }
         const int lanes = (ni + vec - 1) / vec;
         const int lpr = ((lanes + 63) / 64) * 64;
         const int threads = rt().opt_jacobi_rows == 8 ? 512 : 256;      // FL_OPT_JACOBI_ROWS: waves per block (4 or 8)
@@ -938,6 +983,7 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
             BQ_LAUNCH_CHECK("mg_smooth2_kernel");
         }
     }
+    if (!cleared) { if (clear & 1) mg_zero(temp, cells); if (clear & 2) mg_zero(x, cells); }
     for (; s < iter; s++) {
         mg_smooth_kernel<<<grid_of(ni, nj, nk), kBlk, 0, rt().compute>>>(in, b, out, alpha, beta, ni, nj, nk);
         double *t = in; in = out; out = t;
@@ -1020,9 +1066,7 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
     // smoothing call of V_Cycle: clear temp0 (and x on the way down), `iter` sweeps
     auto smooth_level = [&](int l, int iter, bool clear_x) {
         if (mg_smooth_tiled(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return;
-        mg_zero(temp0, (size_t)L[l].number);
-        if (clear_x) mg_zero(L[l].x, (size_t)L[l].number);
-        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter);
+        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x ? 3 : 1);
     };
     for (int l = 0; l < levelnum - 1; l++) {
         smooth_level(l, 32, true);
