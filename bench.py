@@ -68,7 +68,7 @@ def parse():
                     help="fl_set_option(ID, VALUE) before the run (A/B timing of library options; repeatable)")
     ap.add_argument("--scheme", choices=["bimocq", "reflection"], default="bimocq",
                     help="bimocq: BASELINE's headline solver; reflection: the MacCormack + reflection scheme the reference's binary "
-                         "ships as its default (main.cpp:51), single GPU")
+                         "ships as its default (main.cpp:51); z-slab ranks with the Jacobi projection")
     ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi",
                     help="jacobi: BASELINE's headline config; mgcg: the fp64 multigrid-CG projection the reference's "
                          "shipped binary runs (SURVEY 8f N1), --mg-iters outer iterations, single GPU")
@@ -264,11 +264,13 @@ def main():
                 args.transport_note = "host-staged over gloo (FALLBACK: RCCL set-up failed)"
         else:
             keep = transport.HostStagedTransport(lib, dist)
-        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost)
+        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost,
+                            scheme=3 if args.scheme == "reflection" else 0)
     elif emul > 1:
         erank = args.emulate_rank if args.emulate_rank is not None else emul // 2
         keep = transport.NullTransport(lib, erank, emul)
-        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=erank, nranks=emul, ghost=args.ghost)
+        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=erank, nranks=emul, ghost=args.ghost,
+                            scheme=3 if args.scheme == "reflection" else 0)
     else:
         s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, scheme=3 if args.scheme == "reflection" else 0)
     comm_size = int(lib.fl_comm_size())
@@ -286,8 +288,6 @@ def main():
     mg = args.projection == "mgcg"
     if mg and multi:
         sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
-    if args.scheme == "reflection" and multi:
-        sys.exit("--scheme reflection is single-GPU")
     if args.scheme == "reflection":
         args.no_extra = True                    # the extra legs compare BiMocq state-elision variants
     s.setProjection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)

@@ -538,18 +538,19 @@ template <bool P2>
 __global__ __launch_bounds__(256) void clamp_extrema_kernel(const float *field, float *field_temp,
                                                             const float *u, const float *v, const float *w,
                                                             Spacing sp, int ni, int nj, int nk, int dx, int dy, int dz,
-                                                            float ox, float oy, float oz, float dt)
+                                                            float ox, float oy, float oz, float dt, int koff, int nkg)
 {
+    // (ni, nj, nk: LOCAL buffer dims; z-slab ranks: local plane k is global plane k + koff of nkg cell planes)
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (i >= ni || j >= nj || k >= nk) return;
     const float h = sp.h;
     const int ci = ni - dx, cj = nj - dy, ck = nk - dz;
-    Vel3 vel{make_field(u, ci + 1, cj, ck, 0), make_field(v, ci, cj + 1, ck, 0), make_field(w, ci, cj, ck + 1, 0)};
-    Field src = make_field(field, ni, nj, nk, 0);
+    Vel3 vel{make_field(u, ci + 1, cj, ck, koff), make_field(v, ci, cj + 1, ck, koff), make_field(w, ci, cj, ck + 1, koff)};
+    Field src = make_field(field, ni, nj, nk, koff);
     const f3 org = mk3(-ox * h, -oy * h, -oz * h);
-    const f3 lo = mk3(h, h, h), hi = mk3((float)ci * h - h, (float)cj * h - h, (float)ck * h - h);
+    const f3 lo = mk3(h, h, h), hi = mk3((float)ci * h - h, (float)cj * h - h, (float)nkg * h - h);
     const float halfdt = 0.5f * dt;
-    const f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+    const f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)(k + koff) + org.z);
     f3 vl = get_velocity<P2>(vel, sp, pt);
     f3 px = mk3(pt.x - vl.x * halfdt, pt.y - vl.y * halfdt, pt.z - vl.z * halfdt);
     vl = get_velocity<P2>(vel, sp, px);
@@ -1118,10 +1119,10 @@ BQ_ENTRY(gpu_clamp_extrema, (float *field, float *fieldTemp, float *u, float *v,
     BQ_ENTER("gpu_clamp_extrema", field, fieldTemp, u, v, w)
     BQ_REQUIRE(field != fieldTemp && ((dimx | dimy | dimz) == 0 || (dimx + dimy + dimz) == 1) &&
                ni - dimx >= 1 && nj - dimy >= 1 && nk - dimz >= 1, "gpu_clamp_extrema");
-    if (rt().slab_on) { latch(FL_ERR_UNSUPPORTED, "gpu_clamp_extrema", "the reflection scheme is single-GPU"); return; }
     Spacing sp = make_spacing(h);
+    const Grid g = mk_grid(ni - dimx, nj - dimy, nk - dimz);          // the slab context (single GPU: koff 0, nkg = cell planes)
     BQ_DISPATCH1(clamp_extrema_kernel, sp.pow2, grid_for(ni, nj, nk), field, fieldTemp, u, v, w, sp, ni, nj, nk,
-                 dimx, dimy, dimz, ox, oy, oz, dt);
+                 dimx, dimy, dimz, ox, oy, oz, dt, g.koff, g.nkg);
 }
 
 BQ_ENTRY(gpu_clamp_extrema_box, (const float *before, float *after, int ni, int nj, int nk), (before, after, ni, nj, nk))

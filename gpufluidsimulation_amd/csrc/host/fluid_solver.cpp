@@ -119,11 +119,14 @@ void BimocqGPUSolver::advance(int framenum, float dt)
 
 // :232-337 advanceReflection: MacCormack advection of rho, T and of the velocity (half step),
 // sources, projection, reflection 2 u_proj - u advected another half step, sources, projection.  The
-// limiter is the corrected gpu_clamp_extrema (include/bimocq_gpu.h).  Single GPU.
+// limiter is the corrected gpu_clamp_extrema (include/bimocq_gpu.h).
+// z-slab ranks (Jacobi projection): every look-up states how far it reaches along z -- the trace travels at most
+// |t| * max|u| (getCFL) and the sample adds its cell and the half-cell stagger -- so gpuMapper::require refreshes ghost
+// planes exactly when an input's correct depth no longer covers that reach, and produced() records what is left of it.
 void BimocqGPUSolver::advanceReflection(int framenum, float dt)
 {
     gpuMapper &gs = *GpuSolver;
-    if (gs.slab.on && gs.slab.nranks > 1) { fl_report_error(FL_ERR_UNSUPPORTED, "the reflection scheme is single-GPU"); return; }
+    const bool slabs = gs.slab.on && gs.slab.nranks > 1;
     DeviceField *extra[] = { &DensityTemp, &TemperatureTemp };
     for (DeviceField *f : extra)
         if (!f->get() && !gs.allocField(*f, FIELD_S)) return;
@@ -132,30 +135,61 @@ void BimocqGPUSolver::advanceReflection(int framenum, float dt)
     const float h = CellSize;
     const int ni = g.ni, nj = g.nj, nk = g.nk;
     const size_t n = g.n(), nu = g.nu(), nv = g.nv(), nw = g.nw();
+    // ghost planes a look-up after a trace over time t can touch
+    // (vmax: the speed bound of the velocity field the traces run through -- max|u| of getCFL() until the first
+    // projection has changed the field, a fresh maximum after it; single-GPU runs never look at it)
+    float vmax = MaxVelocity;
+    auto reach = [&](float t) { return (int)std::ceil(std::fabs((double)t) * (double)vmax / (double)h) + 3; };
+    auto vel_valid = [&]() { return gpuMapper::minValid({ &VelocityU, &VelocityV, &VelocityW }); };
 
     // semilagAdvectField / semilagAdvectVelocity (GPU_Advection.h:530-551) clear their outputs first
     auto semilagScalar = [&](DeviceField &dst, DeviceField &src, float t) {
+        const int r = reach(t);
+        gs.require({ &src, &VelocityU, &VelocityV, &VelocityW }, r);
         fl_memset(dst, 0, n * sizeof(float));
         gpu_semilag(dst, src, VelocityU, VelocityV, VelocityW, 0, 0, 0, h, ni, nj, nk, cfldt, t);
+        gs.produced(dst, std::min(src.valid, vel_valid()) - r);
     };
     auto semilagVelocity = [&](DeviceField &uo, DeviceField &vo, DeviceField &wo, DeviceField &us, DeviceField &vs, DeviceField &ws, float t) {
+        const int r = reach(t);
+        gs.require({ &us, &vs, &ws, &VelocityU, &VelocityV, &VelocityW }, r);
         uo.zero(); vo.zero(); wo.zero();
         gpu_semilag(uo, us, VelocityU, VelocityV, VelocityW, 1, 0, 0, h, ni, nj, nk, cfldt, t);
         gpu_semilag(vo, vs, VelocityU, VelocityV, VelocityW, 0, 1, 0, h, ni, nj, nk, cfldt, t);
         gpu_semilag(wo, ws, VelocityU, VelocityV, VelocityW, 0, 0, 1, h, ni, nj, nk, cfldt, t);
+        const int vv = vel_valid();
+        gs.produced(uo, std::min(us.valid, vv) - r); gs.produced(vo, std::min(vs.valid, vv) - r); gs.produced(wo, std::min(ws.valid, vv) - r);
+    };
+    // the limiter reads `field` around the departure point of a trace over dtc and rewrites `temp` at the node itself
+    auto limiter = [&](DeviceField &field, DeviceField &temp, int bi, int bj, int bk, int dx, int dy, int dz, float dtc) {
+        const int r = reach(dtc);
+        gs.require({ &field, &VelocityU, &VelocityV, &VelocityW }, r);
+        gpu_clamp_extrema(field, temp, VelocityU, VelocityV, VelocityW, bi, bj, bk, dx, dy, dz, 0.5f * dx, 0.5f * dy, 0.5f * dz, h, dtc);
+        gs.produced(temp, std::min(temp.valid, std::min(field.valid, vel_valid()) - r));
     };
     auto clampVelocity = [&]() {                         // :283-285, :323-325: source field = VelocityU/V/W
-        gpu_clamp_extrema(VelocityU, VelocityUTemp, VelocityU, VelocityV, VelocityW, ni + 1, nj, nk, 1, 0, 0, 0.5f, 0.f, 0.f, h, 0.5f * dt);
-        gpu_clamp_extrema(VelocityV, VelocityVTemp, VelocityU, VelocityV, VelocityW, ni, nj + 1, nk, 0, 1, 0, 0.f, 0.5f, 0.f, h, 0.5f * dt);
-        gpu_clamp_extrema(VelocityW, VelocityWTemp, VelocityU, VelocityV, VelocityW, ni, nj, nk + 1, 0, 0, 1, 0.f, 0.f, 0.5f, h, 0.5f * dt);
+        limiter(VelocityU, VelocityUTemp, ni + 1, nj, nk, 1, 0, 0, 0.5f * dt);
+        limiter(VelocityV, VelocityVTemp, ni, nj + 1, nk, 0, 1, 0, 0.5f * dt);
+        limiter(VelocityW, VelocityWTemp, ni, nj, nk + 1, 0, 0, 1, 0.5f * dt);
+    };
+    // f1 += coeff * f2
+    auto axpy = [&](DeviceField &f1, DeviceField &f2, float coeff, size_t count) {
+        gs.add(f1, f2, coeff, count);
+        gs.produced(f1, std::min(f1.valid, f2.valid));
     };
     auto sources = [&](bool emit) {                      // :289-297 / :330-337
         if (emit) emitSmoke(framenum, dt);
         addBuoyancy(0.5f * dt);
         if (Viscosity) {
-            diffuseField(VelocityU, VelocityUTemp, TempSrcU, ni + 1, nj, nk, 20, Viscosity, 0.5f * dt);
-            diffuseField(VelocityV, VelocityVTemp, TempSrcV, ni, nj + 1, nk, 20, Viscosity, 0.5f * dt);
-            diffuseField(VelocityW, VelocityWTemp, TempSrcW, ni, nj, nk + 1, 20, Viscosity, 0.5f * dt);
+            if (slabs) {
+                diffuseFieldSlab(VelocityU, VelocityUTemp, TempSrcU, ni + 1, nj, nk, 20, Viscosity, 0.5f * dt);
+                diffuseFieldSlab(VelocityV, VelocityVTemp, TempSrcV, ni, nj + 1, nk, 20, Viscosity, 0.5f * dt);
+                diffuseFieldSlab(VelocityW, VelocityWTemp, TempSrcW, ni, nj, nk + 1, 20, Viscosity, 0.5f * dt);
+            } else {
+                diffuseField(VelocityU, VelocityUTemp, TempSrcU, ni + 1, nj, nk, 20, Viscosity, 0.5f * dt);
+                diffuseField(VelocityV, VelocityVTemp, TempSrcV, ni, nj + 1, nk, 20, Viscosity, 0.5f * dt);
+                diffuseField(VelocityW, VelocityWTemp, TempSrcW, ni, nj, nk + 1, 20, Viscosity, 0.5f * dt);
+            }
         }
     };
 
@@ -163,29 +197,34 @@ void BimocqGPUSolver::advanceReflection(int framenum, float dt)
     for (int a = 0; a < 2; a++) {                        // :237-263
         semilagScalar(*tmp[a], *scal[a], -dt);
         semilagScalar(TempSrcU, *tmp[a], dt);
-        gs.add(*tmp[a], TempSrcU, -0.5f, n);
-        gs.add(*tmp[a], *scal[a], 0.5f, n);
-        gpu_clamp_extrema(*scal[a], *tmp[a], VelocityU, VelocityV, VelocityW, ni, nj, nk, 0, 0, 0, 0.f, 0.f, 0.f, h, dt);
+        axpy(*tmp[a], TempSrcU, -0.5f, n);
+        axpy(*tmp[a], *scal[a], 0.5f, n);
+        limiter(*scal[a], *tmp[a], ni, nj, nk, 0, 0, 0, dt);
         fl_memcpy_d2d(*scal[a], *tmp[a], n * sizeof(float));
+        gs.produced(*scal[a], tmp[a]->valid);
     }
     // :267-287
     semilagVelocity(VelocityUTemp, VelocityVTemp, VelocityWTemp, VelocityU, VelocityV, VelocityW, -0.5f * dt);
     semilagVelocity(TempSrcU, TempSrcV, TempSrcW, VelocityUTemp, VelocityVTemp, VelocityWTemp, 0.5f * dt);
-    gs.add(VelocityUTemp, TempSrcU, -0.5f, nu); gs.add(VelocityVTemp, TempSrcV, -0.5f, nv); gs.add(VelocityWTemp, TempSrcW, -0.5f, nw);
-    gs.add(VelocityUTemp, VelocityU, 0.5f, nu); gs.add(VelocityVTemp, VelocityV, 0.5f, nv); gs.add(VelocityWTemp, VelocityW, 0.5f, nw);
+    axpy(VelocityUTemp, TempSrcU, -0.5f, nu); axpy(VelocityVTemp, TempSrcV, -0.5f, nv); axpy(VelocityWTemp, TempSrcW, -0.5f, nw);
+    axpy(VelocityUTemp, VelocityU, 0.5f, nu); axpy(VelocityVTemp, VelocityV, 0.5f, nv); axpy(VelocityWTemp, VelocityW, 0.5f, nw);
     clampVelocity();
     VelocityU.copy_from(VelocityUTemp); VelocityV.copy_from(VelocityVTemp); VelocityW.copy_from(VelocityWTemp);
 
     sources(true);
     VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW);   // :299-303
     projection();                                        // :305
+    if (slabs) vmax = std::max(vmax, gpu_max_abs3(VelocityU, VelocityV, VelocityW, g.ni, g.nj, g.nk));
     gpu_mad(duProj, VelocityU, VelocityUTemp, 2.f, -1.f, (int)nu);      // :307-309
     gpu_mad(dvProj, VelocityV, VelocityVTemp, 2.f, -1.f, (int)nv);
     gpu_mad(dwProj, VelocityW, VelocityWTemp, 2.f, -1.f, (int)nw);
+    gs.produced(duProj, std::min(VelocityU.valid, VelocityUTemp.valid));
+    gs.produced(dvProj, std::min(VelocityV.valid, VelocityVTemp.valid));
+    gs.produced(dwProj, std::min(VelocityW.valid, VelocityWTemp.valid));
     semilagVelocity(VelocityUTemp, VelocityVTemp, VelocityWTemp, duProj, dvProj, dwProj, -0.5f * dt);             // :311
     semilagVelocity(TempSrcU, TempSrcV, TempSrcW, VelocityUTemp, VelocityVTemp, VelocityWTemp, 0.5f * dt);        // :313
-    gs.add(VelocityUTemp, TempSrcU, -0.5f, nu); gs.add(VelocityVTemp, TempSrcV, -0.5f, nv); gs.add(VelocityWTemp, TempSrcW, -0.5f, nw);
-    gs.add(VelocityUTemp, duProj, 0.5f, nu); gs.add(VelocityVTemp, dvProj, 0.5f, nv); gs.add(VelocityWTemp, dwProj, 0.5f, nw);
+    axpy(VelocityUTemp, TempSrcU, -0.5f, nu); axpy(VelocityVTemp, TempSrcV, -0.5f, nv); axpy(VelocityWTemp, TempSrcW, -0.5f, nw);
+    axpy(VelocityUTemp, duProj, 0.5f, nu); axpy(VelocityVTemp, dvProj, 0.5f, nv); axpy(VelocityWTemp, dwProj, 0.5f, nw);
     clampVelocity();
     VelocityU.copy_from(VelocityUTemp); VelocityV.copy_from(VelocityVTemp); VelocityW.copy_from(VelocityWTemp);
     sources(false);

@@ -668,14 +668,15 @@ void orc_clamp_extrema(const float *field, float *field_temp, const float *u, co
 {
     const int ci = ni - dimx, cj = nj - dimy, ck = nk - dimz;
     const f3 org = mk3(-ox * h, -oy * h, -oz * h);
-    const f3 lo = mk3(h, h, h), hi = mk3((float)ci * h - h, (float)cj * h - h, (float)ck * h - h);
+    /* z-slab context: nk is the LOCAL buffer's plane count, local plane k is global plane k + KOFF */
+    const f3 lo = mk3(h, h, h), hi = mk3((float)ci * h - h, (float)cj * h - h, (float)NKG(ck) * h - h);
     const float halfdt = 0.5f * dt;
     const long sj = ni, sk = (long)ni * nj, count = (long)ni * nj * nk;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < nk; k++)
         for (int j = 0; j < nj; j++)
             for (int i = 0; i < ni; i++) {
-                f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)k + org.z);
+                f3 pt = mk3(h * (float)i + org.x, h * (float)j + org.y, h * (float)(k + KOFF) + org.z);
                 f3 vel = get_velocity(u, v, w, h, ci, cj, ck, pt);
                 f3 px = mk3(pt.x - vel.x * halfdt, pt.y - vel.y * halfdt, pt.z - vel.z * halfdt);
                 vel = get_velocity(u, v, w, h, ci, cj, ck, px);
@@ -683,7 +684,7 @@ void orc_clamp_extrema(const float *field, float *field_temp, const float *u, co
                 float qx = (px.x - org.x) / h, qy = (px.y - org.y) / h, qz = (px.z - org.z) / h;
                 int gi = (int)floorf(qx), gj = (int)floorf(qy), gk = (int)floorf(qz);
                 float cx = qx - (float)gi, cy = qy - (float)gj, cz = qz - (float)gk;
-                long base = (long)gi + sj * gj + sk * gk;
+                long base = (long)gi + sj * gj + sk * (gk - KOFF);
                 if (base < 0) base = count;
                 float v0 = ld(field, base, count),           v1 = ld(field, base + 1, count);
                 float v2 = ld(field, base + sj, count),      v3 = ld(field, base + sj + 1, count);

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--rms-tol", type=float, default=0.0, help="> 0: compare by RMS instead of bit for bit (debug)")
     ap.add_argument("--viscosity", type=float, default=0.0)
     ap.add_argument("--overlap", type=int, default=1, help="BQ_OPT_OVERLAP_EXCHANGES")
+    ap.add_argument("--scheme", type=int, default=0, help="0: BiMocq, 3: MAC_REFLECTION (BQ_SCHEME_*)")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
                          "ranks on one GPU that needs BQ_RCCL_LIBRARY = the tests' stand-in (tests/fake_rccl)")
@@ -85,7 +86,8 @@ def main():
     zmid = 0.5 * nk * h
     em = [(0.5 * ni * h, 0.3 * nj * h, zmid + 0.3 * h, 0.16 * ni * h, 1.0, 2.0, 0.0, 2),
           (0.4 * ni * h, 0.35 * nj * h, 0.22 * nk * h, 0.12 * ni * h, 0.7, 1.0, 0.0, 1)]
-    s = solver.BimocqGPUSolver(ni, nj, nk, a.L, a.viscosity, BLEND, lib=hostlib, errlib=abilib, rank=rank, nranks=world, ghost=a.ghost)
+    s = solver.BimocqGPUSolver(ni, nj, nk, a.L, a.viscosity, BLEND, lib=hostlib, errlib=abilib, rank=rank, nranks=world, ghost=a.ghost,
+                               scheme=a.scheme)
     s.setSmoke(0.05, 1.0, em)
     s.setProjection(a.iters, 0.5)
     s.setOption(1, a.keep_dmc_border)
@@ -98,8 +100,12 @@ def main():
     o.set_smoke(0.05, 1.0, em)
     o.set_projection(a.iters, 0.5)
     o.set_option(1, a.keep_dmc_border)
+    if a.scheme:
+        o.set_option(3, a.scheme)
     dt = a.dt_cells * h
     names = ["rho", "T", "div", "p", "u", "v", "w", "uinit", "vinit", "winit", "rhoinit", "Tinit"]
+    if a.scheme:
+        names = ["rho", "T", "div", "p", "u", "v", "w"]        # the reflection scheme keeps no map state
     plane = {"u": (ni + 1) * nj, "uinit": (ni + 1) * nj, "v": ni * (nj + 1), "vinit": ni * (nj + 1)}
     bad = 0
     if os.environ.get("SLAB_TEST_TRACE") == "1":

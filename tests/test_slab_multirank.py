@@ -101,6 +101,19 @@ def test_wall_sheets_are_what_makes_the_default_exact_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_reflection_scheme_on_slabs_cpu():
+    """MAC_REFLECTION (the reference binary's default scheme) with the Jacobi projection on two and three
+    z-slab ranks: MacCormack semilag pairs, the corrected limiter, two projections per step -- every owned plane equals
+    the single-domain oracle bit for bit; also with viscosity (20 diffusion sweeps per component and half step)"""
+    rc, out = launch(2, "--backend", "cpu", "--scheme", 3, "--steps", 3, "--iters", 16, "--dt-cells", 1.0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(3, "--backend", "cpu", "--scheme", 3, "--dims", 24, 20, 36, "--steps", 2, "--iters", 12, "--dt-cells", 1.5,
+                     "--viscosity", 2e-3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
 def test_ghost_zone_too_shallow_is_refused_cpu():
     """a time step that moves data further than the ghost zone must fail loudly, not silently diverge"""
     rc, out = launch(2, "--backend", "cpu", "--steps", 4, "--ghost", 3, "--dt-cells", 2.0)
@@ -128,6 +141,17 @@ def test_three_ranks_gpu():
     """a middle rank exchanges with two neighbours; 36 planes -> 12 owned each, 6 ghost planes: too thin for the
     operator split at the larger reaches, so both forms occur in one run"""
     rc, out = launch(3, "--backend", "gpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
+@pytest.mark.gpu
+def test_reflection_scheme_on_slabs_gpu():
+    rc, out = launch(2, "--backend", "gpu", "--scheme", 3, "--steps", 3, "--iters", 16, "--dt-cells", 1.0, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(3, "--backend", "gpu", "--scheme", 3, "--dims", 24, 20, 36, "--steps", 2, "--iters", 12, "--dt-cells", 1.5,
+                     "--viscosity", 2e-3, threads=4)
     assert rc == 0, out
     assert out.count("mismatches=0") == 3
 
