@@ -211,7 +211,7 @@ template <int NF> struct CompensateArgs { const float *src[NF]; float *init[NF];
 // ---- A5: advect_kernel (GPU_kernel.cu:312-374) --------------------------------------------
 // Q4: the caller vouches for the map's values (tile_value_ok): the quarter-weight map lerps run in fp32
 template <bool P2, bool PT, int SD, int NF, bool Q4 = false>
-__global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void advect_kernel(AdvectArgs<NF> a,
+__global__ __launch_bounds__(256, NF == 1 ? 7 : 5) void advect_kernel(AdvectArgs<NF> a,
                                                      const float *bx, const float *by, const float *bz,
                                                      Spacing sp, Grid g, int dx, int dy, int dz, int fused)
 {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 // ---- A6/A8: cumulate_kernel (GPU_kernel.cu:376-436): dst += blend9(coeff*src(map(x))) ------
 // ID: the map is the identity map of gpu_init_maps (mx/my/mz are not read).
 template <bool P2, bool PT, int SD, int NF, bool ID, bool Q4 = false>
-__global__ __launch_bounds__(256, NF == 1 ? 6 : 5) void cumulate_kernel(CumulateArgs<NF> a,
+__global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void cumulate_kernel(CumulateArgs<NF> a,
                                                        const float *mx, const float *my, const float *mz,
                                                        Spacing sp, Grid g, int dx, int dy, int dz)
 {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void wall_fixup_kernel(const float *src, int s
 
 // ---- A6: compensate_kernel (GPU_kernel.cu:438-499): err = blend9(src(map(x))) - init(x) ----
 template <bool P2, bool PT, int SD, int NF, bool Q4 = false>
-__global__ __launch_bounds__(256, 6) void compensate_kernel(CompensateArgs<NF> a,
+__global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void compensate_kernel(CompensateArgs<NF> a,
                                                          const float *mx, const float *my, const float *mz,
                                                          Spacing sp, Grid g, int dx, int dy, int dz, int fused)
 {
