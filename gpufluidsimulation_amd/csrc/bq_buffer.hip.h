@@ -18,6 +18,7 @@ __device__ v4f bq_buffer_load_x4(v4i rsrc, int voffset, int soffset, int aux) __
 __device__ v2f bq_buffer_load_x2(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float bq_buffer_load_x1(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void bq_buffer_store_x4(v4f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ void bq_buffer_store_x2(v2f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 __device__ __forceinline__ v4i make_rsrc4(const void *ptr, unsigned bytes)
 {

@@ -607,6 +607,97 @@ __global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict
 }
 
 
+// ---- residual / A x in the marching form ------------------------------------------------------------------------------
+// mg_residual_kernel and mg_poisson_kernel give every cell a thread that loads its seven points: 3.8 TB/s at 256^3.  Here
+// a thread owns the double2 columns of rows j, j+1 as in mg_lean2r_kernel and marches along z with x of the planes q-1, q,
+// q+1 in a ring: per plane it loads x on rows j-1 .. j+2 of the new plane (the outer two for the y neighbours of the plane
+// being finished... one plane later) -- 4 + 2 (rhs) loads and 2 stores for four cells.  POISSON: out = A x (calc_poisson_kernel,
+// :1075-1085), else out = rhs - A x (update_residual_kernel, :1251-1261); interior cells only, boundary cells of `out` are
+// not touched (lanes on an x boundary store the one interior cell of their pair).
+template <bool WIDE, bool POISSON>
+__global__ __launch_bounds__(256) void mg_stencil_lean_kernel(const double *__restrict__ p, const double *__restrict__ rhs,
+                                                              double *__restrict__ out, int nx, int ny, int nz,
+                                                              int cw, int nby, int kchunk)
+{
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);      // XCD-contiguous block order
+    const int by = b % nby, bz = b / nby;
+    const int rows = 256 / cw;
+    const int c = threadIdx.x % cw;
+    const int r = cw >= 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cw) : (int)threadIdx.x / cw;
+    const int xraw = 2 * c, j = 2 * (by * rows + r);
+    const int kbeg = max(1, bz * kchunk), kend = min(nz - 1, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;
+    const bool xok = xraw < nx;
+    const bool xlast = xok && xraw == nx - 1;                       // odd rows: the lane holds the boundary column alone
+    const int x = xok ? xraw : 0;
+    const bool xlo = x == 0, xhi = x + 1 == nx - 1;
+    const bool row0 = xok && !xlast && j >= 1 && j <= ny - 2, row1 = xok && !xlast && j + 1 >= 1 && j + 1 <= ny - 2;
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 8u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(rhs, bytes), ro = make_rsrc4(out, bytes);
+    unsigned vo[4];                                                 // rows j-1 .. j+2 (clamped into the array)
+#pragma unroll
+    for (int a = 0; a < 4; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 8u;
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 8u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    // WIDE: the x neighbour of a wave's first / last lane is the column just outside the wave, rows j, j+1
+    const int lane = threadIdx.x & 63;
+    const bool edgeL = WIDE && lane == 0 && xok && xraw > 0, edgeR = WIDE && lane == 63 && xraw + 2 < nx;
+    const int xe = edgeL ? xraw - 1 : (edgeR ? xraw + 2 : x);
+    unsigned ve[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) ve[a] = (edgeL || edgeR) ? ((unsigned)min(max(xe, 0), nx - 1) + (unsigned)nx * (unsigned)min(max(j + a, 0), ny - 1)) * 8u : 0x80000000u;
+
+    // rings over planes (compile-time slots, the loop is unrolled four times): X[.][0..3] = x on rows j-1 .. j+2 of the
+    // planes q-1, q, q+1 and the one arriving; R = rhs rows j, j+1 and E = outside column of plane q and the one arriving
+    D2 X[4][4], R[2][2];
+    double E[2][2];
+    int q = kbeg;
+    {
+        const unsigned pm = po(q - 1), pc = po(q), pn = po(q + 1);
+#pragma unroll
+        for (int a = 0; a < 4; a++) { X[3][a] = ld_d2(rp, vo[a], pm); X[0][a] = ld_d2(rp, vo[a], pc); X[1][a] = ld_d2(rp, vo[a], pn); }
+        if (!POISSON) { R[0][0] = ld_d2(rd, vo[1], pc); R[0][1] = ld_d2(rd, vo[2], pc); }
+        if (WIDE) { E[0][0] = ld_d(rp, ve[0], pc); E[0][1] = ld_d(rp, ve[1], pc); }
+    }
+#define MG_ST_PHASE(T)                                                                                              \
+    {                                                                                                               \
+        constexpr int im = (T + 3) & 3, ic = T, in_ = (T + 1) & 3, ia = (T + 2) & 3, rc = T & 1, rn = (T + 1) & 1;     \
+        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        _Pragma("unroll") for (int a = 0; a < 4; a++) X[ia][a] = ld_d2(rp, vo[a], pa);                               \
+        if (!POISSON) { R[rn][0] = ld_d2(rd, vo[1], pb); R[rn][1] = ld_d2(rd, vo[2], pb); }                         \
+        if (WIDE) { E[rn][0] = ld_d(rp, ve[0], pb); E[rn][1] = ld_d(rp, ve[1], pb); }                               \
+        _Pragma("unroll") for (int rr = 0; rr < 2; rr++) {                                                           \
+            const D2 ce = X[ic][rr + 1], fr = X[ic][rr], bk = X[ic][rr + 2], dn = X[im][rr + 1], up = X[in_][rr + 1]; \
+            double left = lane_up(ce.b), right = lane_down(ce.a);                                                   \
+            if (WIDE) { if (edgeL) left = E[rc][rr]; if (edgeR) right = E[rc][rr]; }                                \
+            D2 o;                                                                                                   \
+            o.a = (left + ce.b + fr.a + bk.a + dn.a + up.a) - ce.a * 6;                                             \
+            o.b = (ce.a + right + fr.b + bk.b + dn.b + up.b) - ce.b * 6;                                            \
+            if (!POISSON) { o.a = R[rc][rr].a - o.a; o.b = R[rc][rr].b - o.b; }                                     \
+            if (rr == 0 ? row0 : row1) {                                                                            \
+                const unsigned pk = pstride * (unsigned)q;                                                          \
+                if (!xlo && !xhi) st_d2<0>(o, ro, vo[rr + 1], pk);                                                  \
+                else if (xlo && !xhi) bq_buffer_store_x2(__builtin_bit_cast(v2f, o.b), ro, (int)(vo[rr + 1] + 8u), (int)pk, 0); \
+                else if (xhi && !xlo) bq_buffer_store_x2(__builtin_bit_cast(v2f, o.a), ro, (int)vo[rr + 1], (int)pk, 0); \
+            }                                                                                                       \
+        }                                                                                                           \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        MG_ST_PHASE(0)
+        if (q >= kend) break;
+        MG_ST_PHASE(1)
+        if (q >= kend) break;
+        MG_ST_PHASE(2)
+        if (q >= kend) break;
+        MG_ST_PHASE(3)
+        if (q >= kend) break;
+    }
+#undef MG_ST_PHASE
+}
+
 // ---- S sweeps per launch on the coarse levels (LDS tiles) ---------------------------------------------
 // Levels 1 .. 5 of a 256^3 V-cycle (127^3 .. 7^3) are 176 launches of mg_smooth_kernel per cycle, 2 - 12 us each and
 // mostly launch latency: 43 ms of a 229 ms step.  Here a workgroup stages a 16^3 region of x in LDS (thread (tx, ty)
@@ -1020,8 +1111,37 @@ static bool mg_smooth_tiled(double *x, const double *b, double *temp, double alp
     return true;
 }
 
+// out = rhs - A x (poisson = false) or out = A x through the marching kernel; false = not applicable to this grid
+static bool mg_stencil_lean(double *out, const double *rhs, const double *x, int ni, int nj, int nk, bool poisson)
+{
+    if (!rt().opt_mgcg_tile || (long long)ni * nj * nk < (1ll << 20)) return false;
+    if (ni < 8 || ni > 512 || nj < 4 || nk < 3 || (double)ni * nj * nk * 8.0 >= 2147483648.0) return false;
+    if (ni % 2 == 0 && ((((uintptr_t)out | (uintptr_t)x | (uintptr_t)(poisson ? x : rhs)) & 15u) != 0)) return false;
+    int cw = 16;
+    while (cw * 2 < ni) cw *= 2;
+    const bool wide = cw > 64;
+    const int rows2 = 256 / cw, nby2 = (nj + 2 * rows2 - 1) / (2 * rows2);
+    int gcd = nby2, rem = 256;
+    while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+    const int quantum = 256 / gcd;
+    const int target = 32;
+    int nchunks = ((2 * nk + target) / (2 * target) + quantum / 2) / quantum * quantum;
+    if (nchunks < quantum) nchunks = quantum;
+    int kc = (nk + nchunks - 1) / nchunks;
+    if (kc < 4) kc = 4;
+    const int nbz = (nk + kc - 1) / kc;
+    hipStream_t st = rt().compute;
+    const double *rp = poisson ? x : rhs;
+    if (wide) { if (poisson) mg_stencil_lean_kernel<true, true><<<nby2 * nbz, 256, 0, st>>>(x, rp, out, ni, nj, nk, cw, nby2, kc);
+                else         mg_stencil_lean_kernel<true, false><<<nby2 * nbz, 256, 0, st>>>(x, rp, out, ni, nj, nk, cw, nby2, kc); }
+    else      { if (poisson) mg_stencil_lean_kernel<false, true><<<nby2 * nbz, 256, 0, st>>>(x, rp, out, ni, nj, nk, cw, nby2, kc);
+                else         mg_stencil_lean_kernel<false, false><<<nby2 * nbz, 256, 0, st>>>(x, rp, out, ni, nj, nk, cw, nby2, kc); }
+    return BQ_LAUNCH_CHECK("mg_stencil_lean_kernel");
+}
+
 static void mg_residual(double *r, const double *b, const double *x, int ni, int nj, int nk)
 {
+    if (mg_stencil_lean(r, b, x, ni, nj, nk, false)) return;
     mg_residual_kernel<<<grid_of(ni, nj, nk), kBlk, 0, rt().compute>>>(r, b, x, ni, nj, nk);
     BQ_LAUNCH_CHECK("mg_residual_kernel");
 }
@@ -1196,8 +1316,10 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
     for (int it = 0; it < iter; it++) {
         const int off = it * 2;
         // smoothing_conjugate_gradient (:1485-1495): aMulDir = temp0, dotDir = temp1
-        mg_poisson_kernel<<<grid_of(ni, nj, nk), kBlk, 0, st>>>(dir, temp0, ni, nj, nk);
-        BQ_LAUNCH_CHECK("mg_poisson_kernel");
+        if (!mg_stencil_lean(temp0, nullptr, dir, ni, nj, nk, true)) {
+            mg_poisson_kernel<<<grid_of(ni, nj, nk), kBlk, 0, st>>>(dir, temp0, ni, nj, nk);
+            BQ_LAUNCH_CHECK("mg_poisson_kernel");
+        }
         mg_dot(dir, temp0, temp1, tempResult, number, off + 1);
         mg_update_x_kernel<<<blocks1d(number), 256, 0, st>>>(p, dir, tempResult, number, off, off + 1);
         BQ_LAUNCH_CHECK("mg_update_x_kernel");
