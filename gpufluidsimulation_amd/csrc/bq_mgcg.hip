@@ -177,7 +177,14 @@ __global__ __launch_bounds__(64) void mg_calc_sum_tree_kernel(const double *__re
 __global__ __launch_bounds__(256) void mg_max_partial_kernel(const double *__restrict__ v, size_t count, double *__restrict__ part)
 {
     double m = 0;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) m = fmax(m, v[q]);
+    // pairs of doubles (the arrays are 16-byte aligned allocations; an odd count leaves one element for thread 0)
+    const size_t pairs = (((uintptr_t)v & 15u) == 0) ? count / 2 : 0;
+    const double2 *v2 = reinterpret_cast<const double2 *>(v);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < pairs; q += (size_t)gridDim.x * 256) {
+        const double2 t = v2[q];
+        m = fmax(m, fmax(t.x, t.y));
+    }
+    for (size_t q = 2 * pairs + (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) m = fmax(m, v[q]);
     __shared__ double sh[256];
     sh[threadIdx.x] = m;
     __syncthreads();
@@ -1172,25 +1179,29 @@ static void mg_max(const double *v, double *result, size_t count, int iter_index
 }
 
 // V_Cycle, multi-level form (:1636-1707), `else` branch
-static void v_cycle(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+// copy_b: whether level 0's right-hand side is copied into L[0].b first (the reference does, :1640).  The copy only
+// matters for what L[0].b holds afterwards, i.e. in the last outer iteration; before that level 0 reads `residual` itself
+// (nothing writes it until this function's last launch) and 134 MB of traffic per cycle stay away.
+static void v_cycle(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum, bool copy_b = true)
 {
     double scale[LEVEL_COUNT] = { 1.0, 1.0, 1.0, 1.0, 1.0, 1.0 };
     scale[1] = 8.0;                                                                          // M3
     hipStream_t st = rt().compute;
     const size_t n0 = (size_t)L[0].number;
-    BQ_HIP(hipMemcpyAsync(L[0].b, residual, n0 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (copy_b) BQ_HIP(hipMemcpyAsync(L[0].b, residual, n0 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    auto rhs = [&](int l) -> const double * { return (l == 0 && !copy_b) ? residual : L[l].b; };
     // The reference clears all n0 entries of temp0 before every smoothing call; a level-l smoothing only
     // ever touches the first L[l].number of them, so that is what is cleared.  (What stays behind in the
     // rest of temp0 is later seen only at boundary indices of the level-0 product dir*A(dir), where dir
     // is 0: no value depends on it.)
     // smoothing call of V_Cycle: clear temp0 (and x on the way down), `iter` sweeps
     auto smooth_level = [&](int l, int iter, bool clear_x) {
-        if (mg_smooth_tiled(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return;
-        mg_smooth(L[l].x, L[l].b, temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x ? 3 : 1);
+        if (mg_smooth_tiled(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return;
+        mg_smooth(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x ? 3 : 1);
     };
     for (int l = 0; l < levelnum - 1; l++) {
         smooth_level(l, 32, true);
-        mg_residual(L[l].r, L[l].b, L[l].x, L[l].ni, L[l].nj, L[l].nk);
+        mg_residual(L[l].r, rhs(l), L[l].x, L[l].ni, L[l].nj, L[l].nk);
         mg_restrict_kernel<<<grid_of(L[l + 1].ni, L[l + 1].nj, L[l + 1].nk), kBlk, 0, st>>>(
             L[l].r, L[l + 1].b, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
         BQ_LAUNCH_CHECK("mg_restrict_kernel");
@@ -1224,11 +1235,10 @@ struct VCycleGraph {
     SCoarseLevelInfo levels[LEVEL_COUNT];
     int levelnum = 0, fuse = 0, rows = 0, kchunk2 = 0, tile = 0;
 };
-static VCycleGraph g_vcg;
+static VCycleGraph g_vcgs[2];                                // [copy_b]
 
-static bool vcg_matches(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
 {
-    const VCycleGraph &c = g_vcg;
     if (!c.exec || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
     if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk2 != rt().opt_jacobi_kchunk2 ||
         c.tile != rt().opt_mgcg_tile) return false;
@@ -1240,17 +1250,19 @@ static bool vcg_matches(const double *b, double *x, double *residual, const SCoa
     return true;
 }
 
-static void v_cycle_replayed(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+static void v_cycle_replayed(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum, bool copy_b)
 {
-    if (!rt().opt_mgcg_graph || rt().opt_profile_jacobi) { v_cycle(b, x, residual, L, temp0, levelnum); return; }
+    if (!rt().opt_mgcg_tile) copy_b = true;
+    if (!rt().opt_mgcg_graph || rt().opt_profile_jacobi) { v_cycle(b, x, residual, L, temp0, levelnum, copy_b); return; }
+    VCycleGraph &g_vcg = g_vcgs[copy_b ? 1 : 0];
     hipStream_t st = rt().compute;
-    if (!vcg_matches(b, x, residual, L, temp0, levelnum)) {
+    if (!vcg_matches(g_vcg, b, x, residual, L, temp0, levelnum)) {
         if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
         (void)scratch(64);                                   // no allocation may happen while capturing
         hipGraph_t graph = nullptr;
         bool ok = BQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         if (ok) {
-            v_cycle(b, x, residual, L, temp0, levelnum);
+            v_cycle(b, x, residual, L, temp0, levelnum, copy_b);
             ok = BQ_HIP(hipStreamEndCapture(st, &graph)) && rt().err == FL_OK;
         }
         if (ok) ok = BQ_HIP(hipGraphInstantiate(&g_vcg.exec, graph, nullptr, nullptr, 0));
@@ -1266,7 +1278,8 @@ static void v_cycle_replayed(const double *b, double *x, double *residual, const
 
 void mgcg_release_graph()
 {
-    if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
+    for (VCycleGraph &g_vcg : g_vcgs)
+        if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
 }
 
 } // namespace bq
@@ -1325,7 +1338,7 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
         BQ_LAUNCH_CHECK("mg_update_x_kernel");
         mg_residual(residual, div, p, ni, nj, nk);
 
-        v_cycle_replayed(div, p, residual, levels, temp0, levelNum);
+        v_cycle_replayed(div, p, residual, levels, temp0, levelNum, it == iter - 1);
         mg_max(residual, tempResult, number, 2001 + it);
 
         // updateDir (:1497-1503)
