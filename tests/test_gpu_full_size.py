@@ -46,6 +46,31 @@ def test_hip_reproduces_full_size_hashes(case):
     s.close()
 
 
+@pytest.mark.parametrize("case", ["mgcg_128", "reflection_128", "reflection_mgcg_64", "mgcg_256", "reflection_256"])
+def test_hip_reproduces_next_row_hashes(case):
+    """SURVEY 8(f) rows N1 / N3 at sizes the toy shapes do not reach: the fp64 multigrid-CG projection at 128^3 and 256^3
+    (lean smoother on levels 0 and 1, LDS tile smoother below, block transfer operators, marching residual), the
+    MAC_REFLECTION scheme at 128^3 and 256^3 with the Jacobi projection, and the reference binary's default configuration
+    (reflection + multigrid-CG) at 64^3 -- per-step SHA-256 of rho, u, v, w against the CPU oracle's, committed as
+    tests/golden/next_row_hashes.json by tests/golden/make_next_row_hashes.py (no oracle in the loop here)."""
+    from make_hashes import FIELDS, SMOKE, digest_hex
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    with open(os.path.join(HERE, "golden", "next_row_hashes.json")) as f:
+        spec = json.load(f)["cases"][case]
+    n = spec["grid"]
+    s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, scheme=spec["scheme"])
+    s.setSmoke(0.0, 1.0, [SMOKE])
+    s.setProjection(spec["iterations"], 0.5, spec["projection_kind"])
+    s.setOption(3, 1)
+    for row in spec["rows"]:
+        s.advance(row["step"] - 1, 2.0 / n)
+        assert float(np.float32(s.cfldt)) == row["cfldt"], row["step"]
+        for k in FIELDS:
+            assert digest_hex(s.field(k)) == row[k], (case, row["step"], k)
+    s._check()
+    s.close()
+
+
 def test_512_production_kernels_equal_generic_kernels(tmp_path):
     """512^3 (the grid of BASELINE config 4), 2 steps, 200 Jacobi iterations: default launch configuration (WIDE two-row
     fused Jacobi, LDS-staged structured map look-ups, marching limiter) against FL_OPT_JACOBI_VARIANT = 1 /
