@@ -90,7 +90,13 @@ def main():
     torch.set_num_threads(1)
     lib = bq.hip_lib()
     assert lib.fl_init(0) == 0
-    tr = transport.HostStagedTransport(lib, dist)
+    if os.environ.get("BQ_RCCL_LIBRARY"):
+        # the library's own RCCL branch, through the multi-process stand-in for librccl (tests/fake_rccl)
+        assert lib.fl_comm_selftest() == 0, lib.fl_last_error_string()
+        transport.init_rccl(lib, dist)
+        tr = None
+    else:
+        tr = transport.HostStagedTransport(lib, dist)
     s = solver.BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=0, rank=rank, nranks=world, ghost=a.ghost)
     scene(s, n, a.iters)
     if a.keep_dmc_border is not None:
@@ -123,9 +129,9 @@ def main():
     ok = worst <= a.rms_tol
     if rank == 0:
         out = {"grid": [n, n, n], "ranks": world, "ghost": a.ghost, "jacobi_iters": a.iters, "steps": a.steps,
-               "keep_dmc_border": mode, "transport": "host-staged over gloo, ranks share GPU 0",
+               "keep_dmc_border": mode, "transport": ("RCCL branch through tests/fake_rccl" if os.environ.get("BQ_RCCL_LIBRARY") else "host-staged over gloo") + ", ranks share GPU 0",
                "compared_with": "single-GPU run of the same library in the same mode (itself bit-identical to the CPU oracle)",
-               "worst_rms": worst, "rms_tol": a.rms_tol, "exchanges_per_rank": tr.exchanges, "checkpoints": report}
+               "worst_rms": worst, "rms_tol": a.rms_tol, "exchanges_per_rank": (tr.exchanges if tr else None), "checkpoints": report}
         print(f"[slab-deviation] {world} ranks, {n}^3, BQ_OPT_KEEP_DMC_BORDER = {mode}: worst RMS {worst:.3e} "
               f"({'within' if ok else 'ABOVE'} {a.rms_tol:g})", flush=True)
         if a.json:

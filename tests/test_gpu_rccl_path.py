@@ -66,6 +66,27 @@ def test_four_ranks_without_overlap_and_with_viscosity(fake):
     assert out.count("mismatches=0") == 4
 
 
+def test_bench_mode_at_128_over_the_rccl_branch(fake, tmp_path):
+    """what `bench.py --gpus N` runs (library defaults, 200 Jacobi iterations, G = 8, wall sheets), 128^3, 12 steps, two
+    ranks on the RCCL branch against the single-GPU run: RMS of rho, u, v, w exactly 0"""
+    ref = str(tmp_path / "ref")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    worker = os.path.join(ROOT, "tests", "slab_deviation_worker.py")
+    common = ["--size", "128", "--steps", "12", "--iters", "200", "--checkpoints", "1", "6", "12"]
+    r = subprocess.run([sys.executable, worker, "--make-reference", ref, *common], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    js = str(tmp_path / "dev.json")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), worker,
+                        "--reference", ref, *common, "--rms-tol", "1e-5", "--json", js], cwd=ROOT,
+                       env=dict(env, BQ_RCCL_LIBRARY=fake), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.load(open(js))
+    assert "RCCL branch" in out["transport"] and out["keep_dmc_border"] == 0
+    assert out["worst_rms"] == 0.0, out["checkpoints"][-1]
+
+
 def test_bench_gpus_2_runs_the_rccl_branch(fake, tmp_path):
     """`python bench.py --gpus 2` (self-launched ranks, default --transport rccl): the line says RCCL saw two ranks, and
     the per-slab dumps of the run stitch to the single-GPU dump byte for byte"""
