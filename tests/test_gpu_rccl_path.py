@@ -27,12 +27,19 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.fixture(scope="module")
-def fake():
+@pytest.fixture(scope="module", params=["sync", "async", "async-delayed"])
+def fake(request):
+    """sync: blocking copies through host memory (checks matching, sizes, deadlocks); async: stream-ordered transfers
+    into device mailboxes shared over hipIpc (a missing stream dependency on the caller's side shows as a mismatch);
+    async-delayed: the same with a 256 MB fill in front of every transfer, so that it starts ~100 us after the call"""
     from build_fake_rccl import build
     import oracle_lib
     oracle_lib.build()
-    return build()
+    os.environ.pop("BQ_FAKE_RCCL_DELAY_MB", None)
+    if request.param == "async-delayed":
+        os.environ["BQ_FAKE_RCCL_DELAY_MB"] = "256"
+    yield build("sync" if request.param == "sync" else "async")
+    os.environ.pop("BQ_FAKE_RCCL_DELAY_MB", None)
 
 
 def launch_worker(fake, nproc, *args, timeout=900):
