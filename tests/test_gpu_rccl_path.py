@@ -124,3 +124,21 @@ def test_bench_gpus_2_runs_the_rccl_branch(fake, tmp_path):
         assert len(parts) == 2
         stitched = np.concatenate([read_density_dump(os.path.join(two, p))[1] for p in parts])
         assert len(rec) > 100 and stitched.tobytes() == rec.tobytes(), f
+
+
+def test_bench_gpus_4_on_the_rccl_branch(fake):
+    """four self-launched ranks (interior ranks with two neighbours, wall sheets between all pairs), strong scaling of one
+    64^3 grid: rc 0, one line, four ranks in the communicator"""
+    env = dict(os.environ, OMP_NUM_THREADS="2", BQ_RCCL_LIBRARY=fake)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "64", "--steps", "3", "--warmup", "1",
+                        "--jacobi-iters", "40", "--no-cpu-baseline", "--no-extra"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "falling back" not in r.stderr
+    assert line["n_gpus"] == 4 and line["config"]["comm_size"] == 4 and line["config"]["grid_per_gpu"] == [64, 64, 16]
+    assert line["scaling"] == "strong" and line["value"] > 0
