@@ -12,6 +12,14 @@
 // Bounds: every kernel here streams fp64 arrays -- 24 B/cell per smoothing sweep (x, b in, x' out).  At
 // 256^3 the three level-0 arrays (402 MB) exceed the 256 MiB Infinity Cache, so the level-0 sweeps are
 // HBM-bound; levels >= 1 (<= 50 MB) live in the cache.
+//
+// Kernels by level size (256^3 V-cycle: 256, 127, 63, 31, 15, 7):
+//   >= 1 M cells   mg_lean2r_kernel (two sweeps per launch, two rows per thread, buffer descriptors, plane rings; odd rows
+//                  too), mg_stencil_lean_kernel (residual and A.dir in the marching form), clears reduced to the faces;
+//   <  2^19 cells  mg_smooth_tile_kernel (4 or 2 sweeps per launch on a 16^3 region in LDS, clears folded in);
+//   every level    mg_restrict_kernel (3x3x3 register block), mg_prolong_block_kernel (2x2x2 fine cells per thread);
+//   fallbacks      mg_smooth_kernel / mg_smooth2_kernel / mg_residual_kernel / mg_poisson_kernel / mg_prolong_kernel
+//                  (one thread per cell; FL_OPT_MGCG_TILE = 0, FL_OPT_JACOBI_FUSE = 0, FL_OPT_JACOBI_ROWS = 3 select them).
 #include "bq_device.hip.h"
 #include "bq_buffer.hip.h"
 #include <type_traits>
