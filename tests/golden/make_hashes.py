@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 OUT = os.path.join(HERE, "rising_smoke_hashes.json")
 SMOKE = (0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)
-CASES = {"128": (128, 10), "256": (256, 2)}              # grid -> steps
+CASES = {"128": (128, 60), "256": (256, 2)}              # grid -> steps
 FIELDS = ("rho", "u", "v", "w")
 
 
