@@ -110,6 +110,7 @@ HIP_SIGS = {
     "fl_box_unpack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),
     "fl_box_copy": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, c_i, VP, c_i]),
     "fl_p2p_exchange": (None, [c_i, VP, VP, VP, VP, VP]),
+    "fl_p2p_exchange_begin": (None, [c_i, VP, VP, VP, VP, VP]),
     "fl_comm_set_custom_p2p": (None, [VP]),
     "gpu_accumulate_wall_fixup": (None, [VP, c_i, c_i, VP, VP, VP, VP, VP, c_f, c_i, c_i, c_i, c_i, c_f, VP, c_i, VP, c_i, VP, c_i]),
 }

@@ -336,8 +336,8 @@ void fl_box_copy(const float *src, int nbi, int nbj, int nk_src, int koff_src, f
 
 void fl_comm_set_custom_p2p(fl_p2p_cb p2p) { g_custom_p2p = p2p; }
 
-void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
-                     float *const *recv, const size_t *recv_count)
+static void p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
+                         float *const *recv, const size_t *recv_count, bool wait)
 {
     if (g_nranks <= 1 || n <= 0) return;
     Runtime &r = rt();
@@ -365,7 +365,20 @@ void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *
     }
     if (!BQ_NCCL(GroupEnd())) return;
     BQ_HIP(hipEventRecord(ev->done, r.halo));
-    BQ_HIP(hipStreamWaitEvent(r.compute, ev->done, 0));
+    if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, ev->done, 0));
+    else g_ev_pending = ev->done;
+}
+
+void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
+                     float *const *recv, const size_t *recv_count)
+{
+    p2p_exchange(n, peers, send, send_count, recv, recv_count, true);
+}
+
+void fl_p2p_exchange_begin(int n, const int *peers, float *const *send, const size_t *send_count,
+                           float *const *recv, const size_t *recv_count)
+{
+    p2p_exchange(n, peers, send, send_count, recv, recv_count, false);
 }
 
 // Exercises every RCCL entry point this file binds on a throw-away ONE-rank communicator: unique id,

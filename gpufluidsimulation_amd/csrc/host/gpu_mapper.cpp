@@ -74,27 +74,31 @@ const WallPlan &gpuMapper::wallPlan(FieldKind kind, int Dback, int need)
 void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx, DeviceField &by, DeviceField &bz,
                           int Dback, int need, float coeff, int out_valid)
 {
+    wallFixupBegin(items, Dback, need);
+    wallFixupEnd(bx, by, bz, coeff, out_valid);
+}
+
+// First half: the pieces other ranks need are gathered from MY OWNED planes (always correct) and the messages start on
+// the halo stream -- before the stage-3 operator they will correct is launched, so that they travel while it runs.
+void gpuMapper::wallFixupBegin(std::initializer_list<WallItem> items, int Dback, int need)
+{
+    wall_n_ = 0;
     if (!slab.on || slab.nranks <= 1 || items.size() == 0 || items.size() > 3) return;
     const int nr = slab.nranks;
-    const WallPlan *plans[3] = { nullptr, nullptr, nullptr };
-    const WallItem *its[3] = { nullptr, nullptr, nullptr };
     int n = 0;
     for (const WallItem &it : items) {
         const WallPlan &p = wallPlan(it.kind, Dback, need);
         if (p.empty() || p.shadow_k1 <= p.shadow_k0) continue;
-        its[n] = &it; plans[n] = &p; n++;
+        wall_items_[n] = it; wall_plans_now_[n] = &p; n++;
     }
     if (!n) return;
-    auto dims = [&](FieldKind kind, int &nbi, int &nbj, int &nkf) {
-        nbi = g.ni + (kind == FIELD_U); nbj = g.nj + (kind == FIELD_V); nkf = g.nk + (kind == FIELD_W);
-    };
     // the assembled copies: the global planes [k0, k1) of the sampled field, NaN wherever nothing has been placed.
     // Send / receive buffers: field after field, inside a field peer after peer (both sides derive the same order)
-    size_t send_total = 0, recv_total = 0, send_base[3], recv_base[3];
+    size_t send_total = 0, recv_total = 0;
     for (int a = 0; a < n; a++) {
-        const WallPlan &p = *plans[a];
+        const WallPlan &p = *wall_plans_now_[a];
         int nbi, nbj, nkf;
-        dims(its[a]->kind, nbi, nbj, nkf);
+        wallDims(wall_items_[a].kind, nbi, nbj, nkf);
         const size_t plane = (size_t)nbi * (size_t)nbj;
         Shadow &sh = wall_shadow_[a];
         const size_t count = plane * (size_t)(p.shadow_k1 - p.shadow_k0);
@@ -103,71 +107,83 @@ void gpuMapper::wallFixup(std::initializer_list<WallItem> items, DeviceField &bx
             fl_memset(sh.buf.get(), 0xFF, sh.buf.bytes());           // all-ones bytes: a NaN in every float
             sh.k0 = p.shadow_k0; sh.k1 = p.shadow_k1; sh.plane = plane;
         }
-        send_base[a] = send_total; recv_base[a] = recv_total;
+        wall_send_base_[a] = send_total; wall_recv_base_[a] = recv_total;
         send_total += WallPlan::volume(p.send_all);
         recv_total += WallPlan::volume(p.recv_all);
     }
     if ((wall_send_.count() < send_total && !wall_send_.alloc(send_total + send_total / 8 + 64)) ||
         (wall_recv_.count() < recv_total && !wall_recv_.alloc(recv_total + recv_total / 8 + 64))) return;
-    // my own pieces go straight into the copies, the pieces other ranks need into the send buffer
     for (int a = 0; a < n; a++) {
-        const WallPlan &p = *plans[a];
+        const WallPlan &p = *wall_plans_now_[a];
         int nbi, nbj, nkf;
-        dims(its[a]->kind, nbi, nbj, nkf);
-        const float *src = its[a]->src->get();
-        Shadow &sh = wall_shadow_[a];
-        if (!p.local.empty())
-            fl_box_copy(src, nbi, nbj, nkf, slab.koff(), sh.buf.get(), sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size());
+        wallDims(wall_items_[a].kind, nbi, nbj, nkf);
         if (!p.send_all.empty())
-            fl_box_pack(src, nbi, nbj, nkf, slab.koff(), p.send_all.data(), (int)p.send_all.size(), wall_send_.get() + send_base[a]);
+            fl_box_pack(wall_items_[a].src->get(), nbi, nbj, nkf, slab.koff(), p.send_all.data(), (int)p.send_all.size(),
+                        wall_send_.get() + wall_send_base_[a]);
     }
     // one group of point-to-point messages: per field and peer that owes me planes or that I owe planes
-    {
-        std::vector<int> peers; std::vector<float *> sp, rp; std::vector<size_t> sc, rc;
-        for (int a = 0; a < n; a++) {
-            const WallPlan &p = *plans[a];
-            size_t so = send_base[a], ro = recv_base[a];
-            for (int q = 0; q < nr; q++) {
-                const size_t ns = p.send_vol[(size_t)q], nrv = p.recv_vol[(size_t)q];
-                if (q != slab.rank && (ns || nrv)) {
-                    peers.push_back(q); sp.push_back(wall_send_.get() + so); sc.push_back(ns);
-                    rp.push_back(wall_recv_.get() + ro); rc.push_back(nrv);
-                }
-                so += ns; ro += nrv;
+    std::vector<int> peers; std::vector<float *> sp, rp; std::vector<size_t> sc, rc;
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *wall_plans_now_[a];
+        size_t so = wall_send_base_[a], ro = wall_recv_base_[a];
+        for (int q = 0; q < nr; q++) {
+            const size_t ns = p.send_vol[(size_t)q], nrv = p.recv_vol[(size_t)q];
+            if (q != slab.rank && (ns || nrv)) {
+                peers.push_back(q); sp.push_back(wall_send_.get() + so); sc.push_back(ns);
+                rp.push_back(wall_recv_.get() + ro); rc.push_back(nrv);
             }
+            so += ns; ro += nrv;
         }
-        if (!peers.empty()) fl_p2p_exchange((int)peers.size(), peers.data(), sp.data(), sc.data(), rp.data(), rc.data());
-        wall_bytes_moved += (long long)recv_total * 4;
     }
-    // scatter what arrived, re-evaluate the wall layers on the planes the stage produced, then blank the copies again
-    // (a cell the plan did not foresee must read NaN next time as well, never stale data)
+    if (!peers.empty()) fl_p2p_exchange_begin((int)peers.size(), peers.data(), sp.data(), sc.data(), rp.data(), rc.data());
+    wall_bytes_moved += (long long)recv_total * 4;
+    wall_n_ = n;
+}
+
+// Second half, after the stage-3 operator: my own pieces (they may lie on ghost planes the operator's exchange has just
+// refreshed) and what arrived go into the copies, the wall layers are re-evaluated on the planes the stage produced, and
+// the copies are blanked again (a cell the plan did not foresee must read NaN next time as well, never stale data).
+void gpuMapper::wallFixupEnd(DeviceField &bx, DeviceField &by, DeviceField &bz, float coeff, int out_valid)
+{
+    const int n = wall_n_;
+    wall_n_ = 0;
+    if (!n) return;
+    for (int a = 0; a < n; a++) {
+        const WallPlan &p = *wall_plans_now_[a];
+        int nbi, nbj, nkf;
+        wallDims(wall_items_[a].kind, nbi, nbj, nkf);
+        Shadow &sh = wall_shadow_[a];
+        if (!p.local.empty())
+            fl_box_copy(wall_items_[a].src->get(), nbi, nbj, nkf, slab.koff(), sh.buf.get(), sh.k1 - sh.k0, sh.k0, p.local.data(), (int)p.local.size());
+    }
+    fl_halo_wait();                                      // the messages of wallFixupBegin
     const bool can_window = overlap_exchanges && fuse_housekeeping && fl_get_option(FL_OPT_FUSED_HOUSEKEEPING) >= 0;
     const int ov = out_valid < 0 ? 0 : (out_valid > slab.G ? slab.G : out_valid);
     const int w0 = can_window ? slab.G - ov : 0, w1 = can_window ? g.nk - slab.G + (ov > 1 ? ov : 1) : g.nk;
     for (int a = 0; a < n; a++) {
-        const WallPlan &p = *plans[a];
+        const WallPlan &p = *wall_plans_now_[a];
         int nbi, nbj, nkf;
-        dims(its[a]->kind, nbi, nbj, nkf);
+        wallDims(wall_items_[a].kind, nbi, nbj, nkf);
         Shadow &sh = wall_shadow_[a];
         if (!p.recv_all.empty())
-            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.recv_all.data(), (int)p.recv_all.size(), wall_recv_.get() + recv_base[a]);
+            fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.recv_all.data(), (int)p.recv_all.size(), wall_recv_.get() + wall_recv_base_[a]);
     }
     const bool windowed = can_window && (w0 > 0 || w1 < g.nk) && fl_set_plane_window(w0, w1) == 1;
     for (int a = 0; a < n; a++) {
-        const WallPlan &p = *plans[a];
-        const FieldKind kind = its[a]->kind;
+        const WallPlan &p = *wall_plans_now_[a];
+        const FieldKind kind = wall_items_[a].kind;
         const int axis = kind == FIELD_U ? 0 : kind == FIELD_V ? 1 : kind == FIELD_W ? 2 : -1;
         Shadow &sh = wall_shadow_[a];
-        gpu_accumulate_wall_fixup(sh.buf.get(), sh.k0, sh.k1 - sh.k0, its[a]->before->get(), its[a]->dst->get(),
+        gpu_accumulate_wall_fixup(sh.buf.get(), sh.k0, sh.k1 - sh.k0, wall_items_[a].before->get(), wall_items_[a].dst->get(),
                                   bx.get(), by.get(), bz.get(), g.h, g.ni, g.nj, g.nk, axis, coeff,
                                   p.xlist.data(), (int)p.xlist.size(), p.ylist.data(), (int)p.ylist.size(),
                                   p.zlist.data(), (int)p.zlist.size());
     }
     if (windowed) fl_set_plane_window(-1, -1);
     for (int a = 0; a < n; a++) {
-        const WallPlan &p = *plans[a];
+        const WallPlan &p = *wall_plans_now_[a];
         int nbi, nbj, nkf;
-        dims(its[a]->kind, nbi, nbj, nkf);
+        wallDims(wall_items_[a].kind, nbi, nbj, nkf);
         Shadow &sh = wall_shadow_[a];
         if (!p.placed_all.empty())
             fl_box_unpack(sh.buf.get(), nbi, nbj, sh.k1 - sh.k0, sh.k0, p.placed_all.data(), (int)p.placed_all.size(), nullptr);

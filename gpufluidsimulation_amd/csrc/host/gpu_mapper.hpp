@@ -227,6 +227,10 @@ public:
     struct WallItem { DeviceField *src, *before, *dst; FieldKind kind; };
     void wallFixup(std::initializer_list<WallItem> items, DeviceField &bx, DeviceField &by, DeviceField &bz,
                    int Dback, int need, float coeff, int out_valid);
+    // the same in two halves around the stage-3 operator: Begin gathers what the other ranks need and starts the
+    // messages (they travel while the operator runs), End places what arrived and re-evaluates the wall layers
+    void wallFixupBegin(std::initializer_list<WallItem> items, int Dback, int need);
+    void wallFixupEnd(DeviceField &bx, DeviceField &by, DeviceField &bz, float coeff, int out_valid);
     long long wall_bytes_moved = 0;         // floats received through wallFixup so far x 4 (statistics)
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
     static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
@@ -305,6 +309,15 @@ private:
     struct Shadow { DeviceField buf; int k0 = 0, k1 = 0; size_t plane = 0; };
     Shadow wall_shadow_[3];
     DeviceField wall_send_, wall_recv_;
+    // between wallFixupBegin and wallFixupEnd
+    int wall_n_ = 0;
+    WallItem wall_items_[3] = {};
+    const WallPlan *wall_plans_now_[3] = { nullptr, nullptr, nullptr };
+    size_t wall_send_base_[3] = { 0, 0, 0 }, wall_recv_base_[3] = { 0, 0, 0 };
+    void wallDims(FieldKind kind, int &nbi, int &nbj, int &nkf) const
+    {
+        nbi = g.ni + (kind == FIELD_U); nbj = g.nj + (kind == FIELD_V); nkf = g.nk + (kind == FIELD_W);
+    }
     const WallPlan &wallPlan(FieldKind kind, int Dback, int need);
 };
 

@@ -175,6 +175,12 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     if (stage2_done) { Ui.valid = std::min(U.valid, err_valid); Vi.valid = std::min(V.valid, err_valid); Wi.valid = std::min(W.valid, err_valid); }
     else { Ui.copy_from(U); Vi.copy_from(V); Wi.copy_from(W); }
     // stage 3: U += blend9(-0.5 * u_src(psi_back(x)))
+    // z-slab ranks, zeroed map border (Q13): the wall layers sample the error far outside the slab -> wall_sheets.hpp.  The
+    // sheets other ranks need are cut from the owned planes of the error field now, so that the messages travel on the
+    // halo stream while the operator runs; what arrives corrects the wall layers afterwards
+    if (!keepDmcBorder)
+        gs.wallFixupBegin({ { &gs.u_src, &Ui, &U, FIELD_U }, { &gs.v_src, &Vi, &V, FIELD_V }, { &gs.w_src, &Wi, &W, FIELD_W } },
+                          m.Dback, reachField(m.Dback));
     gs.withGhosts({ { { &gs.u_src, &gs.v_src, &gs.w_src }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
         QuarterScope q4(m.backQ4);
         gs.accumulateVelocity(gs.u_src, gs.v_src, gs.w_src, U, V, W, m.BackwardX, m.BackwardY, m.BackwardZ, false, -0.5f);
@@ -183,10 +189,7 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     const int stage3_valid = std::min({ gpuMapper::minValid({ &U, &V, &W }),
                                         gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                         gpuMapper::minValid({ &gs.u_src, &gs.v_src, &gs.w_src }) - reachField(m.Dback) });
-    // z-slab ranks, zeroed map border (Q13): the wall layers sample the error far outside the slab -> wall_sheets.hpp
-    if (!keepDmcBorder)
-        gs.wallFixup({ { &gs.u_src, &Ui, &U, FIELD_U }, { &gs.v_src, &Vi, &V, FIELD_V }, { &gs.w_src, &Wi, &W, FIELD_W } },
-                     m.BackwardX, m.BackwardY, m.BackwardZ, m.Dback, reachField(m.Dback), -0.5f, stage3_valid);
+    if (!keepDmcBorder) gs.wallFixupEnd(m.BackwardX, m.BackwardY, m.BackwardZ, -0.5f, stage3_valid);
     gs.producedAll({ &U, &V, &W }, stage3_valid);
     trace_point("v.stage3");
     // stage 4: limiter against the 3x3x3 box of the uncompensated field
@@ -313,6 +316,8 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
     gs.produced(e2, std::min({ fwd() - kReachMap, f2.valid - reachField(m.Dfwd), f2Init_valid }));
     if (stage2_done) { f1Init.valid = f1.valid; f2Init.valid = f2.valid; }
     else { f1Init.copy_from(f1); f2Init.copy_from(f2); }
+    if (!keepDmcBorder)                                  // (as for the velocity: the wall-sheet messages start before the operator)
+        gs.wallFixupBegin({ { &e1, &f1Init, &f1, FIELD_S }, { &e2, &f2Init, &f2, FIELD_S } }, m.Dback, reachField(m.Dback));
     gs.withGhosts({ { { &e1, &e2 }, reachField(m.Dback) }, { { &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap } }, [&] {
         QuarterScope q4(m.backQ4);
         gpu_accumulate_field2(e1, f1, -0.5f, e2, f2, -0.5f, m.BackwardX, m.BackwardY, m.BackwardZ, h, ni, nj, nk, false);
@@ -320,9 +325,7 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
                   gs.validAfter({ &e1, &e2 }, reachField(m.Dback)) - reachField(m.Dback) }), { &f1, &f2 });
     const int s3v1 = std::min({ f1.valid, back() - kReachMap, e1.valid - reachField(m.Dback) });
     const int s3v2 = std::min({ f2.valid, back() - kReachMap, e2.valid - reachField(m.Dback) });
-    if (!keepDmcBorder)
-        gs.wallFixup({ { &e1, &f1Init, &f1, FIELD_S }, { &e2, &f2Init, &f2, FIELD_S } }, m.BackwardX, m.BackwardY, m.BackwardZ,
-                     m.Dback, reachField(m.Dback), -0.5f, std::min(s3v1, s3v2));
+    if (!keepDmcBorder) gs.wallFixupEnd(m.BackwardX, m.BackwardY, m.BackwardZ, -0.5f, std::min(s3v1, s3v2));
     gs.produced(f1, s3v1);
     gs.produced(f2, s3v2);
     e1.plane = plane1; e2.plane = plane2;

@@ -463,6 +463,11 @@ void fl_box_copy(const float *src, int nbi, int nbj, int nk_src, int koff_src, f
  * compute stream waits for the transfers.  Peers need not be z-neighbours (xGMI is a full mesh: one link per pair). */
 void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *send_count,
                      float *const *recv, const size_t *recv_count);
+/* the same without the compute stream waiting: the messages travel while the compute stream goes on; fl_halo_wait()
+ * before the received data are read or the send buffers rewritten (a later fl_halo_exchange / fl_halo_wait pair covers it
+ * too: the halo stream runs its exchanges in order).  A host-side transport completes inside the call. */
+void fl_p2p_exchange_begin(int n, const int *peers, float *const *send, const size_t *send_count,
+                           float *const *recv, const size_t *recv_count);
 /* host-side transport for fl_p2p_exchange (see fl_comm_set_custom; called with the compute stream idle) */
 typedef void (*fl_p2p_cb)(int n, const int *peers, float *const *send, const size_t *send_count,
                           float *const *recv, const size_t *recv_count);

@@ -193,6 +193,11 @@ void fl_p2p_exchange(int n, const int *peers, float *const *send, const size_t *
     if (!c_p2p) { latch(FL_ERR_COMM, "fl_p2p_exchange: no transport"); return; }
     c_p2p(n, peers, send, send_count, recv, recv_count);
 }
+void fl_p2p_exchange_begin(int n, const int *peers, float *const *send, const size_t *send_count,
+                           float *const *recv, const size_t *recv_count)
+{
+    fl_p2p_exchange(n, peers, send, send_count, recv, recv_count);
+}
 static void box_copy(float *field, int nbi, int nbj, int nk_field, int koff, const fl_box *boxes, int nboxes, float *packed, int mode)
 {
     size_t t = 0;
