@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the two 'extra' legs (dead-state elision, fast lerps)")
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--shallow-exchange", action="store_true",
+                    help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 1: blocking ghost refreshes move only the planes asked for (N > 1)")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
     ap.add_argument("--keep-dmc-border", type=int, default=None,
                     help="N > 1: BQ_OPT_KEEP_DMC_BORDER (see DESIGN.md section 7); default = the library's slab default")
@@ -295,6 +297,8 @@ def main():
     # buffer the reference updates is updated, including the *Prev state that nothing reads when blend == 1.  The
     # library's default elides that dead state; its rate is reported next to the headline as "extra".
     s.setOption(3, 1)
+    if args.shallow_exchange:
+        s.setOption(6, 1)
     if args.keep_dmc_border is not None:
         s.setOption(1, args.keep_dmc_border)
     if args.dump:

@@ -56,9 +56,11 @@ void gpuMapper::require(std::initializer_list<DeviceField *> fields, int depth)
     // All G planes move, whatever depth was asked for: moving only `depth` planes was measured on two ranks
     // (tests/slab_worker.py, 32x32x64, G = 8): 26 % fewer planes outside the Jacobi loop but 4 more exchanges per step
     // (the deeper validity is what spares later operators their own exchange) -- no gain.
-    fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, slab.G, 1);
+    // (BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: only `depth` planes -- what pays depends on the links, see include/bimocq_solver.h)
+    const int moved = shallow_blocking ? depth : slab.G;
+    fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, moved, 1);
     for (DeviceField *f : fields)
-        if (always || f->valid < depth) f->valid = slab.G;
+        if (always || f->valid < depth) f->valid = moved;
 }
 
 const WallPlan &gpuMapper::wallPlan(FieldKind kind, int Dback, int need)

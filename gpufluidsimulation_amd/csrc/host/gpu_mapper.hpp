@@ -233,6 +233,7 @@ public:
     void wallFixupEnd(DeviceField &bx, DeviceField &by, DeviceField &bz, float coeff, int out_valid);
     long long wall_bytes_moved = 0;         // floats received through wallFixup so far x 4 (statistics)
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
+    bool shallow_blocking = false;          // BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: require() moves only the planes asked for
     static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes
     void produced(DeviceField &f, int valid) const { if (slab.on) f.valid = valid < 0 ? 0 : valid; }

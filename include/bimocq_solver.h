@@ -76,7 +76,13 @@ enum {
     /* z-slab ranks, 1 (default): the ghost-plane exchange in front of a map operator runs on the halo stream while the
      * operator works on the planes that cannot reach a ghost plane; the planes at both ends follow the exchange.
      * 0: exchange, then the whole operator.  Same values either way. */
-    BQ_OPT_OVERLAP_EXCHANGES = 5
+    BQ_OPT_OVERLAP_EXCHANGES = 5,
+    /* z-slab ranks, 0 (default): a BLOCKING ghost-plane refresh (the ones no operator hides: the projection's velocity
+     * refresh, the limiter's) moves all G ghost planes, whatever depth was asked for -- the deeper validity spares later
+     * operators their own exchange.  1: it moves only the planes asked for (3 instead of 24 MB per velocity refresh at
+     * 512^2 planes); the operators that need more fetch it in their own, overlapped exchange.  Same values either way;
+     * which is faster depends on the links (host-staged transport: 0). */
+    BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 6
 };
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
  * last step measured (policy 1; 0 otherwise) */

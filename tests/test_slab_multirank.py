@@ -101,6 +101,18 @@ def test_wall_sheets_are_what_makes_the_default_exact_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_shallow_blocking_exchanges_cpu():
+    """BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 1: blocking refreshes move only the planes asked for; same values, fewer planes"""
+    rc, deep = launch(2, "--backend", "cpu", "--steps", 3)
+    assert rc == 0, deep
+    rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--shallow", 1)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    import re
+    planes = lambda text: int(re.search(r"planes=(\d+)", text).group(1))
+    assert planes(out) < planes(deep), (planes(out), planes(deep))
+
+
 def test_reflection_scheme_on_slabs_cpu():
     """MAC_REFLECTION (the reference binary's default scheme) with the Jacobi projection on two and three
     z-slab ranks: MacCormack semilag pairs, the corrected limiter, two projections per step -- every owned plane equals
@@ -143,6 +155,13 @@ def test_three_ranks_gpu():
     rc, out = launch(3, "--backend", "gpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0, threads=4)
     assert rc == 0, out
     assert out.count("mismatches=0") == 3
+
+
+@pytest.mark.gpu
+def test_shallow_blocking_exchanges_gpu():
+    rc, out = launch(2, "--backend", "gpu", "--steps", 3, "--shallow", 1, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
 
 
 @pytest.mark.gpu
