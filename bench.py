@@ -77,8 +77,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the two 'extra' legs (dead-state elision, fast lerps)")
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--shallow-exchange", action="store_true",
-                    help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 1: blocking ghost refreshes move only the planes asked for (N > 1)")
+    ap.add_argument("--shallow-exchange", type=int, nargs="?", const=1, default=0,
+                    help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 = blocking ghost refreshes, 2 = also the overlapped ones move only "
+                         "the planes asked for (N > 1)")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
     ap.add_argument("--keep-dmc-border", type=int, default=None,
                     help="N > 1: BQ_OPT_KEEP_DMC_BORDER (see DESIGN.md section 7); default = the library's slab default")
@@ -298,7 +299,7 @@ def main():
     # library's default elides that dead state; its rate is reported next to the headline as "extra".
     s.setOption(3, 1)
     if args.shallow_exchange:
-        s.setOption(6, 1)
+        s.setOption(6, args.shallow_exchange)
     if args.keep_dmc_border is not None:
         s.setOption(1, args.keep_dmc_border)
     if args.dump:
@@ -328,11 +329,14 @@ def main():
         lib.fl_set_option(int(k), int(v))
     run(args.warmup)
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
+    lib.fl_comm_stats(None, 1)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     el = time.perf_counter() - t0
+    comm_stats = (C.c_longlong * 4)()
+    lib.fl_comm_stats(comm_stats, 0)
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 0)
     bq.check()
     ms, launches, sweeps = C.c_double(0.0), C.c_longlong(0), C.c_longlong(0)
@@ -388,6 +392,9 @@ def main():
                                + (", density dumped every frame (async, per slab)" if args.dump else ""),
                    "grid_per_gpu": [nx, ny, own_planes], "global_grid": [nx, ny, nz_global], "dt": dt,
                    "comm_size": comm_size,
+                   "comm_per_step_rank0": None if not multi else {
+                       "ghost_exchanges": round(comm_stats[0] / args.steps, 1), "ghost_MB_sent": round(comm_stats[1] / args.steps / 1e6, 1),
+                       "wall_sheet_groups": round(comm_stats[2] / args.steps, 1), "wall_sheet_MB_sent": round(comm_stats[3] / args.steps / 1e6, 2)},
                    "parallelism": "1 GPU" if world == 1 else
                    f"{world} z-slabs of {own_planes} planes, {args.ghost} ghost planes, neighbour exchange over "
                    + getattr(args, "transport_note", args.transport + (f" ({comm_size} ranks in the communicator)" if args.transport == "rccl" else ""))

@@ -104,6 +104,7 @@ HIP_SIGS = {
     "fl_comm_size": (c_i, []),
     "fl_halo_exchange": (None, [c_i, C.POINTER(VP), C.POINTER(C.c_size_t), C.POINTER(c_i), c_i, c_i, c_i, c_i]),
     "fl_halo_wait": (None, []),
+    "fl_comm_stats": (None, [VP, c_i]),
     "fl_comm_set_custom": (None, [c_i, c_i, VP, VP]),
     # wall sheets (reference-faithful DMC border on z-slab ranks)
     "fl_box_pack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),

@@ -54,6 +54,8 @@ static int g_ev_next = 0;
 static hipEvent_t g_ev_pending = nullptr;   // `done` of the newest exchange nobody has waited for yet (fl_halo_wait)
 static bool g_null_transport = false;       // fl_comm_set_null: exchanges and all-reduces are skipped (timing aid)
 static fl_p2p_cb g_custom_p2p = nullptr;
+// traffic counters (fl_comm_stats): exchanges issued, bytes this rank sent in them, wall-sheet message groups, bytes sent in them
+static long long g_stat[4] = { 0, 0, 0, 0 };
 
 static EvPair *next_events()
 {
@@ -215,6 +217,12 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
     if (n <= 0 || !fields || !plane_elems || !extra || depth < 1 || depth > G || own < depth + 1) {
         latch(FL_ERR_BAD_ARGUMENT, "fl_halo_exchange", "bad depth/ghost/owned plane counts"); return;
     }
+    {
+        const int lo_ = g_rank - 1, hi_ = g_rank + 1;
+        long long bytes = 0;
+        for (int f = 0; f < n; f++) bytes += (long long)plane_elems[f] * 4 * ((lo_ >= 0 ? depth + extra[f] : 0) + (hi_ < g_nranks ? depth : 0));
+        g_stat[0] += 1; g_stat[1] += bytes;
+    }
     if (g_null_transport) return;               // timing aid: nothing moves, nothing waits
     if (g_custom_exchange) {                    // host-side transport: everything queued so far must be done
         BQ_HIP(hipStreamSynchronize(r.compute));
@@ -346,6 +354,11 @@ static void p2p_exchange(int n, const int *peers, float *const *send, const size
         if (peers[m] < 0 || peers[m] >= g_nranks || peers[m] == g_rank || (send_count[m] && !send[m]) || (recv_count[m] && !recv[m])) {
             latch(FL_ERR_BAD_ARGUMENT, "fl_p2p_exchange", "bad peer or null buffer"); return;
         }
+    {
+        long long bytes = 0;
+        for (int m = 0; m < n; m++) bytes += (long long)send_count[m] * 4;
+        g_stat[2] += 1; g_stat[3] += bytes;
+    }
     if (g_null_transport) return;
     if (g_custom_exchange || g_custom_p2p) {
         if (!g_custom_p2p) { latch(FL_ERR_COMM, "fl_p2p_exchange", "the custom transport has no point-to-point callback (fl_comm_set_custom_p2p)"); return; }
@@ -420,6 +433,12 @@ int fl_comm_selftest(void)
     } else rc = fl_last_error();
     g_rccl.CommDestroy(comm);
     return rc;
+}
+
+void fl_comm_stats(long long out[4], int reset)
+{
+    if (out) for (int a = 0; a < 4; a++) out[a] = g_stat[a];
+    if (reset) for (int a = 0; a < 4; a++) g_stat[a] = 0;
 }
 
 void fl_halo_wait(void)

@@ -211,10 +211,12 @@ public:
         }
         if (trace_require() && slab.rank == 0)
             fprintf(stderr, "[require] %d fields, reach %d: exchange overlapped with planes [%d, %d) of %d\n", n, reach, k0, k1, g.nk);
-        fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, slab.G, /*wait=*/0);
+        // (BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 2: only the planes the operator can reach travel)
+        const int depth_moved = shallow_blocking >= 2 ? reach : slab.G;
+        fl_halo_exchange(n, ptrs, planes, extras, g.nk, slab.G, depth_moved, /*wait=*/0);
         op();                                       // planes [k0, k1): no ghost plane within reach
         fl_halo_wait();
-        for (int a = 0; a < n; a++) moved[a]->valid = slab.G;
+        for (int a = 0; a < n; a++) moved[a]->valid = depth_moved;
         fl_set_plane_window(w0, k0); op();
         fl_set_plane_window(k1, w1); op();
         fl_set_plane_window(-1, -1);
@@ -233,7 +235,7 @@ public:
     void wallFixupEnd(DeviceField &bx, DeviceField &by, DeviceField &bz, float coeff, int out_valid);
     long long wall_bytes_moved = 0;         // floats received through wallFixup so far x 4 (statistics)
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
-    bool shallow_blocking = false;          // BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: require() moves only the planes asked for
+    int shallow_blocking = 0;               // BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 require(), 2 also withGhosts() move only the planes asked for
     static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes
     void produced(DeviceField &f, int valid) const { if (slab.on) f.valid = valid < 0 ? 0 : valid; }

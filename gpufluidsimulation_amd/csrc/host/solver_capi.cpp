@@ -99,7 +99,7 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
     } else if (option == BQ_OPT_OVERLAP_EXCHANGES) {
         s->solver->GpuSolver->overlap_exchanges = value != 0;
     } else if (option == BQ_OPT_SHALLOW_BLOCKING_EXCHANGE) {
-        s->solver->GpuSolver->shallow_blocking = value != 0;
+        s->solver->GpuSolver->shallow_blocking = value < 0 ? 0 : value;
     } else if (option == BQ_OPT_REINIT_POLICY) {
         s->solver->setReinitPolicy(value);
         s->solver->ScalarAdvector.keepDmcBorder = s->solver->VelocityAdvector.keepDmcBorder;
@@ -115,7 +115,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
     case BQ_OPT_FULL_STATE:          return s->solver->keep_full_state ? 1 : 0;
     case BQ_OPT_FUSED_HOUSEKEEPING:  return s->solver->GpuSolver->fuse_housekeeping ? 1 : 0;
     case BQ_OPT_OVERLAP_EXCHANGES:   return s->solver->GpuSolver->overlap_exchanges ? 1 : 0;
-    case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking ? 1 : 0;
+    case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking;
     default:                         return -1;
     }
 }

@@ -428,6 +428,9 @@ int  fl_comm_size(void);
 void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, const int *extra,
                       int nk_local, int G, int depth, int wait);
 void fl_halo_wait(void);
+/* traffic of this rank since the last reset: out[0] ghost-plane exchanges issued, out[1] bytes sent in them, out[2] point-to-point
+ * message groups (wall sheets), out[3] bytes sent in them (counted also when the transport is the null or a host-side one) */
+void fl_comm_stats(long long out[4], int reset);
 /* Host-side transport hook: replaces RCCL by two callbacks (blocking, called with the compute stream
  * idle).  `exchange` receives fl_halo_exchange's arguments and must move the planes itself
  * (fl_memcpy_d2h / its own wire / fl_memcpy_h2d; plane ranges as documented in bq_halo.hip);

@@ -81,7 +81,8 @@ enum {
      * refresh, the limiter's) moves all G ghost planes, whatever depth was asked for -- the deeper validity spares later
      * operators their own exchange.  1: it moves only the planes asked for (3 instead of 24 MB per velocity refresh at
      * 512^2 planes); the operators that need more fetch it in their own, overlapped exchange.  Same values either way;
-     * which is faster depends on the links (host-staged transport: 0). */
+     * which is faster depends on the links (host-staged transport: 0).  2: the overlapped exchanges in front of the map
+     * operators move only the planes the operator can reach as well (reach 4-5 of G = 8 planes at CFL 1-2). */
     BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 6
 };
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the

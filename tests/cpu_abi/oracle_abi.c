@@ -182,6 +182,7 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
     c_exchange(n, fields, plane_elems, extra, nk_local, G, depth);
 }
 void fl_halo_wait(void) {}
+void fl_comm_stats(long long out[4], int reset) { (void)reset; if (out) for (int a = 0; a < 4; a++) out[a] = 0; }
 
 /* ---- wall sheets (include/bimocq_gpu.h, section 4) on host memory ---- */
 static fl_p2p_cb c_p2p;

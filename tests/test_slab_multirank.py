@@ -105,12 +105,13 @@ def test_shallow_blocking_exchanges_cpu():
     """BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 1: blocking refreshes move only the planes asked for; same values, fewer planes"""
     rc, deep = launch(2, "--backend", "cpu", "--steps", 3)
     assert rc == 0, deep
-    rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--shallow", 1)
-    assert rc == 0, out
-    assert out.count("mismatches=0") == 2
     import re
     planes = lambda text: int(re.search(r"planes=(\d+)", text).group(1))
-    assert planes(out) < planes(deep), (planes(out), planes(deep))
+    for mode in (1, 2):                                  # 2: the overlapped exchanges move only the operator's reach as well
+        rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--shallow", mode)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 2
+        assert planes(out) < planes(deep), (mode, planes(out), planes(deep))
 
 
 def test_reflection_scheme_on_slabs_cpu():
@@ -159,9 +160,10 @@ def test_three_ranks_gpu():
 
 @pytest.mark.gpu
 def test_shallow_blocking_exchanges_gpu():
-    rc, out = launch(2, "--backend", "gpu", "--steps", 3, "--shallow", 1, threads=4)
-    assert rc == 0, out
-    assert out.count("mismatches=0") == 2
+    for mode in (1, 2):
+        rc, out = launch(2, "--backend", "gpu", "--steps", 3, "--shallow", mode, threads=4)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 2
 
 
 @pytest.mark.gpu
