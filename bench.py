@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--shallow-exchange", type=int, nargs="?", const=1, default=0,
                     help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 = blocking ghost refreshes, 2 = also the overlapped ones move only "
                          "the planes asked for (N > 1)")
+    ap.add_argument("--no-ends-first", action="store_true", help="BQ_OPT_JACOBI_ENDS_FIRST = 0 (N > 1)")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
     ap.add_argument("--keep-dmc-border", type=int, default=None,
                     help="N > 1: BQ_OPT_KEEP_DMC_BORDER (see DESIGN.md section 7); default = the library's slab default")
@@ -300,6 +301,8 @@ def main():
     s.setOption(3, 1)
     if args.shallow_exchange:
         s.setOption(6, args.shallow_exchange)
+    if args.no_ends_first:
+        s.setOption(7, 0)
     if args.keep_dmc_border is not None:
         s.setOption(1, args.keep_dmc_border)
     if args.dump:

@@ -410,17 +410,27 @@ bool BimocqGPUSolver::projection(bool with_delta)
     int left = jacobi_iters - 1;                                         // iterate iter-1 is applied
     const int own0 = G, own1 = g.nk - G;                                 // local owned planes [own0, own1)
     bool pair_split = G >= 2 && own1 - own0 >= 5;                        // until the operator library says it cannot
+    // The exchange a chunk starts with is hidden by the interior part of its first pair only -- one launch (40 us at
+    // 512 x 512 x 80) against 8 planes per direction (130 us at 64 GB/s).  So the last two pairs of a chunk that another
+    // chunk follows run ENDS FIRST: the G + 2 and then the G owned planes at either end (which need nothing beyond what
+    // the pair before produced), the exchange of the now final boundary planes starts, and the two interiors plus the
+    // interior of the next chunk's first pair run while it travels (three launches instead of one).
+    const bool ends_first_ok = gs.overlap_exchanges && gs.jacobi_ends_first && G >= 6 && G % 2 == 0 && own1 - own0 >= 2 * G + 8;
+    bool in_flight = false;                                              // the exchange of `cur`'s ghost planes has been started
     while (left > 0) {
         int where;
         int chunk;
-        if (cur->valid >= std::min(left, G)) {
+        if (!in_flight && cur->valid >= std::min(left, G)) {
             chunk = std::min(left, G);
             where = gpu_jacobi_sweeps(*cur, div, *oth, g.ni, g.nj, g.nk, chunk, alpha, beta);
         } else {
             // The ghost planes of `cur` travel on the halo stream while the compute stream sweeps what does not
             // depend on them; the planes next to them follow the exchange.
-            float *ptr = cur->get(); size_t pe = cur->plane; int ex = 0;
-            fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0);
+            if (!in_flight) {
+                float *ptr = cur->get(); size_t pe = cur->plane; int ex = 0;
+                fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0);
+            }
+            in_flight = false;
             int done = 0;
             chunk = std::min(left, G);
             if (pair_split && chunk >= 2) {
@@ -451,8 +461,21 @@ bool BimocqGPUSolver::projection(bool with_delta)
             int rest = chunk - done;
             DeviceField *in = oth, *out = cur;
             int depth = G - done;                                        // correct ghost planes of `in`
-            while (pair_split && rest >= 2 &&
-                   gpu_jacobi_sweep_pair_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - (depth - 2), own1 + (depth - 2), 0, 0, alpha, beta)) {
+            const bool ends_first = ends_first_ok && pair_split && done == 2 && chunk == G && left > chunk;
+            while (pair_split && rest >= 2) {
+                if (ends_first && rest == 4) {
+                    // the last two pairs, ends first (depth is 4 here: this pair covers [own0 - 2, own1 + 2), the last [own0, own1))
+                    if (!gpu_jacobi_sweep_pair_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - 2, own0 + G + 2, own1 - G - 2, own1 + 2, alpha, beta)) break;
+                    gpu_jacobi_sweep_pair_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own0 + G, own1 - G, own1, alpha, beta);
+                    // `in` now holds the chunk's result on the planes the neighbours need: send them, receive theirs
+                    { float *ptr = in->get(); size_t pe = in->plane; int ex = 0; fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0); }
+                    in_flight = true;
+                    gpu_jacobi_sweep_pair_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 + G + 2, own1 - G - 2, 0, 0, alpha, beta);
+                    gpu_jacobi_sweep_pair_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0 + G, own1 - G, 0, 0, alpha, beta);
+                    rest -= 4; depth -= 4;                               // (two pairs: the newest iterate is back in `in`)
+                    break;
+                }
+                if (!gpu_jacobi_sweep_pair_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - (depth - 2), own1 + (depth - 2), 0, 0, alpha, beta)) break;
                 std::swap(in, out); rest -= 2; depth -= 2;
             }
             const int w2 = rest > 0 ? gpu_jacobi_sweeps(*in, div, *out, g.ni, g.nj, g.nk, rest, alpha, beta) : 0;

@@ -98,6 +98,8 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         }
     } else if (option == BQ_OPT_OVERLAP_EXCHANGES) {
         s->solver->GpuSolver->overlap_exchanges = value != 0;
+    } else if (option == BQ_OPT_JACOBI_ENDS_FIRST) {
+        s->solver->GpuSolver->jacobi_ends_first = value != 0;
     } else if (option == BQ_OPT_SHALLOW_BLOCKING_EXCHANGE) {
         s->solver->GpuSolver->shallow_blocking = value < 0 ? 0 : value;
     } else if (option == BQ_OPT_REINIT_POLICY) {
@@ -115,6 +117,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
     case BQ_OPT_FULL_STATE:          return s->solver->keep_full_state ? 1 : 0;
     case BQ_OPT_FUSED_HOUSEKEEPING:  return s->solver->GpuSolver->fuse_housekeeping ? 1 : 0;
     case BQ_OPT_OVERLAP_EXCHANGES:   return s->solver->GpuSolver->overlap_exchanges ? 1 : 0;
+    case BQ_OPT_JACOBI_ENDS_FIRST:   return s->solver->GpuSolver->jacobi_ends_first ? 1 : 0;
     case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking;
     default:                         return -1;
     }

@@ -83,7 +83,13 @@ enum {
      * 512^2 planes); the operators that need more fetch it in their own, overlapped exchange.  Same values either way;
      * which is faster depends on the links (host-staged transport: 0).  2: the overlapped exchanges in front of the map
      * operators move only the planes the operator can reach as well (reach 4-5 of G = 8 planes at CFL 1-2). */
-    BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 6
+    BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 6,
+    /* z-slab ranks with at least 2 G + 8 owned planes, 1 (default): the last two fused pairs of every pressure chunk that
+     * another chunk follows run on the planes next to the slab ends first, the exchange for the next chunk starts there,
+     * and their interiors (and the next chunk's first interior) run while it travels -- three launches hide the 8-plane
+     * exchange instead of one, at two more short launches per chunk (+ 2 % compute on a 512 x 512 x 64 rank).  0: the
+     * exchange starts when the chunk is complete.  Same values either way. */
+    BQ_OPT_JACOBI_ENDS_FIRST = 7
 };
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
  * last step measured (policy 1; 0 otherwise) */

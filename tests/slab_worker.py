@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--viscosity", type=float, default=0.0)
     ap.add_argument("--overlap", type=int, default=1, help="BQ_OPT_OVERLAP_EXCHANGES")
     ap.add_argument("--shallow", type=int, default=0, help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE")
+    ap.add_argument("--ends-first", type=int, default=1, help="BQ_OPT_JACOBI_ENDS_FIRST")
     ap.add_argument("--scheme", type=int, default=0, help="0: BiMocq, 3: MAC_REFLECTION (BQ_SCHEME_*)")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
@@ -94,6 +95,7 @@ def main():
     s.setOption(1, a.keep_dmc_border)
     s.setOption(5, a.overlap)
     s.setOption(6, a.shallow)
+    s.setOption(7, a.ends_first)
     if a.backend == "cpu":
         # the oracle library inside the CPU stand-in carries the slab context; the reference run below
         # uses the separately loaded liboracle.so, which stays single-domain

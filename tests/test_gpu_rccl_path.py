@@ -73,6 +73,17 @@ def test_four_ranks_without_overlap_and_with_viscosity(fake):
     assert out.count("mismatches=0") == 4
 
 
+def test_tall_slabs_ends_first_chunks_over_the_rccl_branch(fake):
+    """slabs tall enough for the ends-first pressure chunks (the exchange for the next chunk starts while two pair interiors
+    of this one are still to run): on the stream-ordered stand-ins a sweep that touched planes in flight would show"""
+    rc, out = launch_worker(fake, 2, "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 3, "--iters", 60)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch_worker(fake, 3, "--dims", 24, 20, 96, "--ghost", 6, "--steps", 2, "--iters", 40, "--dt-cells", 1.0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
 def test_bench_mode_at_128_over_the_rccl_branch(fake, tmp_path):
     """what `bench.py --gpus N` runs (library defaults, 200 Jacobi iterations, G = 8, wall sheets), 128^3, 12 steps, two
     ranks on the RCCL branch against the single-GPU run: RMS of rho, u, v, w exactly 0"""

@@ -101,6 +101,21 @@ def test_wall_sheets_are_what_makes_the_default_exact_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_tall_slabs_run_the_ends_first_chunks_cpu():
+    """slabs of at least 2 G + 8 owned planes: the last two fused pairs of every pressure chunk run ends first and the
+    exchange for the next chunk starts before their interiors (fluid_solver.cpp: projection); G = 6 (three pairs per
+    chunk) on two ranks, G = 8 (four pairs) on three"""
+    rc, out = launch(2, "--backend", "cpu", "--dims", 24, 20, 64, "--ghost", 6, "--steps", 3, "--iters", 40)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 96, "--ghost", 8, "--steps", 2, "--iters", 36, "--dt-cells", 1.0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+    rc, out = launch(2, "--backend", "cpu", "--dims", 24, 20, 64, "--ghost", 6, "--steps", 2, "--iters", 40, "--ends-first", 0)
+    assert rc == 0, out                                  # BQ_OPT_JACOBI_ENDS_FIRST = 0: the plain chunk order stays tested
+    assert out.count("mismatches=0") == 2
+
+
 def test_shallow_blocking_exchanges_cpu():
     """BQ_OPT_SHALLOW_BLOCKING_EXCHANGE = 1: blocking refreshes move only the planes asked for; same values, fewer planes"""
     rc, deep = launch(2, "--backend", "cpu", "--steps", 3)
@@ -154,6 +169,16 @@ def test_three_ranks_gpu():
     """a middle rank exchanges with two neighbours; 36 planes -> 12 owned each, 6 ghost planes: too thin for the
     operator split at the larger reaches, so both forms occur in one run"""
     rc, out = launch(3, "--backend", "gpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
+@pytest.mark.gpu
+def test_tall_slabs_run_the_ends_first_chunks_gpu():
+    rc, out = launch(2, "--backend", "gpu", "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 3, "--iters", 60, threads=4)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(3, "--backend", "gpu", "--dims", 24, 20, 96, "--ghost", 6, "--steps", 2, "--iters", 40, "--dt-cells", 1.0, threads=4)
     assert rc == 0, out
     assert out.count("mismatches=0") == 3
 
