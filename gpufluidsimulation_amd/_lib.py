@@ -105,6 +105,8 @@ HIP_SIGS = {
     "fl_halo_exchange": (None, [c_i, C.POINTER(VP), C.POINTER(C.c_size_t), C.POINTER(c_i), c_i, c_i, c_i, c_i]),
     "fl_halo_wait": (None, []),
     "fl_comm_stats": (None, [VP, c_i]),
+    "fl_comm_profile": (None, [C.POINTER(c_d), C.POINTER(C.c_longlong), c_i]),
+    "fl_comm_rccl_version": (c_i, []),
     "fl_comm_set_custom": (None, [c_i, c_i, VP, VP]),
     # wall sheets (reference-faithful DMC border on z-slab ranks)
     "fl_box_pack": (None, [VP, c_i, c_i, c_i, c_i, VP, c_i, VP]),
@@ -123,6 +125,8 @@ FL_OPT_JACOBI_FUSE, FL_OPT_JACOBI_KCHUNK2, FL_OPT_MGCG_GRAPH, FL_OPT_FAST_LERP =
 FL_OPT_FUSED_HOUSEKEEPING = 12
 FL_OPT_MAP_QUARTER_FP32 = 13
 FL_OPT_MGCG_TILE = 14
+FL_OPT_PROFILE_COMM = 15
+FL_OPT_RESERVE_CUS = 16
 
 
 class BimocqLibraryMissing(RuntimeError):

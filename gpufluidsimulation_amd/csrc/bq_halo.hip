@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <chrono>
+#include <vector>
 
 namespace bq {
 
@@ -37,9 +39,11 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;         // optional (reports only)
 };
 
 static Rccl g_rccl;
+static void allreduce_span(hipEvent_t a, hipEvent_t b);
 static ncclComm_t g_comm = nullptr;
 static int g_rank = 0, g_nranks = 1;
 // optional host-side transport (fl_comm_set_custom): used instead of RCCL when set
@@ -56,6 +60,42 @@ static bool g_null_transport = false;       // fl_comm_set_null: exchanges and a
 static fl_p2p_cb g_custom_p2p = nullptr;
 // traffic counters (fl_comm_stats): exchanges issued, bytes this rank sent in them, wall-sheet message groups, bytes sent in them
 static long long g_stat[4] = { 0, 0, 0, 0 };
+
+// FL_OPT_PROFILE_COMM: every place where the COMPUTE stream waits for the halo stream is bracketed by two timing events
+// on the compute stream.  The first completes when the compute stream has run dry up to the wait, the second when the
+// wait has been satisfied: their distance is communication time that no kernel hid ("exposed").  Summed by
+// fl_comm_profile().  A host-side transport blocks the host instead; that wall time is counted the same way.
+struct WaitSpan { hipEvent_t a, b; };
+static std::vector<WaitSpan> g_wait_spans;
+static double g_wait_host_ms = 0.0;
+static long long g_wait_host_count = 0;
+
+static void compute_waits_for(hipEvent_t done)
+{
+    Runtime &r = rt();
+    if (!r.opt_profile_comm) { BQ_HIP(hipStreamWaitEvent(r.compute, done, 0)); return; }
+    WaitSpan sp{nullptr, nullptr};
+    if (!BQ_HIP(hipEventCreate(&sp.a)) || !BQ_HIP(hipEventCreate(&sp.b))) { BQ_HIP(hipStreamWaitEvent(r.compute, done, 0)); return; }
+    BQ_HIP(hipEventRecord(sp.a, r.compute));
+    BQ_HIP(hipStreamWaitEvent(r.compute, done, 0));
+    BQ_HIP(hipEventRecord(sp.b, r.compute));
+    g_wait_spans.push_back(sp);
+}
+
+static std::vector<WaitSpan> g_allreduce_spans;
+static void allreduce_span(hipEvent_t a, hipEvent_t b) { g_allreduce_spans.push_back(WaitSpan{a, b}); }
+
+struct HostWaitTimer {                      // wall time of a blocking host-side transport call
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    HostWaitTimer() : on(rt().opt_profile_comm != 0) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~HostWaitTimer()
+    {
+        if (!on) return;
+        g_wait_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        g_wait_host_count++;
+    }
+};
 
 static EvPair *next_events()
 {
@@ -91,6 +131,7 @@ static bool load_rccl()
     BQ_SYM(GroupEnd, "ncclGroupEnd")
     BQ_SYM(GetErrorString, "ncclGetErrorString")
 #undef BQ_SYM
+    *(void **)(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");
     return true;
 }
 
@@ -116,7 +157,12 @@ bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStr
         return BQ_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st)) && BQ_HIP(hipStreamSynchronize(st));
     }
     if (!g_comm) return true;
-    return BQ_NCCL(AllReduce(dev, dev, count, is_double ? ncclDouble : ncclFloat, is_max ? ncclMax : ncclSum, g_comm, st));
+    // the all-reduce runs IN the stream it is given (the compute stream): its whole duration is exposed; timed separately
+    hipEvent_t a = nullptr, b = nullptr;
+    const bool timed = rt().opt_profile_comm && BQ_HIP(hipEventCreate(&a)) && BQ_HIP(hipEventCreate(&b)) && BQ_HIP(hipEventRecord(a, st));
+    const bool ok = BQ_NCCL(AllReduce(dev, dev, count, is_double ? ncclDouble : ncclFloat, is_max ? ncclMax : ncclSum, g_comm, st));
+    if (timed) { BQ_HIP(hipEventRecord(b, st)); allreduce_span(a, b); }
+    return ok;
 }
 int comm_ranks() { return g_nranks; }
 
@@ -226,6 +272,7 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
     if (g_null_transport) return;               // timing aid: nothing moves, nothing waits
     if (g_custom_exchange) {                    // host-side transport: everything queued so far must be done
         BQ_HIP(hipStreamSynchronize(r.compute));
+        HostWaitTimer timer;
         g_custom_exchange(n, fields, plane_elems, extra, nk_local, G, depth);
         (void)wait;
         return;
@@ -253,7 +300,7 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
     }
     if (!BQ_NCCL(GroupEnd())) return;
     BQ_HIP(hipEventRecord(ev->done, r.halo));
-    if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, ev->done, 0));
+    if (wait) compute_waits_for(ev->done);
     else g_ev_pending = ev->done;
 }
 
@@ -363,6 +410,7 @@ static void p2p_exchange(int n, const int *peers, float *const *send, const size
     if (g_custom_exchange || g_custom_p2p) {
         if (!g_custom_p2p) { latch(FL_ERR_COMM, "fl_p2p_exchange", "the custom transport has no point-to-point callback (fl_comm_set_custom_p2p)"); return; }
         BQ_HIP(hipStreamSynchronize(r.compute));
+        HostWaitTimer timer;
         g_custom_p2p(n, peers, send, send_count, recv, recv_count);
         return;
     }
@@ -378,7 +426,7 @@ static void p2p_exchange(int n, const int *peers, float *const *send, const size
     }
     if (!BQ_NCCL(GroupEnd())) return;
     BQ_HIP(hipEventRecord(ev->done, r.halo));
-    if (wait) BQ_HIP(hipStreamWaitEvent(r.compute, ev->done, 0));
+    if (wait) compute_waits_for(ev->done);
     else g_ev_pending = ev->done;
 }
 
@@ -444,8 +492,44 @@ void fl_comm_stats(long long out[4], int reset)
 void fl_halo_wait(void)
 {
     if (g_nranks <= 1 || !g_ev_pending) return;
-    BQ_HIP(hipStreamWaitEvent(rt().compute, g_ev_pending, 0));
+    compute_waits_for(g_ev_pending);
     g_ev_pending = nullptr;
+}
+
+// FL_OPT_PROFILE_COMM.  ms[0] / n[0]: milliseconds the compute stream spent blocked on the halo stream (or the host inside a
+// host-side transport) and the number of such waits; ms[1] / n[1]: the in-stream scalar all-reduces (CFL maximum, map
+// guard, norms), which run ON the compute stream.  Since the last reset; blocking (synchronises the compute stream).
+void fl_comm_profile(double ms[2], long long n[2], int reset)
+{
+    double m[2] = { g_wait_host_ms, 0.0 };
+    long long c[2] = { g_wait_host_count, 0 };
+    if (rt().ready && (!g_wait_spans.empty() || !g_allreduce_spans.empty())) {
+        BQ_HIP(hipStreamSynchronize(rt().compute));
+        const std::vector<WaitSpan> *sets[2] = { &g_wait_spans, &g_allreduce_spans };
+        for (int a = 0; a < 2; a++)
+            for (const WaitSpan &sp : *sets[a]) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess && t > 0.f) m[a] += (double)t;
+                c[a]++;
+            }
+    }
+    if (ms) { ms[0] = m[0]; ms[1] = m[1]; }
+    if (n) { n[0] = c[0]; n[1] = c[1]; }
+    if (reset) {
+        for (std::vector<WaitSpan> *v : { &g_wait_spans, &g_allreduce_spans }) {
+            for (const WaitSpan &sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+            v->clear();
+        }
+        g_wait_host_ms = 0.0; g_wait_host_count = 0;
+    }
+}
+
+// ncclGetVersion of the loaded RCCL (e.g. 22105), 0 when none is loaded or the library does not export it
+int fl_comm_rccl_version(void)
+{
+    int v = 0;
+    if (g_rccl.handle && g_rccl.GetVersion && g_rccl.GetVersion(&v) == ncclSuccess) return v;
+    return 0;
 }
 
 } // extern "C"

@@ -32,6 +32,10 @@ struct Runtime {
     bool        map_guard_on = false;
     int         opt_mgcg_graph = 1;         // replay the multigrid V-cycle from a captured hipGraph
     int         opt_mgcg_tile = 1;          // FL_OPT_MGCG_TILE: LDS tile smoother on the coarse levels of the V-cycle
+    int         opt_profile_comm = 0;       // FL_OPT_PROFILE_COMM: time the compute stream's waits on the halo stream
+    int         opt_reserve_cus = 0;        // FL_OPT_RESERVE_CUS: CUs the compute stream leaves to the halo stream's RCCL kernels
+    int         device_cus = 0;             // CUs of the device (hipDeviceProp_t::multiProcessorCount), set by fl_init
+    int         num_cus = 256;              // CUs the compute stream may use (device CUs - opt_reserve_cus)
     int         opt_jacobi_rows = 0;        // float4 rows per thread in the tiled kernel (0 = auto)
     // z-slab context (fl_set_slab): local plane k is global plane k + slab_koff of slab_nkg planes;
     // this rank owns global planes [slab_own0, slab_own1) (reductions count only those)

@@ -19,6 +19,88 @@ __device__ __forceinline__ float hypot2(float y, float z)
     return (float)sqrt((double)y * (double)y + (double)z * (double)z);
 }
 
+/* The oracle's orc_acosf / orc_cosf, operation for operation.  acosf / cosf of the emitter's velocity ring (GPU_kernel.cu:750-752), restated with IEEE double +, -, *, /, sqrt and
+ * floor only, so that every compiler and both sides of the parity tests produce the same bits (within 1 ulp of any
+ * libm).  acos: asin's Taylor series on |x| <= 1/2 (22 terms, c_k = C(2k,k) / (4^k (2k+1)): truncation < 1e-15),
+ * acos(r) = pi/2 - asin(r) for |r| <= 1/2, 2 asin(sqrt((1-|r|)/2)) beyond, reflected for r < 0.  cos: Cody-Waite
+ * reduction by pi/2 (two-part constant, exact for the |x| < 2^19 this is specified on; the emitter passes 8 theta <=
+ * 8 pi), Taylor series of sin / cos on |y| <= pi/4. */
+__device__ __forceinline__ float acos_portable(float rf)
+{
+    double r = (double)rf;
+    if (!(r == r)) return rf;
+    if (r > 1.0) r = 1.0;
+    if (r < -1.0) r = -1.0;
+    const double PI = 3.14159265358979311600e+00;
+    const double PIO2 = 1.57079632679489655800e+00;
+    double a = r < 0.0 ? -r : r;
+    double x = a <= 0.5 ? a : sqrt((1.0 - a) * 0.5);
+    double z = x * x;
+    double p = 2104098963720.0 / 791648371998720.0;
+    p = p * z + 538257874440.0 / 189115999977472.0;
+    p = p * z + 137846528820.0 / 45079976738816.0;
+    p = p * z + 35345263800.0 / 10720238370816.0;
+    p = p * z + 9075135300.0 / 2542620639232.0;
+    p = p * z + 2333606220.0 / 601295421440.0;
+    p = p * z + 601080390.0 / 141733920768.0;
+    p = p * z + 155117520.0 / 33285996544.0;
+    p = p * z + 40116600.0 / 7784628224.0;
+    p = p * z + 10400600.0 / 1811939328.0;
+    p = p * z + 2704156.0 / 419430400.0;
+    p = p * z + 705432.0 / 96468992.0;
+    p = p * z + 184756.0 / 22020096.0;
+    p = p * z + 48620.0 / 4980736.0;
+    p = p * z + 12870.0 / 1114112.0;
+    p = p * z + 3432.0 / 245760.0;
+    p = p * z + 924.0 / 53248.0;
+    p = p * z + 252.0 / 11264.0;
+    p = p * z + 70.0 / 2304.0;
+    p = p * z + 20.0 / 448.0;
+    p = p * z + 6.0 / 80.0;
+    p = p * z + 2.0 / 12.0;
+    double s = x + x * (z * p);                 /* asin(x) */
+    double res;
+    if (a <= 0.5) res = r < 0.0 ? PIO2 + s : PIO2 - s;
+    else res = r < 0.0 ? PI - 2.0 * s : 2.0 * s;
+    return (float)res;
+}
+
+__device__ __forceinline__ float cos_portable(float xf)
+{
+    double x = (double)xf;
+    if (!(x == x)) return xf;
+    if (x < 0.0) x = -x;
+    if (!(x < 524288.0)) return (float)(x - x);  /* outside the specified range (Inf -> NaN, huge -> 0) */
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;   /* first 33 bits of pi/2 */
+    const double PIO2_LO = 6.07710050650619224932e-11;   /* pi/2 - PIO2_HI */
+    double kd = floor(x * TWO_OVER_PI + 0.5);
+    double y = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    double z = y * y;
+    double c = -1.0 / 6402373705728000.0;        /* cos: sum (-1)^m z^m / (2m)!, m <= 9 */
+    c = c * z + 1.0 / 20922789888000.0;
+    c = c * z - 1.0 / 87178291200.0;
+    c = c * z + 1.0 / 479001600.0;
+    c = c * z - 1.0 / 3628800.0;
+    c = c * z + 1.0 / 40320.0;
+    c = c * z - 1.0 / 720.0;
+    c = c * z + 1.0 / 24.0;
+    c = c * z - 0.5;
+    c = c * z + 1.0;
+    double s = 1.0 / 355687428096000.0;          /* sin: y sum (-1)^m z^m / (2m+1)!, m <= 8 */
+    s = s * z - 1.0 / 1307674368000.0;
+    s = s * z + 1.0 / 6227020800.0;
+    s = s * z - 1.0 / 39916800.0;
+    s = s * z + 1.0 / 362880.0;
+    s = s * z - 1.0 / 5040.0;
+    s = s * z + 1.0 / 120.0;
+    s = s * z - 1.0 / 6.0;
+    s = y + y * (z * s);
+    long long q = (long long)kd & 3;
+    double res = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
+    return (float)res;
+}
+
 // emit_smoke_velocity_kernel (GPU_kernel.cu:736-758); the u-face offset is used for all three
 // components, as in the reference
 __global__ __launch_bounds__(256) void emit_velocity_kernel(float *field, float h, int ni, int nj, int nk,
@@ -32,8 +114,8 @@ __global__ __launch_bounds__(256) void emit_velocity_kernel(float *field, float 
     float dy = (float)j * h - cy;
     float dz = (float)k * h - cz;
     if (norm3(dx, dy, dz) < radius) {
-        float theta = acosf(dy / hypot2(dy, dz));
-        float c8 = cosf((float)(8.0 * (double)theta));
+        float theta = acos_portable(dy / hypot2(dy, dz));
+        float c8 = cos_portable((float)(8.0 * (double)theta));
         field[(size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * kl)] = (float)((double)emiter * 0.06 * (1.0 + 0.01 * (double)c8));
     }
 }

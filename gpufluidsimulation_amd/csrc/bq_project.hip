@@ -1144,6 +1144,24 @@ static void jacobi_sweep(const float *in, const float *div, float *out, int ni, 
     BQ_LAUNCH_CHECK("jacobi_tile_kernel");
 }
 
+// How many k-chunks a fused launch cuts `nkr` planes into when the compute stream does not own the whole chip
+// (FL_OPT_RESERVE_CUS): the rules below fill 256 CUs in whole rounds; with another CU count no chunk count divides evenly, so
+// take the one that minimises rounds x planes marched per block (chunk + `warm` warm-up planes), nearest to the target
+// chunk length among near-equal candidates.  per_cu: resident blocks per CU.
+static int chunks_for_cus(int nkr, int nrow, int target, int warm, int ncus, int per_cu)
+{
+    double best = 1e30; int best_n = 1, best_gap = 1 << 30;
+    for (int n = 1; n <= std::max(1, nkr / 4); n++) {
+        const int kc = (nkr + n - 1) / n;
+        const long blocks = (long)nrow * ((nkr + kc - 1) / kc);
+        const long rounds = (blocks + (long)ncus * per_cu - 1) / ((long)ncus * per_cu);
+        const double cost = (double)rounds * (kc + warm);
+        const int gap = std::abs(kc - target);
+        if (cost < best * 0.97 || (cost <= best * 1.03 && gap < best_gap)) { best = std::min(best, cost); best_n = n; best_gap = gap; }
+    }
+    return best_n;
+}
+
 static const char *g_last_pair_kernel = "";     // name of the fused sweep kernel launched last (fl_jacobi_kernel_name)
 
 // Two sweeps in one launch (in -> out holds iterate +2) when the fused kernel applies; returns false
@@ -1184,13 +1202,15 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
         const int target2 = wide ? 80 : 32;
         int nchunks = ((2 * nkr + target2) / (2 * target2) + quantum / 2) / quantum * quantum;
         if (nchunks < quantum) nchunks = quantum;
+        const int ncus = rt().num_cus;
+        if (ncus != 256) nchunks = chunks_for_cus(nkr, nby2, target2, 2, ncus, 1);
         int kc = (nkr + nchunks - 1) / nchunks;
         bool pays = kc >= 16;
         if (!whole && std::max(lenA, lenB) <= 48) {
             // short ranges (the ends of a split launch): as many chunks as fill the 256 CUs once -- a block marches its
             // chunk plus two warm-up planes, so 2 ranges x 32 row blocks x 4 chunks of 3 planes beat 2 x 32 x 1 of 10
             const int nranges = (lenA > 0) + (lenB > 0);
-            const int per_range = std::max(1, 256 / std::max(1, nby2 * nranges));
+            const int per_range = std::max(1, ncus / std::max(1, nby2 * nranges));
             kc = std::max(2, (std::max(lenA, lenB) + per_range - 1) / per_range);
             pays = true;
         }
@@ -1237,6 +1257,7 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
         const int quantum = 512 / gcd;                          // chunk counts that make nby * nbz a multiple of 512
         int nchunks = ((2 * nkr + target) / (2 * target) + quantum / 2) / quantum * quantum;
         if (nchunks < quantum) nchunks = quantum;
+        if (rt().num_cus != 256) nchunks = chunks_for_cus(nkr, nby, target, 2, rt().num_cus, 2);
         kchunk = (nkr + nchunks - 1) / nchunks;
         if (kchunk < 16) kchunk = target;                       // small grids: no whole round to fill anyway
         if (!whole && std::max(lenA, lenB) <= 48) kchunk = std::max(lenA, lenB);
@@ -1270,6 +1291,7 @@ static bool jacobi_sweep_triple(const float *in, const float *div, float *out, i
     const int target = 32;
     int nchunks = ((2 * nk + target) / (2 * target) + quantum / 2) / quantum * quantum;
     if (nchunks < quantum) nchunks = quantum;
+    if (rt().num_cus != 256) nchunks = chunks_for_cus(nk, nby2, target, 4, rt().num_cus, 1);
     int kc = (nk + nchunks - 1) / nchunks;
     if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
     if (kc < 16 && rt().opt_jacobi_rows != 2) return false;  // chunks too short to pay for four warm-up planes

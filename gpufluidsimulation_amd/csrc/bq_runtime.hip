@@ -3,6 +3,7 @@
 // (src/bimocq3D/GPU_Advection.h:214-326): device selection, zero-filled allocation,
 // copies, event timing -- plus the error latch the reference lacks.
 #include "bq_host.h"
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 
@@ -50,6 +51,25 @@ void *pinned(size_t bytes)
     return g_rt.pinned;
 }
 
+// The compute stream.  FL_OPT_RESERVE_CUS = k > 0: created with a CU mask that leaves k compute units unused, so that the
+// RCCL send/recv kernels of the halo stream find free CUs the moment an exchange is issued instead of queueing behind
+// compute workgroups that occupy all of them (the fused Jacobi kernels run one 4-wave block per CU for the whole launch).
+// The mask's bits are dealt round-robin over the 8 XCDs (KFD: bit i -> XCD i % 8; tools/cu_mask_probe.hip prints what a
+// mask really excludes), so clearing the top k bits takes k / 8 CUs from every XCD.
+static bool create_compute_stream()
+{
+    const int total = g_rt.device_cus > 0 ? g_rt.device_cus : 256;
+    int k = g_rt.opt_reserve_cus;
+    if (k < 0) k = 0;
+    if (k > total / 2) k = total / 2;
+    g_rt.num_cus = total - k;
+    if (k == 0) return BQ_HIP(hipStreamCreateWithFlags(&g_rt.compute, hipStreamNonBlocking));
+    uint32_t mask[16] = { 0 };
+    const int words = (total + 31) / 32;
+    for (int b = 0; b < total - k; b++) mask[b / 32] |= 1u << (b % 32);
+    return BQ_HIP(hipExtStreamCreateWithCUMask(&g_rt.compute, (uint32_t)words, mask));
+}
+
 } // namespace bq
 
 using bq::g_rt;
@@ -77,7 +97,8 @@ int fl_init(int device)
         bq::latch(FL_ERR_NO_DEVICE, "fl_init: kernels are built for gfx950 only, device is", prop.gcnArchName);
         return FL_ERR_NO_DEVICE;
     }
-    if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.compute, hipStreamNonBlocking))) return FL_ERR_HIP;
+    g_rt.device_cus = prop.multiProcessorCount;
+    if (!bq::create_compute_stream()) return FL_ERR_HIP;
     if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.halo, hipStreamNonBlocking))) return FL_ERR_HIP;
     if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.copy, hipStreamNonBlocking))) return FL_ERR_HIP;
     g_rt.device = device;
@@ -252,6 +273,21 @@ void fl_set_option(int option, int value)
     case FL_OPT_FUSED_HOUSEKEEPING: g_rt.opt_fused_housekeeping = value & 15; break;
     case FL_OPT_MAP_QUARTER_FP32: g_rt.opt_map_quarter_fp32 = value != 0; break;
     case FL_OPT_MGCG_TILE:       g_rt.opt_mgcg_tile = value < 0 ? 0 : value; break;
+    case FL_OPT_PROFILE_COMM:    g_rt.opt_profile_comm = value != 0; break;
+    case FL_OPT_RESERVE_CUS: {
+        const int k = value < 0 ? 0 : value;
+        if (k == g_rt.opt_reserve_cus) break;
+        g_rt.opt_reserve_cus = k;
+        if (!g_rt.ready) break;                 // applied by fl_init
+        // swap the compute stream for one with the new mask: everything queued has to finish first, and a cached
+        // graph captured on the old stream is dropped
+        fl_sync();
+        bq::mgcg_release_graph();
+        (void)hipStreamDestroy(g_rt.compute);
+        g_rt.compute = nullptr;
+        if (!bq::create_compute_stream()) g_rt.ready = false;
+        break;
+    }
     default: bq::latch(FL_ERR_BAD_ARGUMENT, "fl_set_option", "unknown option");
     }
 }
@@ -273,6 +309,8 @@ int fl_get_option(int option)
     case FL_OPT_FUSED_HOUSEKEEPING: return g_rt.opt_fused_housekeeping;
     case FL_OPT_MAP_QUARTER_FP32: return g_rt.opt_map_quarter_fp32;
     case FL_OPT_MGCG_TILE:       return g_rt.opt_mgcg_tile;
+    case FL_OPT_PROFILE_COMM:    return g_rt.opt_profile_comm;
+    case FL_OPT_RESERVE_CUS:     return g_rt.opt_reserve_cus;
     default: return -1;
     }
 }

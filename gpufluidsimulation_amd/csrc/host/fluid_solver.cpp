@@ -523,6 +523,40 @@ static BimocqGPUSolver *g_trace_solver = nullptr;
 static int g_trace_frame = 0;
 static void trace_hook_fn(const char *stage) { if (g_trace_solver) trace_stage(*g_trace_solver, stage, g_trace_frame); }
 
+// BQ_OPT_PROFILE_PHASES: one event per phase boundary on the compute stream (it closes the running span and opens the
+// next); the spans are summed in phaseTotals()
+void BimocqGPUSolver::phaseMark(int phase)
+{
+    if (!profile_phases && phase_open_ < 0) return;
+    void *ev = fl_event_create();
+    if (!ev) return;
+    fl_event_record(ev);
+    bool used = false;
+    if (phase_open_ >= 0) { phase_spans_.push_back(PhaseSpan{ phase_open_ev_, ev, phase_open_ }); used = true; }
+    if (profile_phases && phase >= 0 && phase < PH_COUNT) { phase_open_ev_ = ev; phase_open_ = phase; used = true; }
+    else { phase_open_ev_ = nullptr; phase_open_ = -1; }
+    if (!used) fl_event_destroy(ev);
+}
+
+void BimocqGPUSolver::phaseTotals(double ms[PH_COUNT], long long *steps, bool reset)
+{
+    for (int a = 0; a < PH_COUNT; a++) ms[a] = 0.0;
+    for (const PhaseSpan &sp : phase_spans_) {
+        const float t = fl_event_elapsed_ms(sp.a, sp.b);
+        if (t > 0.f) ms[sp.phase] += (double)t;
+    }
+    if (steps) *steps = phase_steps_;
+    if (reset) {
+        std::vector<void *> evs;
+        for (const PhaseSpan &sp : phase_spans_) { evs.push_back(sp.a); evs.push_back(sp.b); }
+        std::sort(evs.begin(), evs.end());
+        evs.erase(std::unique(evs.begin(), evs.end()), evs.end());
+        for (void *e : evs) if (e != phase_open_ev_) fl_event_destroy(e);
+        phase_spans_.clear();
+        phase_steps_ = 0;
+    }
+}
+
 // :129-230
 void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
 {
@@ -530,6 +564,7 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     g_trace_solver = this; g_trace_frame = framenum; g_trace_hook = trace_hook_fn;
     if (framenum == 0) MaxVelocity = CellSize;           // :131 (overwritten by getCFL, kept for the record)
     float proj_coeff = 2.f;
+    phaseMark(PH_MAPS);
     const float cfldt = getCFL();                        // :136
     last_cfldt = cfldt;
     // how many cells anything can travel this step (bounds the reach of the gather kernels on slab ranks)
@@ -539,6 +574,7 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     VelocityAdvector.updateMapping(VelocityU, VelocityV, VelocityW, cfldt, dt, dcells);
     if (!ScalarAdvector.sharesMaps()) ScalarAdvector.updateMapping(VelocityU, VelocityV, VelocityW, cfldt, dt, dcells);
     trace_stage(*this, "maps", framenum);
+    phaseMark(PH_ADVECT);
 
     // :143-145
     VelocityAdvector.advectVelocity(VelocityU, VelocityV, VelocityW, VelocityUInit, VelocityVInit, VelocityWInit,
@@ -547,6 +583,7 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     ScalarAdvector.advectFields2(Density, DensityInit, DensityPrev, Temperature, TemperatureInit, TemperaturePrev);
     const bool policy1 = reinit_policy == 1;
     trace_stage(*this, "advect", framenum);
+    phaseMark(PH_FORCES);
 
     // Dead state: what :213-214 accumulates into *Init before a re-initialisation moves to *Prev (:503-511), and *Prev
     // is read by the two-level advection only when blend != 1 (Mapping.cpp:383-390).  With blend == 1 and a
@@ -604,8 +641,10 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
     if (!delta_from_gradient) { VelocityUTemp.copy_from(VelocityU); VelocityVTemp.copy_from(VelocityV); VelocityWTemp.copy_from(VelocityW); }
 
     trace_stage(*this, "forces", framenum);
+    phaseMark(PH_PROJECTION);
     const bool have_delta = projection(delta_from_gradient);             // :183
     trace_stage(*this, "projection", framenum);
+    phaseMark(PH_ACCUMULATE);
 
     if (!have_delta) {
         // :188-193 dProj = U - UTemp.  The reference copies U into dProj and then adds -1*UTemp in
@@ -666,6 +705,8 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
         scalarReinitialize();
     }
     steps_taken++;
+    if (phase_open_ >= 0) phase_steps_++;
+    phaseMark(PH_COUNT);
     trace_stage(*this, "reinit", framenum);
 }
 

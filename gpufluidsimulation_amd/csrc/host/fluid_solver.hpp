@@ -70,6 +70,12 @@ public:
     int   jacobi_iters = 100;           // :409
     float halfrdx = 0.5f;               // :410 (quarter-strength projection; 1.0 is the physical value)
     bool  verbose = false;              // print "[Bimocq GPU Time: ...]" like the reference (:126)
+    // BQ_OPT_PROFILE_PHASES: event pairs on the compute stream around the phases of advanceBimocq -- where a step's time
+    // goes on THIS rank, exposed communication included (the waits sit inside the phase that needs the data)
+    enum Phase { PH_MAPS = 0, PH_ADVECT, PH_FORCES, PH_PROJECTION, PH_ACCUMULATE, PH_COUNT };
+    bool  profile_phases = false;
+    void  phaseMark(int phase);                     // closes the running phase and opens `phase` (PH_COUNT: just close)
+    void  phaseTotals(double ms[PH_COUNT], long long *steps, bool reset);   // blocking
 
     float _alpha = 0.f, _beta = 0.f;    // smoke parameters (:529-534)
     Scheme myscheme;
@@ -106,6 +112,11 @@ public:
     std::vector<Emitter> sim_emitter;
 
 private:
+    struct PhaseSpan { void *a, *b; int phase; };
+    std::vector<PhaseSpan> phase_spans_;
+    void *phase_open_ev_ = nullptr;
+    int phase_open_ = -1;
+    long long phase_steps_ = 0;
     bool ok_ = false;
     float *dump_host_ = nullptr;        // pinned staging buffer of the asynchronous dump
     DeviceField dump_dev_;              // device snapshot of the dumped frame (the next advance() rewrites Density)

@@ -14,6 +14,25 @@ gpuMapper::gpuMapper(int device, int nx, int ny, int nz, float h, const SlabCtx 
     slab = sl;
     g.ni = nx; g.nj = ny; g.nk = slab.on ? slab.nk_local() : nz; g.h = h;
     if (fl_init(device) != FL_OK) return;                 // cudaInit(), GPU_Advection.h:214-226
+    // The operator ABI's size limits (include/bimocq_gpu.h, "Limits"), checked before anything is allocated: the gather
+    // kernels address a field through a buffer descriptor with 32-bit byte offsets, so ONE field -- (ni+1)(nj+1)(nk+1)
+    // floats at most -- must stay below 2 GiB, and planes are launched along grid.z (nk + 1 <= 65 535).  BASELINE config 5
+    // (1024 x 1024 x 512: 2.0 GiB per field) therefore needs at least two z-slab ranks.
+    {
+        const double per_plane = 4.0 * (double)(g.ni + 1) * (double)(g.nj + 1);
+        if (per_plane * (double)(g.nk + 1) >= 2147483648.0 || g.nk + 1 > 65535) {
+            int ranks = 0;
+            const int G = slab.on && slab.G > 0 ? slab.G : 8;
+            for (int r = 2; r <= 4096 && !ranks; r++)
+                if (nz % r == 0 && per_plane * (double)(nz / r + 2 * G + 1) < 2147483648.0 && nz / r + 2 * G + 1 <= 65535) ranks = r;
+            char msg[240];
+            snprintf(msg, sizeof msg, "a field of %d x %d x %d planes is %.2f GiB: the operators take fields below 2 GiB (32-bit buffer "
+                     "descriptors) and at most 65534 planes; split the grid into at least %d z-slab ranks",
+                     g.ni, g.nj, g.nk, per_plane * (double)(g.nk + 1) / 1073741824.0, ranks);
+            fl_report_error(FL_ERR_UNSUPPORTED, msg);
+            return;
+        }
+    }
     if (slab.on) fl_set_slab(slab.koff(), slab.nkg, slab.own0, slab.own1, slab.nk_local());
     else fl_set_slab(0, 0, 0, 0, 0);
     ok_ = allocField(u_src, FIELD_U) && allocField(v_src, FIELD_V) && allocField(w_src, FIELD_W)

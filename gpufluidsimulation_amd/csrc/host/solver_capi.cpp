@@ -102,6 +102,8 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         s->solver->GpuSolver->jacobi_ends_first = value != 0;
     } else if (option == BQ_OPT_SHALLOW_BLOCKING_EXCHANGE) {
         s->solver->GpuSolver->shallow_blocking = value < 0 ? 0 : value;
+    } else if (option == BQ_OPT_PROFILE_PHASES) {
+        s->solver->profile_phases = value != 0;
     } else if (option == BQ_OPT_REINIT_POLICY) {
         s->solver->setReinitPolicy(value);
         s->solver->ScalarAdvector.keepDmcBorder = s->solver->VelocityAdvector.keepDmcBorder;
@@ -119,6 +121,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
     case BQ_OPT_OVERLAP_EXCHANGES:   return s->solver->GpuSolver->overlap_exchanges ? 1 : 0;
     case BQ_OPT_JACOBI_ENDS_FIRST:   return s->solver->GpuSolver->jacobi_ends_first ? 1 : 0;
     case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking;
+    case BQ_OPT_PROFILE_PHASES:      return s->solver->profile_phases ? 1 : 0;
     default:                         return -1;
     }
 }
@@ -189,6 +192,14 @@ long bq_solver_mg_history(const bq_solver *s, double *host, long capacity)
     if (host)
         for (long a = 0; a < capacity && a < (long)h.size(); a++) host[a] = h[(size_t)a];
     return (long)h.size();
+}
+
+long long bq_solver_phase_ms(bq_solver *s, double ms[BQ_PHASE_COUNT], int reset)
+{
+    if (!s || !ms) return 0;
+    long long steps = 0;
+    s->solver->phaseTotals(ms, &steps, reset != 0);
+    return steps;
 }
 
 float bq_solver_last_cfldt(const bq_solver *s) { return s ? s->solver->last_cfldt : 0.f; }

@@ -1,0 +1,19 @@
+"""The two synthetic scenes of BASELINE.json's configs, as emitter tuples
+(cx, cy, cz, radius, density, temperature, emiter, frames) for BimocqGPUSolver.setSmoke / OracleSolver.set_smoke.
+Shared by bench.py, the tests and the golden-hash generators so that all of them run the very same scene."""
+
+# configs 2-4: rising smoke -- one spherical source at step 0, buoyancy along +y (drop 0, rise 1)
+SMOKE = (0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)
+
+
+def rising_smoke(nz_global, h):
+    """the source of SURVEY 8d, centred in z of a grid of nz_global planes of spacing h"""
+    return [(SMOKE[0], SMOKE[1], 0.5 * nz_global * h) + SMOKE[3:]]
+
+
+def leapfrog(nz_global, h):
+    """config 5: the reference's vortex-collision emitters (src/bimocq3D/main.cpp:52-78: 10 frames, density 1, the
+    velocity ring of emit_smoke_velocity_kernel) placed coaxially and both blowing along +x, so that the rear ring
+    threads the front one; no buoyancy (drop = rise = 0)"""
+    zc = 0.5 * nz_global * h
+    return [(0.15, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10), (0.35, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10)]

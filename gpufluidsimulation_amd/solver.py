@@ -41,7 +41,9 @@ HOST_SIGS = {
     "bq_solver_last_cfldt": (C.c_float, [C.c_void_p]),
     "bq_solver_last_ms": (C.c_float, [C.c_void_p]),
     "bq_solver_reinit_count": (C.c_int, [C.c_void_p]),
+    "bq_solver_phase_ms": (C.c_longlong, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
 }
+PHASES = ("maps", "advect_compensate", "forces", "projection", "accumulate_reinit")
 
 _host = None
 
@@ -122,6 +124,12 @@ class BimocqGPUSolver:
 
     def getOption(self, option):
         return self.lib.bq_solver_get_option(self.s, option)
+
+    def phaseMs(self, reset=True):
+        """BQ_OPT_PROFILE_PHASES (option 8): ({phase: ms summed over the profiled steps}, steps)"""
+        ms = (C.c_double * len(PHASES))()
+        steps = self.lib.bq_solver_phase_ms(self.s, ms, 1 if reset else 0)
+        return dict(zip(PHASES, list(ms))), int(steps)
 
     def reinitCounts(self):
         """(velocity map re-initialisations, scalar map re-initialisations) so far"""

@@ -200,6 +200,19 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
                                        double *tempResult, struct SCoarseLevelInfo *levels,
                                        int levelNum, int iter, double halfrdx);
 
+/* ---- Limits of the operators above (part of the ABI contract; each violation latches an error, nothing is launched) ----
+ *   * ONE field must stay below 2 GiB: 4 (ni+1)(nj+1)(nk+1) < 2^31 bytes.  The gather kernels (gpu_solve_*, gpu_advect_*,
+ *     gpu_compensate_*, gpu_accumulate_*, gpu_semilag, gpu_clamp_extrema, gpu_estimate_distortion) address a field through
+ *     a buffer resource descriptor with 32-bit byte offsets, and the offset 2 GiB is where a cell whose base index is
+ *     negative is parked so that the descriptor's range check zeroes its corners (FL_ERR_BAD_ARGUMENT "field larger than
+ *     2 GiB").  512^3 is 0.5 GiB; BASELINE config 5 (1024 x 1024 x 512 = 2.0 GiB per field) needs >= 2 z-slab ranks --
+ *     bq_solver_create / gpuMapper refuse it on one rank with FL_ERR_UNSUPPORTED and name the rank count.
+ *   * one plane must stay below 2^23 elements: (ni+1)(nj+1) < 8 388 608 (flat indices are formed with 24-bit multiplies).
+ *   * nk + 1 <= 65 535: planes are launched along grid.z ("nk too large for grid.z").
+ *   * the fused Jacobi kernels take rows of 32..1024 floats with ni % 4 == 0 and 16-byte aligned pointers; any other row
+ *     runs the one-sweep kernels (same values).
+ */
+
 /* ------------------------------------------------------------------------------------------
  * 2. Runtime mini-ABI (replaces gpuMapper's direct CUDA runtime calls)
  * ---------------------------------------------------------------------------------------- */
@@ -277,6 +290,13 @@ enum {
                                  * the LDS tile kernel -- 4 (the 32-sweep calls) or 2 (the 4-sweep calls) sweeps per launch on a
                                  * 16^3 region per workgroup, and the clears of x / temp0 folded into the first two launches;
                                  * 0: one launch per sweep (mg_smooth_kernel).  Same values either way.          */
+    FL_OPT_PROFILE_COMM    = 15,/* 1: every wait of the compute stream on the halo stream (fl_halo_exchange with wait != 0, fl_halo_wait,
+                                 * fl_p2p_exchange) is bracketed by two timing events, and every in-stream all-reduce too; the
+                                 * sums are read with fl_comm_profile().  Default 0.                                 */
+    FL_OPT_RESERVE_CUS     = 16,/* k > 0: the compute stream is (re)created with a CU mask that leaves k compute units (k / 8 per
+                                 * XCD) to the halo stream, so that RCCL's send/recv kernels start the moment an exchange is
+                                 * issued instead of waiting for compute workgroups to drain; the Jacobi launchers size their
+                                 * grids for the remaining CUs.  Setting it synchronises.  Default 0 (all CUs).       */
     FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
                                  * contract.  1: the caller vouches that every value of the map arrays it passes to the
                                  * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map
@@ -431,6 +451,12 @@ void fl_halo_wait(void);
 /* traffic of this rank since the last reset: out[0] ghost-plane exchanges issued, out[1] bytes sent in them, out[2] point-to-point
  * message groups (wall sheets), out[3] bytes sent in them (counted also when the transport is the null or a host-side one) */
 void fl_comm_stats(long long out[4], int reset);
+/* FL_OPT_PROFILE_COMM: ms[0] / n[0] = milliseconds the compute stream spent blocked on the halo stream (communication that
+ * no kernel hid; with a host-side transport: the wall time of its blocking calls) and the number of such waits,
+ * ms[1] / n[1] = the in-stream scalar all-reduces (CFL maximum, map guard, norms), since the last reset.  Blocking. */
+void fl_comm_profile(double ms[2], long long n[2], int reset);
+/* ncclGetVersion() of the RCCL this process loaded (e.g. 22105), 0 when none is loaded */
+int  fl_comm_rccl_version(void);
 /* Host-side transport hook: replaces RCCL by two callbacks (blocking, called with the compute stream
  * idle).  `exchange` receives fl_halo_exchange's arguments and must move the planes itself
  * (fl_memcpy_d2h / its own wire / fl_memcpy_h2d; plane ranges as documented in bq_halo.hip);

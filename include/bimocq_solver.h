@@ -89,8 +89,16 @@ enum {
      * and their interiors (and the next chunk's first interior) run while it travels -- three launches hide the 8-plane
      * exchange instead of one, at two more short launches per chunk (+ 2 % compute on a 512 x 512 x 64 rank).  0: the
      * exchange starts when the chunk is complete.  Same values either way. */
-    BQ_OPT_JACOBI_ENDS_FIRST = 7
+    BQ_OPT_JACOBI_ENDS_FIRST = 7,
+    /* 1: advanceBimocq brackets its phases with events on the compute stream (read with bq_solver_phase_ms): where the
+     * step's time goes on this rank, the waits for ghost planes included in the phase that needs them.  Default 0. */
+    BQ_OPT_PROFILE_PHASES = 8
 };
+/* BQ_OPT_PROFILE_PHASES: milliseconds per phase summed over the steps since the last reset -- map update (DMC + RK3,
+ * BimocqGPUSolver.cpp:136-139), advection with error compensation (:143-145), sources and forces (:157-177), projection
+ * (:179-193), accumulation and re-initialisation (:195-229).  Returns the number of steps summed.  Blocking. */
+enum { BQ_PHASE_MAPS = 0, BQ_PHASE_ADVECT, BQ_PHASE_FORCES, BQ_PHASE_PROJECTION, BQ_PHASE_ACCUMULATE, BQ_PHASE_COUNT };
+long long bq_solver_phase_ms(bq_solver *s, double ms[BQ_PHASE_COUNT], int reset);
 /* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
  * last step measured (policy 1; 0 otherwise) */
 int   bq_solver_reinit_counts(const bq_solver *s, int which);

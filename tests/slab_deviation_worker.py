@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--make-reference", default=None, metavar="DIR")
     ap.add_argument("--reference", default=None, metavar="DIR")
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"), help="non-cubic grid, h = 1 / NX (config 5's rows: 1024 1024 64)")
+    ap.add_argument("--scene", choices=["smoke", "leapfrog"], default="smoke", help="gpufluidsimulation_amd/scenes.py")
+    ap.add_argument("--dump", default=None, metavar="DIR", help="also write the density dump of every checkpoint step (blocking outputResult)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--checkpoints", type=int, nargs="*", default=None, help="steps (1-based) to compare; default: 1, 5, 10, ... and the last")
     ap.add_argument("--iters", type=int, default=200)
@@ -45,8 +48,13 @@ def parse():
     return ap.parse_args()
 
 
-def scene(s, n, iters):
-    s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])      # what bench.py runs
+def scene(s, dims, iters, which="smoke"):
+    from gpufluidsimulation_amd import scenes
+    nx, ny, nz = dims
+    if which == "leapfrog":
+        s.setSmoke(0.0, 0.0, scenes.leapfrog(nz, 1.0 / nx))              # BASELINE config 5, what bench.py --scene leapfrog runs
+    else:
+        s.setSmoke(0.0, 1.0, scenes.rising_smoke(nz, 1.0 / nx))          # what bench.py runs
     s.setProjection(iters, 0.5)
     s.setOption(3, 1)                                                    # BQ_OPT_FULL_STATE, as in bench.py's headline
 
@@ -58,9 +66,12 @@ def checkpoints(a):
 
 def main():
     a = parse()
-    n = a.size
-    dt = 2.0 / n
+    nx, ny, nz = a.grid if a.grid else (a.size, a.size, a.size)
+    dims = (nx, ny, nz)
+    dt = 2.0 / nx
     cps = checkpoints(a)
+    if a.dump:
+        os.makedirs(a.dump, exist_ok=True)
     import gpufluidsimulation_amd as bq
     from gpufluidsimulation_amd import solver, transport
 
@@ -68,8 +79,8 @@ def main():
         os.makedirs(a.make_reference, exist_ok=True)
         lib = bq.hip_lib()
         assert lib.fl_init(0) == 0
-        s = solver.BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=0)
-        scene(s, n, a.iters)
+        s = solver.BimocqGPUSolver(nx, ny, nz, 1.0, 0.0, 1.0, device=0)
+        scene(s, dims, a.iters, a.scene)
         if a.keep_dmc_border is not None:
             s.setOption(1, a.keep_dmc_border)
         for f in range(a.steps):
@@ -77,8 +88,11 @@ def main():
             if f + 1 in cps:
                 for name in FIELDS:
                     np.save(os.path.join(a.make_reference, f"step{f + 1:04d}_{name}.npy"), s.field(name))
+                if a.dump:
+                    s.outputResult(f, a.dump)
         s._check()
-        print(f"[reference] {a.steps} steps of {n}^3 on one GPU, checkpoints {cps}, max|v| = {np.abs(s.field('v')).max():.4f}", flush=True)
+        print(f"[reference] {a.steps} steps of {nx}x{ny}x{nz} on one GPU, checkpoints {cps}, max|u| = {np.abs(s.field('u')).max():.4f}, "
+              f"max|v| = {np.abs(s.field('v')).max():.4f}", flush=True)
         s.close()
         return 0
 
@@ -97,21 +111,23 @@ def main():
         tr = None
     else:
         tr = transport.HostStagedTransport(lib, dist)
-    s = solver.BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0, device=0, rank=rank, nranks=world, ghost=a.ghost)
-    scene(s, n, a.iters)
+    s = solver.BimocqGPUSolver(nx, ny, nz, 1.0, 0.0, 1.0, device=0, rank=rank, nranks=world, ghost=a.ghost)
+    scene(s, dims, a.iters, a.scene)
     if a.keep_dmc_border is not None:
         s.setOption(1, a.keep_dmc_border)
     mode = s.getOption(1)
-    plane = {"u": (n + 1) * n, "v": n * (n + 1)}
+    plane = {"u": (nx + 1) * ny, "v": nx * (ny + 1)}
     report, worst = [], 0.0
     for f in range(a.steps):
         s.advance(f, dt)
         s._check()
         if f + 1 not in cps:
             continue
+        if a.dump:
+            s.outputResult(f, a.dump)
         row = {"step": f + 1}
         for name in FIELDS:
-            pe = plane.get(name, n * n)
+            pe = plane.get(name, nx * ny)
             ref = np.load(os.path.join(a.reference, f"step{f + 1:04d}_{name}.npy"), mmap_mode="r")
             mine = s.owned(name).astype(np.float64)
             want = np.asarray(ref[pe * s.own0: pe * s.own0 + mine.size], dtype=np.float64)
@@ -128,11 +144,11 @@ def main():
             print(f"[slab-deviation] step {f + 1:3d}: " + "  ".join(f"{k} rms {row[k]['rms']:.2e} max {row[k]['max']:.2e}" for k in FIELDS), flush=True)
     ok = worst <= a.rms_tol
     if rank == 0:
-        out = {"grid": [n, n, n], "ranks": world, "ghost": a.ghost, "jacobi_iters": a.iters, "steps": a.steps,
+        out = {"grid": [nx, ny, nz], "scene": a.scene, "ranks": world, "ghost": a.ghost, "jacobi_iters": a.iters, "steps": a.steps,
                "keep_dmc_border": mode, "transport": ("RCCL branch through tests/fake_rccl" if os.environ.get("BQ_RCCL_LIBRARY") else "host-staged over gloo") + ", ranks share GPU 0",
                "compared_with": "single-GPU run of the same library in the same mode (itself bit-identical to the CPU oracle)",
                "worst_rms": worst, "rms_tol": a.rms_tol, "exchanges_per_rank": (tr.exchanges if tr else None), "checkpoints": report}
-        print(f"[slab-deviation] {world} ranks, {n}^3, BQ_OPT_KEEP_DMC_BORDER = {mode}: worst RMS {worst:.3e} "
+        print(f"[slab-deviation] {world} ranks, {nx}x{ny}x{nz}, BQ_OPT_KEEP_DMC_BORDER = {mode}: worst RMS {worst:.3e} "
               f"({'within' if ok else 'ABOVE'} {a.rms_tol:g})", flush=True)
         if a.json:
             with open(a.json, "w") as fjs:
