@@ -45,8 +45,12 @@ $(PKG)/libbimocq_host.so: $(HOST_OBJS) $(PKG)/libbimocq_hip.so
 	g++ -shared -fPIC -pthread -o $@ $(HOST_OBJS) -L$(PKG) -lbimocq_hip $(VDB_LIBS) -Wl,-rpath,'$$ORIGIN'
 
 # the reference's driver loop (main.cpp:137-159) on this library
-example: build/bimocq3d
+example: build/bimocq3d build/bimocq3d_ranks
 build/bimocq3d: examples/bimocq3d_main.cpp $(PKG)/libbimocq_host.so
+	g++ -O2 -std=c++17 -pthread -Iinclude -I$(CSRC)/host $< -o $@ -L$(PKG) -lbimocq_host -lbimocq_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
+# the same loop as one rank of an N-GPU run, C++ only (RANK / WORLD_SIZE from the environment, ncclUniqueId through a file)
+build/bimocq3d_ranks: examples/bimocq3d_ranks.cpp $(PKG)/libbimocq_host.so
 	g++ -O2 -std=c++17 -pthread -Iinclude -I$(CSRC)/host $< -o $@ -L$(PKG) -lbimocq_host -lbimocq_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 oracle:

@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 INFINITY_CACHE_BYTES = 256 << 20
 JACOBI_BYTES_PER_VOXEL = 12.0   # read p + read div + write p'  
 
-SMOKE = (0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)     # (cx, cy, cz, radius, density, temperature, emiter, frames): SURVEY 8d
+from gpufluidsimulation_amd.scenes import SMOKE, leapfrog, rising_smoke     # noqa: E402  (pure Python, no GPU touched)
 
 
 def parse():
@@ -81,6 +81,14 @@ def parse():
                     help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 = blocking ghost refreshes, 2 = also the overlapped ones move only "
                          "the planes asked for (N > 1)")
     ap.add_argument("--no-ends-first", action="store_true", help="BQ_OPT_JACOBI_ENDS_FIRST = 0 (N > 1)")
+    ap.add_argument("--reserve-cus", type=int, default=0, metavar="K",
+                    help="FL_OPT_RESERVE_CUS: the compute stream leaves K compute units (K / 8 per XCD) to the halo stream's "
+                         "RCCL kernels")
+    ap.add_argument("--diag-steps", type=int, default=None,
+                    help="N > 1 (or --emulate-slab): steps of the diagnostic leg after the timed region (exposed communication, "
+                         "per-phase times) and of each extra leg (--shallow-exchange 2, --no-ends-first, --reserve-cus 8/16); "
+                         "default min(steps, 10), 0 = none")
+    ap.add_argument("--cpu-256", action="store_true", help="CPU baseline on BASELINE.md section 4's second sample too: 256^3 x 3 steps (minutes)")
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side of a z-slab rank (N > 1)")
     ap.add_argument("--keep-dmc-border", type=int, default=None,
                     help="N > 1: BQ_OPT_KEEP_DMC_BORDER (see DESIGN.md section 7); default = the library's slab default")
@@ -144,24 +152,34 @@ def cpu_baseline(args):
     cores = int(os.environ.get("BENCH_CPU_THREADS", usable_cores()))
     os.environ["OMP_NUM_THREADS"] = str(cores)                  # read by libgomp when the oracle is loaded
     import oracle_lib
-    oracle_lib.lib(march="native", out="_build_native")        # rebuilt for this host's ISA
-    n = args.cpu_n
-    s = oracle_lib.OracleSolver(n, n, n, 1.0, 0.0, 1.0)
-    s.set_smoke(0.0, 1.0, [SMOKE])
+    oracle_lib.lib(march="native", out="_build_native")        # rebuilt for this host's ISA (oracle/Makefile: -O3 -fopenmp)
     mg = args.projection == "mgcg"
-    s.set_projection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
-    dt = 2.0 / n
-    s.advance(0, dt)                                            # untimed: first-touch + emission
-    t0 = time.perf_counter()
-    for f in range(1, 1 + args.cpu_steps):
-        s.advance(f, dt)
-    el = time.perf_counter() - t0
-    s.close()
-    return {"value": round(n ** 3 * args.cpu_steps / el / 1e6, 4), "unit": "Mvoxels/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{args.cpu_steps} steps of {n}^3 rising smoke ("
-                      + (f"fp64 multigrid-CG, {args.mg_iters} outer iterations" if mg else f"{args.jacobi_iters} Jacobi iters")
-                      + f"), OpenMP C oracle (-O2 -march=native), {el:.1f} s"}
+
+    def sample(n, steps):
+        s = oracle_lib.OracleSolver(n, n, n, 1.0, 0.0, 1.0)
+        s.set_smoke(0.0, 1.0, [SMOKE])
+        s.set_projection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)
+        dt = 2.0 / n
+        s.advance(0, dt)                                        # untimed: first-touch + emission
+        t0 = time.perf_counter()
+        for f in range(1, 1 + steps):
+            s.advance(f, dt)
+        el = time.perf_counter() - t0
+        s.close()
+        return round(n ** 3 * steps / el / 1e6, 4), el
+
+    n = args.cpu_n
+    value, el = sample(n, args.cpu_steps)
+    out = {"value": value, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+           "sample": f"{args.cpu_steps} steps of {n}^3 rising smoke ("
+                     + (f"fp64 multigrid-CG, {args.mg_iters} outer iterations" if mg else f"{args.jacobi_iters} Jacobi iters")
+                     + f"), OpenMP C oracle (gcc -O3 -march=native -fopenmp -ffp-contract=off), {el:.1f} s; BASELINE.md section 4 "
+                       "names 128^3 x 20 and 256^3 x 3 steps -- bounded here to keep the default run within minutes "
+                       "(--cpu-steps 20 / --cpu-256 run those)"}
+    if args.cpu_256:
+        v256, el256 = sample(256, 3)
+        out["sample_256"] = {"value": v256, "unit": "Mvoxels/s", "sample": f"3 steps of 256^3, {el256:.1f} s"}
+    return out
 
 
 def pmc_traffic(dims, kernel):
@@ -219,6 +237,9 @@ def main():
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     lib = bq.hip_lib()
     if lib.fl_init(local_rank) != 0:
+        bq.check()
+    if args.reserve_cus:
+        lib.fl_set_option(bq._lib.FL_OPT_RESERVE_CUS, args.reserve_cus)
         bq.check()
 
     # ---- the grid -------------------------------------------------------------------------------------
@@ -281,14 +302,11 @@ def main():
 
     # ---- the scene ------------------------------------------------------------------------------------
     if args.scene == "leapfrog":
-        # the reference's vortex-collision emitters (main.cpp:52-78: 10 frames, density 1, velocity ring of its
-        # emitter formula), placed coaxially and both blowing along +x: the rear ring threads the front one
-        zc = 0.5 * nz_global * h
-        s.setSmoke(0.0, 0.0, [(0.15, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10), (0.35, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10)])
+        s.setSmoke(0.0, 0.0, leapfrog(nz_global, h))        # gpufluidsimulation_amd/scenes.py
     elif multi and weak:
         s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(nslabs)])    # one source per slab
     else:
-        s.setSmoke(0.0, 1.0, [(SMOKE[0], SMOKE[1], 0.5 * nz_global * h) + SMOKE[3:]])
+        s.setSmoke(0.0, 1.0, rising_smoke(nz_global, h))
     mg = args.projection == "mgcg"
     if mg and multi:
         sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
@@ -365,6 +383,66 @@ def main():
         el_fast = time.perf_counter() - t2
         lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
         extra = (extra_steps, el_extra, el_fast)
+    # ---- diagnostics for z-slab runs: what the timed region alone cannot tell (outside it: the event pairs cost ~1 %) ----
+    # One leg with the run's own settings -- communication no kernel hid (the compute stream's waits on the halo stream),
+    # the in-stream all-reduces, milliseconds per phase of the step, on EVERY rank -- and one short leg per knob whose best
+    # setting only real links can decide.  A single 8-GPU run then says where the time goes and which knob to turn.
+    diag, legs = None, {}
+    dsteps = args.diag_steps if args.diag_steps is not None else max(1, min(10, args.steps))
+    if multi and dsteps > 0 and args.scheme == "bimocq" and not mg:
+        L_ = bq._lib
+        own_voxels = nx * ny * (nz_global // nslabs)
+
+        def leg(setup=None, restore=None):
+            if setup:
+                setup()
+            lib.fl_set_option(L_.FL_OPT_PROFILE_COMM, 1)
+            s.setOption(8, 1)                                   # BQ_OPT_PROFILE_PHASES
+            lib.fl_comm_profile(None, None, 1)
+            s.phaseMs(reset=True)
+            lib.fl_comm_stats(None, 1)
+            barrier()
+            t_ = time.perf_counter()
+            run(dsteps)
+            barrier()
+            e_ = time.perf_counter() - t_
+            ms2, n2, st4 = (C.c_double * 2)(), (C.c_longlong * 2)(), (C.c_longlong * 4)()
+            lib.fl_comm_profile(ms2, n2, 1)
+            phases, psteps = s.phaseMs(reset=True)
+            lib.fl_comm_stats(st4, 0)
+            lib.fl_set_option(L_.FL_OPT_PROFILE_COMM, 0)
+            s.setOption(8, 0)
+            if restore:
+                restore()
+            bq.check()
+            mine = {"rank": rank, "ms_per_step": round(e_ / dsteps * 1e3, 3),
+                    "comm_exposed_ms_per_step": round(ms2[0] / dsteps, 4), "comm_waits_per_step": round(n2[0] / dsteps, 1),
+                    "allreduce_ms_per_step": round(ms2[1] / dsteps, 4), "allreduces_per_step": round(n2[1] / dsteps, 1),
+                    "phase_ms_per_step": {k: round(v / max(1, psteps), 3) for k, v in phases.items()},
+                    "ghost_MB_sent_per_step": round(st4[1] / dsteps / 1e6, 1), "wall_sheet_MB_sent_per_step": round(st4[3] / dsteps / 1e6, 2)}
+            everyone = [mine]
+            if dist is not None:
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+            slow = max(everyone, key=lambda r_: r_["ms_per_step"])
+            out = {"steps": dsteps, "ms_per_step": slow["ms_per_step"],
+                   "value": round((voxels if world > 1 else own_voxels) / (slow["ms_per_step"] * 1e-3) / 1e6, 2),
+                   "comm_exposed_ms_per_step": max(r_["comm_exposed_ms_per_step"] for r_ in everyone),
+                   "allreduce_ms_per_step": max(r_["allreduce_ms_per_step"] for r_ in everyone),
+                   "phase_ms_per_step_slowest_rank": slow["phase_ms_per_step"], "slowest_rank": slow["rank"]}
+            return out, everyone
+
+        diag, everyone = leg()
+        diag["per_rank"] = everyone
+        diag["note"] = ("comm_exposed_ms_per_step: time the compute stream spent blocked on the halo stream (event pairs around "
+                        "every wait; max over ranks) -- communication that no kernel hid; phase times include the waits that fall "
+                        "into the phase; measured in a separate leg after the timed region")
+        sh, ef, rc = args.shallow_exchange, not args.no_ends_first, args.reserve_cus
+        alt_sh = 0 if sh == 2 else 2
+        legs[f"shallow_exchange_{alt_sh}"] = leg(lambda: s.setOption(6, alt_sh), lambda: s.setOption(6, sh))[0]
+        legs["ends_first_" + ("off" if ef else "on")] = leg(lambda: s.setOption(7, 0 if ef else 1), lambda: s.setOption(7, 1 if ef else 0))[0]
+        for k_ in ([8, 16] if rc == 0 else [0]):
+            legs[f"reserve_cus_{k_}"] = leg(lambda: lib.fl_set_option(L_.FL_OPT_RESERVE_CUS, k_), lambda: lib.fl_set_option(L_.FL_OPT_RESERVE_CUS, rc))[0]
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -394,7 +472,9 @@ def main():
                                + f"halfrdx {args.halfrdx}, reinit every step"
                                + (", density dumped every frame (async, per slab)" if args.dump else ""),
                    "grid_per_gpu": [nx, ny, own_planes], "global_grid": [nx, ny, nz_global], "dt": dt,
-                   "comm_size": comm_size,
+                   "nonfinite_velocity_seen": bool(lib.fl_nonfinite_seen(0)),
+                   "comm_size": comm_size, "rccl_version": (int(lib.fl_comm_rccl_version()) or None) if world > 1 else None,
+                   "reserved_cus": args.reserve_cus,
                    "comm_per_step_rank0": None if not multi else {
                        "ghost_exchanges": round(comm_stats[0] / args.steps, 1), "ghost_MB_sent": round(comm_stats[1] / args.steps / 1e6, 1),
                        "wall_sheet_groups": round(comm_stats[2] / args.steps, 1), "wall_sheet_MB_sent": round(comm_stats[3] / args.steps / 1e6, 2)},
@@ -410,9 +490,12 @@ def main():
         # what the rank advances per step is its own slab
         line["value"] = round(nx * ny * own_planes * args.steps / el / 1e6, 2)
         line["config"]["value_counts"] = "owned voxels of the emulated rank only"
+    if diag:
+        line["diagnostics"] = diag
+        line.setdefault("extra", {}).update(legs)
     if extra:
         extra_steps, el_extra, el_fast = extra
-        line["extra"] = {"dead_state_elision": {"value": round(voxels * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
+        line.setdefault("extra", {}).update({"dead_state_elision": {"value": round(voxels * extra_steps / el_extra / 1e6, 2), "unit": "Mvoxels/s",
                                                 "ms_per_step": round(el_extra / extra_steps * 1e3, 3), "steps": extra_steps,
                                                 "note": "library default: with blend == 1 and a re-initialisation every frame the "
                                                         "*Prev fields are never read, so the accumulation that only feeds them is "
@@ -421,7 +504,7 @@ def main():
                                                "ms_per_step": round(el_fast / extra_steps * 1e3, 3), "steps": extra_steps,
                                                "note": "FL_OPT_FAST_LERP = 1 on top of the elision: every lerp of the gather kernels is "
                                                        "one fp32 fma; NOT the reference arithmetic (DESIGN.md section 12: deviation "
-                                                       "from the exact fields measured per grid size, tolerance 1e-5 RMS)"}}
+                                                       "from the exact fields measured per grid size, tolerance 1e-5 RMS)"}})
     if launches.value > 0 and mg:
         # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_lean2r_kernel (mg_smooth2_kernel with FL_OPT_JACOBI_ROWS = 3): one launch reads x and
         # rhs and writes x' once (24 B/cell compulsory), which is 24 B/cell/sweep x 2 sweeps in SURVEY 8(d)'s per-sweep
@@ -461,6 +544,9 @@ def main():
         line["roofline"] = {"bound": "hbm", "kernel": kname,
                             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                             "traffic": traffic,
+                            "traffic_source": ("profiles/jacobi_pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this "
+                                               "grid (FETCH_SIZE x 2 as the microarchitecture guide prescribes for gfx950 + WRITE_SIZE, "
+                                               "separate passes, tools/jacobi_pmc.sh) -- NOT measured in this run") if traffic else None,
                             "frac_traffic": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                             "compulsory_bytes_per_launch": int(compulsory),
                             "working_set": ("infinity-cache" if resident else "hbm"),
@@ -487,6 +573,9 @@ def main():
         lib.fl_comm_destroy()
         dist.destroy_process_group()
     if rank == 0:
+        if line["config"]["nonfinite_velocity_seen"]:
+            print("[bench] WARNING: a NaN or an Inf appeared in the velocity field during this run (fl_nonfinite_seen): the "
+                  "timings are those of a broken simulation", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
 
 

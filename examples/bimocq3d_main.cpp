@@ -46,8 +46,10 @@ int main(int argc, char **argv)
         Emitter a, b;                                                // main.cpp:75-78: 10 frames, density 1, +x velocity ring
         a.emitFrame = b.emitFrame = 10; a.emit_density = b.emit_density = 1.f; a.emit_temperature = b.emit_temperature = 0.f;
         a.emiter = b.emiter = 1.f; a.radius = b.radius = 0.08f;
-        a.e_pos[0] = 0.15f; a.e_pos[1] = 0.5f; a.e_pos[2] = 0.25f;
-        b.e_pos[0] = 0.35f; b.e_pos[1] = 0.5f; b.e_pos[2] = 0.25f;
+        // the ring axis passes BETWEEN nodes: a node on it would get 0/0 from the emitter's direction normalisation
+        const float yc = 0.5f + 0.37f * h, zc = 0.5f * (float)nk * h + 0.29f * h;
+        a.e_pos[0] = 0.15f; a.e_pos[1] = yc; a.e_pos[2] = zc;
+        b.e_pos[0] = 0.35f; b.e_pos[1] = yc; b.e_pos[2] = zc;
         mysolver.setSmoke(smoke_drop, smoke_rise, { a, b });
     } else {
         Emitter src;                                                 // one warm sphere, applied at frame 0 only

@@ -70,6 +70,7 @@ HIP_SIGS = {
     "gpu_maps_quarter_safe": (c_i, [VP, VP, VP] + _G),
     "fl_map_guard_reset": (None, [c_i]),
     "fl_map_guard_read": (None, [C.POINTER(c_i)]),
+    "fl_nonfinite_seen": (c_i, [c_i]),
     "gpu_max_abs3": (c_f, [VP, VP, VP, c_i, c_i, c_i]),
     "gpu_divergence": (None, [VP] * 4 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -177,12 +177,16 @@ __global__ __launch_bounds__(256) void init_maps_kernel(float *x, float *y, floa
 }
 
 // getCFL (BimocqGPUSolver.cpp:348-373) as a wave64 max-reduction over the three components
+// part[b]: the block's maximum of |x|; flag[b] (may be null): 1 when the block met a NaN or an Inf.  A maximum skips NaNs
+// (the reference's host scan `if (fabs(x) > MaxVelocity)` does too), so a field that has gone NaN looks perfectly calm to the
+// CFL -- the flag is how a caller finds out (fl_nonfinite_seen): acc += 0 * x turns NaN for a NaN or an Inf and costs nothing
+// in a kernel that waits for memory.
 __global__ __launch_bounds__(256) void max_abs3_partial_kernel(const float *__restrict__ u, size_t nu,
                                                                const float *__restrict__ v, size_t nv,
                                                                const float *__restrict__ w, size_t nw,
-                                                               float *__restrict__ part)
+                                                               float *__restrict__ part, float *__restrict__ flag)
 {
-    float m = 0.f;
+    float m = 0.f, acc = 0.f;
     const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     // 16-byte loads over the aligned bulk of each array (a maximum does not care about the order), scalars for the rest
     auto scan = [&](const float *f, size_t n) {
@@ -191,29 +195,40 @@ __global__ __launch_bounds__(256) void max_abs3_partial_kernel(const float *__re
         for (size_t i = t0; i < bulk; i += stride) {
             const float4 q = f4[i];
             m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+            acc = __builtin_fmaf(0.f, q.x, acc); acc = __builtin_fmaf(0.f, q.y, acc);
+            acc = __builtin_fmaf(0.f, q.z, acc); acc = __builtin_fmaf(0.f, q.w, acc);
         }
-        for (size_t i = t0; i < head; i += stride) m = fmaxf(m, fabsf(f[i]));
-        for (size_t i = head + 4 * bulk + t0; i < n; i += stride) m = fmaxf(m, fabsf(f[i]));
+        for (size_t i = t0; i < head; i += stride) { m = fmaxf(m, fabsf(f[i])); acc = __builtin_fmaf(0.f, f[i], acc); }
+        for (size_t i = head + 4 * bulk + t0; i < n; i += stride) { m = fmaxf(m, fabsf(f[i])); acc = __builtin_fmaf(0.f, f[i], acc); }
     };
     scan(u, nu); scan(v, nv); scan(w, nw);
     __shared__ float smax[4];
+    __shared__ int sbad[4];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    const bool bad = __any(acc != acc);
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = m; sbad[threadIdx.x >> 6] = bad ? 1 : 0; }
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        if (flag) flag[blockIdx.x] = (sbad[0] | sbad[1] | sbad[2] | sbad[3]) ? 1.f : 0.f;
+    }
 }
 
-__global__ __launch_bounds__(256) void max_final_kernel(const float *__restrict__ part, int n, float floor_value, float *out)
+// out[0] = max(floor, max part); flag != null: out[1] = max flag (0 or 1)
+__global__ __launch_bounds__(256) void max_final_kernel(const float *__restrict__ part, int n, float floor_value, float *out,
+                                                        const float *__restrict__ flag = nullptr)
 {
-    float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
-    __shared__ float smax[4];
+    float m = 0.f, fl = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { m = fmaxf(m, part[i]); if (flag) fl = fmaxf(fl, flag[i]); }
+    __shared__ float smax[4], sfl[4];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    fl = wave_max(fl);
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = m; sfl[threadIdx.x >> 6] = fl; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float r = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
         *out = (r > floor_value) ? r : floor_value;     // `if (fabs(x) > MaxVelocity)` starting from 1e-4
+        if (flag) out[1] = fmaxf(fmaxf(sfl[0], sfl[1]), fmaxf(sfl[2], sfl[3]));
     }
 }
 
@@ -235,7 +250,18 @@ static inline int stream_blocks(size_t n)
 
 using namespace bq;
 
+static int g_nonfinite_seen = 0;    // sticky: a gpu_max_abs3 met a NaN or an Inf in the velocity (fl_nonfinite_seen)
+
 extern "C" {
+
+// 1 when some gpu_max_abs3 since the last reset met a NaN or an Inf in u, v or w (on any slab rank); reset != 0 clears it.
+// The CFL maximum itself skips NaNs like the reference's host scan, so without this a run that has gone NaN looks calm.
+int fl_nonfinite_seen(int reset)
+{
+    const int v = g_nonfinite_seen;
+    if (reset) g_nonfinite_seen = 0;
+    return v;
+}
 
 void gpu_emit_smoke(float *u, float *v, float *w, float *rho, float *T, float h, int ni, int nj, int nk,
                     float centerX, float centerY, float centerZ, float radius, float density, float temperature, float emiter)
@@ -304,9 +330,10 @@ float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int n
     if (!ensure_ready("gpu_max_abs3")) return 0.f;
     if (!u || !v || !w || ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, "gpu_max_abs3", "bad argument"); return 0.f; }
     const int blocks = 1024;
-    float *part = (float *)scratch((blocks + 16) * sizeof(float));
+    float *part = (float *)scratch((2 * blocks + 16) * sizeof(float));
     float *host = (float *)pinned(64);
     if (!part || !host) return 0.f;
+    float *flag = part + blocks + 8;
     hipStream_t st = rt().compute;
     // a slab rank reduces the planes it owns (ghost copies may be stale); the last rank also owns w's top plane
     const Runtime &r = rt();
@@ -315,12 +342,13 @@ float gpu_max_abs3(const float *u, const float *v, const float *w, int ni, int n
     const int wtop = (!r.slab_on || r.slab_own1 == r.slab_nkg) ? 1 : 0;
     const size_t pu = (size_t)(ni + 1) * nj, pv = (size_t)ni * (nj + 1), pw = (size_t)ni * nj;
     const size_t nu = pu * (p1 - p0), nv = pv * (p1 - p0), nw = pw * (p1 - p0 + wtop);
-    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(u + pu * p0, nu, v + pv * p0, nv, w + pw * p0, nw, part);
-    max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 1e-4f, part + blocks);
+    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(u + pu * p0, nu, v + pv * p0, nv, w + pw * p0, nw, part, flag);
+    max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 1e-4f, part + blocks, flag);
     BQ_LAUNCH_CHECK("max_abs3");
-    comm_allreduce(part + blocks, 1, false, true, st);        // global CFL over the slab ranks
-    BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));
+    comm_allreduce(part + blocks, 2, false, true, st);        // global CFL (and the NaN / Inf flag) over the slab ranks
+    BQ_HIP(hipMemcpyAsync(host, part + blocks, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
+    if (host[1] != 0.f) g_nonfinite_seen = 1;
     return host[0];
 }
 
@@ -336,7 +364,7 @@ float gpu_max_field(const float *field, size_t count)
     float *host = (float *)pinned(64);
     if (!part || !host) return 0.f;
     hipStream_t st = rt().compute;
-    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(field, count, field, 0, field, 0, part);    // values are >= 0 or skipped
+    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(field, count, field, 0, field, 0, part, nullptr);    // values are >= 0 or skipped
     max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 0.f, part + blocks);
     BQ_LAUNCH_CHECK("max_field");
     BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));

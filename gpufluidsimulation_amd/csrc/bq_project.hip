@@ -1215,7 +1215,7 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
             pays = true;
         }
         if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
-        if (kc < 4) kc = 4;
+        if (kc < 2) kc = 2;
         if (pays || rt().opt_jacobi_rows == 2) {
             const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kc)};
             const int nbz2 = rg.nchA + chunks_of(lenB, kc);

@@ -15,5 +15,11 @@ def leapfrog(nz_global, h):
     """config 5: the reference's vortex-collision emitters (src/bimocq3D/main.cpp:52-78: 10 frames, density 1, the
     velocity ring of emit_smoke_velocity_kernel) placed coaxially and both blowing along +x, so that the rear ring
     threads the front one; no buoyancy (drop = rise = 0)"""
-    zc = 0.5 * nz_global * h
-    return [(0.15, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10), (0.35, 0.5, zc, 0.08, 1.0, 0.0, 1.0, 10)]
+    # The ring axis must not pass through grid nodes: emit_smoke_velocity_kernel normalises the (y, z) offset from the axis
+    # (GPU_kernel.cu:750), so a node exactly ON it gets 0/0 -- NaN, for v and w too (NaN * 0) -- and the projection then
+    # spreads the NaN 199 cells per step (SURVEY Q14; rounds 1-2 put the axis at (0.5, nz h / 2): on the nodes j = nx/2,
+    # k = nz/2 of EVERY grid, so every leapfrog run of those rounds was a NaN run).  The reference nudges its second
+    # emitter the same way (main.cpp:64: centre y = 0.201 on a 0.002 grid).
+    yc = 0.5 + 0.37 * h
+    zc = 0.5 * nz_global * h + 0.29 * h
+    return [(0.15, yc, zc, 0.08, 1.0, 0.0, 1.0, 10), (0.35, yc, zc, 0.08, 1.0, 0.0, 1.0, 10)]

@@ -317,6 +317,10 @@ const char *fl_jacobi_kernel_name(void);
  * ---------------------------------------------------------------------------------------- */
 /* precondition check of FL_OPT_MAP_QUARTER_FP32: 1 when every value of x, y, z is 0 or in [h/256, 1024 h]; blocking;
  * z-slab ranks get one common answer */
+/* 1 when a gpu_max_abs3 since the last reset met a NaN or an Inf in the velocity (on any slab rank; reset != 0 clears).  The
+ * CFL maximum skips NaNs like the reference's host scan (BimocqGPUSolver.cpp:348-373), so a run that has gone NaN -- e.g. a
+ * source whose axis passes through grid nodes, SURVEY Q14 -- would otherwise look perfectly calm to its driver. */
+int  fl_nonfinite_seen(int reset);
 int  gpu_maps_quarter_safe(const float *x, const float *y, const float *z, float h, int ni, int nj, int nk);
 /* the same check without a pass over the maps: while armed, gpu_solve_backwardDMC (word 0) and gpu_solve_forward (word 1)
  * flag every value they store that fails the test.  _reset(which) arms the guard and clears a word (which < 0: off);

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="BQ_OPT_OVERLAP_EXCHANGES")
     ap.add_argument("--shallow", type=int, default=0, help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE")
     ap.add_argument("--ends-first", type=int, default=1, help="BQ_OPT_JACOBI_ENDS_FIRST")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="FL_OPT_RESERVE_CUS (gpu backend): CU-masked compute stream")
     ap.add_argument("--scheme", type=int, default=0, help="0: BiMocq, 3: MAC_REFLECTION (BQ_SCHEME_*)")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
@@ -70,6 +71,10 @@ def main():
         abilib = bq.hip_lib()
         hostlib = solver.host_lib()
         assert abilib.fl_init(0) == 0
+        if a.reserve_cus:
+            abilib.fl_set_option(bq._lib.FL_OPT_RESERVE_CUS, a.reserve_cus)
+            assert abilib.fl_get_option(bq._lib.FL_OPT_RESERVE_CUS) == a.reserve_cus and abilib.fl_last_error() == 0
+        abilib.fl_set_option(bq._lib.FL_OPT_PROFILE_COMM, 1)
     if a.transport == "rccl":
         assert a.backend == "gpu"
         assert abilib.fl_comm_selftest() == 0, abilib.fl_last_error_string()
@@ -139,6 +144,13 @@ def main():
                 planes = sorted(set((np.nonzero(d)[0] // pe + s.own0).tolist()))
                 print(f"[rank {rank}] step {f}: {name} differs, max|diff| {d.max():.3e} in global planes {planes[:12]}{'...' if len(planes) > 12 else ''}", flush=True)
                 bad += 1
+    if a.backend == "gpu":
+        # FL_OPT_PROFILE_COMM was on: every wait of the compute stream on the halo stream was timed
+        ms2, n2 = (C.c_double * 2)(), (C.c_longlong * 2)()
+        abilib.fl_comm_profile(ms2, n2, 1)
+        print(f"[rank {rank}] comm profile: {n2[0]} waits {ms2[0]:.3f} ms exposed, {n2[1]} in-stream all-reduces {ms2[1]:.3f} ms", flush=True)
+        if world > 1 and not (n2[0] > 0 and ms2[0] >= 0.0):
+            bad += 1
     moved = np.abs(o.field("v")).max()
     print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} planes={tr.planes_moved} "
           f"p2p={tr.p2p_messages}msgs/{tr.p2p_floats}floats max|v|={moved:.4f} mismatches={bad}", flush=True)

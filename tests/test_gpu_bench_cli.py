@@ -48,6 +48,29 @@ def test_multi_rank_bench_launches_itself():
     assert line["config"]["comm_size"] == 2
     assert "BQ_OPT_KEEP_DMC_BORDER = 0" in line["config"]["parallelism"]
     assert line["value"] > 0
+    # N > 1 lines diagnose themselves (here: host-staged transport, whose blocking calls count as exposed communication)
+    d = line["diagnostics"]
+    assert len(d["per_rank"]) == 2 and d["comm_exposed_ms_per_step"] > 0
+    assert d["phase_ms_per_step_slowest_rank"]["projection"] > 0
+    assert {"shallow_exchange_2", "ends_first_off", "reserve_cus_8", "reserve_cus_16"} <= set(line["extra"])
+
+
+def test_emulated_rank_line_carries_phases_and_knob_legs():
+    """--emulate-slab: one process plays a middle rank with a transport that moves nothing; the diagnostic leg gives the
+    per-phase times of the slab code path and the compute-side price of each knob (the CU-masked stream included)"""
+    line = run_bench("--size", 64, "--emulate-slab", 2, "--steps", 3, "--warmup", 1, "--jacobi-iters", 40, "--no-cpu-baseline",
+                     "--no-extra", "--diag-steps", 2)
+    assert "EMULATED" in line["metric"]
+    d = line["diagnostics"]
+    assert d["steps"] == 2 and d["comm_exposed_ms_per_step"] == 0.0 and len(d["per_rank"]) == 1
+    assert d["phase_ms_per_step_slowest_rank"]["advect_compensate"] > 0
+    assert line["extra"]["reserve_cus_8"]["ms_per_step"] > 0 and line["config"]["reserved_cus"] == 0
+
+
+def test_roofline_names_the_source_of_its_traffic_figure():
+    line = run_bench("--steps", 3, "--warmup", 2, "--no-cpu-baseline", "--no-extra")      # 256^3: a committed PMC pass exists
+    rf = line["roofline"]
+    assert rf["traffic"] and "profiles/jacobi_pmc_traffic.json" in rf["traffic_source"] and "NOT measured in this run" in rf["traffic_source"]
 
 
 def test_config5_command_slab_dumps_stitch_to_the_single_gpu_dump(tmp_path):
@@ -58,6 +81,8 @@ def test_config5_command_slab_dumps_stitch_to_the_single_gpu_dump(tmp_path):
     a = run_bench(*common, "--dump", one)
     b = run_bench("--gpus", 2, "--transport", "host", *common, "--dump", two)
     assert "leapfrogging" in a["metric"] and a["config"]["global_grid"] == [64, 64, 32] and b["n_gpus"] == 2
+    # the ring axis passes between nodes (scenes.py): no 0/0 in the emitter, the run stays finite (rounds 1-2: NaN from frame 0)
+    assert a["config"]["nonfinite_velocity_seen"] is False and b["config"]["nonfinite_velocity_seen"] is False
     assert "dumped every frame" in a["config"]["workload"]
     frames = sorted(os.listdir(one))
     assert frames == [f"density_render_{i:04d}.bqd" for i in (1, 2, 3)], frames

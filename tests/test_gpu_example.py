@@ -49,3 +49,34 @@ def test_leapfrog_scene_config5_shape(exe, tmp_path):
         assert np.isfinite(rec["value"]).all() and rec["k"].max() < 32
         # two separate puffs of smoke, one around each ring's source (x = 0.15 and 0.35 of 64 cells)
         assert (rec["i"] < 16).any() and (rec["i"] > 19).any()
+
+
+def test_cpp_rank_driver_two_ranks_stitch_to_one(tmp_path):
+    """examples/bimocq3d_ranks.cpp: the N-rank driver in C++ only (RANK / WORLD_SIZE from the environment, the ncclUniqueId
+    through a file).  Two ranks on this one GPU through the stream-ordered stand-in for librccl (BQ_RCCL_LIBRARY) write
+    per-slab dumps that stitch to the dumps of the same program run as a single rank, byte for byte."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from build_fake_rccl import build
+    from gpufluidsimulation_amd.solver import read_density_dump
+    exe2 = os.path.join(ROOT, "build", "bimocq3d_ranks")
+    if not os.path.exists(exe2):
+        subprocess.check_call(["make", "-s", "example"], cwd=ROOT)
+    fake = build("async")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    args = ["64", "48", "64", "3", None, "1", "8", "60"]            # leapfrog scene: the sources impose velocity
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([exe2] + [one if a is None else a for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "last dump ok" in r.stdout, r.stdout[-2000:]
+    procs = [subprocess.Popen([exe2] + [two if a is None else a for a in args],
+                              env=dict(env, RANK=str(rk), WORLD_SIZE="2", LOCAL_RANK="0", BQ_JOB_ID="t1", BQ_RCCL_LIBRARY=fake),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for rk in (1, 0)]      # rank 1 first: it has to wait for the id
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "[rank 0/2]" in outs[1] and "ghost exchanges" in outs[1] and "last dump ok" in outs[0]
+    for f in sorted(x for x in os.listdir(one) if x.endswith(".bqd")):
+        _, rec = read_density_dump(os.path.join(one, f))
+        parts = sorted(p for p in os.listdir(two) if p.startswith(f[:-4] + ".k"))
+        assert len(parts) == 2, (f, os.listdir(two))
+        stitched = np.concatenate([read_density_dump(os.path.join(two, p))[1] for p in parts])
+        assert len(rec) > 100 and stitched.tobytes() == rec.tobytes(), f

@@ -1,10 +1,12 @@
 """GPU parity, operator by operator: HIP path (through the C-ABI) vs the CPU oracle on the same
 deterministic inputs.  Bar: bit-exact (value equality; the sign of zero is not compared), except
-the emitter's acosf/cosf/hypotf (<= 4 ulp of 0.06) and the summed residual norm (1e-6 relative).
+the summed residual norm (1e-6 relative); the emitter's acosf / cosf / hypotf are restated portably on both sides.
 
 Grids: a non-cubic 24x20x16 with h = 1/24 (IEEE-division path, catches index-order errors) and
 32^3 with h = 1/32 (power-of-two spacing fast path).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -13,7 +15,14 @@ from oracle_lib import fp, lib as oracle
 
 pytestmark = pytest.mark.gpu
 
-GRIDS = [(24, 20, 16, 1.0 / 24), (32, 32, 32, 1.0 / 32)]
+# ... and (round 3) BASELINE config 5's rows: 1024 / 1025 floats wide (rows of 16-17 waves: 16 x-blocks per row in the gather
+# kernels, the marching limiter's 1024-float limit, 4-wave rows in the fused Jacobi), a few rows and planes deep
+GRIDS = [(24, 20, 16, 1.0 / 24), (32, 32, 32, 1.0 / 32), (1024, 12, 10, 1.0 / 1024)]
+# BQ_TEST_EXTRA_GRID="ni,nj,nk": one more grid for a diagnostic run (h = 1 / ni), e.g. 1024,1024,18 -- fields beyond 2^24
+# elements with config 5's planes; minutes of oracle time, so not part of the default suite
+if os.environ.get("BQ_TEST_EXTRA_GRID"):
+    _g = tuple(int(x) for x in os.environ["BQ_TEST_EXTRA_GRID"].split(","))
+    GRIDS.append(_g + (1.0 / _g[0],))
 
 
 @pytest.fixture(scope="module")
@@ -742,4 +751,26 @@ def test_map_value_guards_catch_what_the_fp32_lerps_cannot_take(gm):
     hip.fl_map_guard_read(ok)
     assert list(ok) == [0, 1]
     hip.fl_map_guard_reset(-1)
+    bq.check()
+
+
+def test_nonfinite_velocity_is_flagged(gm):
+    """gpu_max_abs3 skips NaNs like the reference's host scan, so the CFL of a field that has gone NaN looks calm;
+    fl_nonfinite_seen is how a driver finds out (sticky until reset; NaN and Inf, in any of the three components)."""
+    import gpufluidsimulation_amd as bq
+    lib = bq.hip_lib()
+    ni, nj, nk, h = GRIDS[0]
+    gm(ni, nj, nk, h)
+    u, v, w = F.velocity(ni, nj, nk, float(np.float32(h)))
+    lib.fl_nonfinite_seen(1)
+    d = dev(u, v, w)
+    ref = max(1e-4, float(max(np.abs(u).max(), np.abs(v).max(), np.abs(w).max())))
+    assert lib.gpu_max_abs3(d[0].ptr, d[1].ptr, d[2].ptr, ni, nj, nk) == np.float32(ref) and lib.fl_nonfinite_seen(0) == 0
+    for which, bad in ((0, np.nan), (1, np.inf), (2, -np.inf)):
+        f = [u.copy(), v.copy(), w.copy()]
+        f[which][f[which].size // 3] = bad
+        d = dev(*f)
+        got = lib.gpu_max_abs3(d[0].ptr, d[1].ptr, d[2].ptr, ni, nj, nk)
+        assert lib.fl_nonfinite_seen(0) == 1 and lib.fl_nonfinite_seen(1) == 1 and lib.fl_nonfinite_seen(0) == 0
+        assert got == (np.float32(ref) if np.isnan(bad) else np.float32(np.inf))
     bq.check()

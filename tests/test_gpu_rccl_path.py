@@ -84,6 +84,18 @@ def test_tall_slabs_ends_first_chunks_over_the_rccl_branch(fake):
     assert out.count("mismatches=0") == 3
 
 
+def test_reserved_cus_change_no_value_over_the_rccl_branch(fake):
+    """FL_OPT_RESERVE_CUS = 8 / 16: the compute stream is recreated with a CU mask (248 / 240 of the 256 compute units, the
+    Jacobi launchers size their grids for them) so that RCCL's send / recv kernels find free CUs; tall slabs, so that the
+    ends-first pressure chunks and the fused plane-range launches run under the mask.  Every field equals the oracle's."""
+    rc, out = launch_worker(fake, 2, "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 3, "--iters", 60, "--reserve-cus", 8)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2 and "comm profile" in out
+    rc, out = launch_worker(fake, 3, "--dims", 24, 20, 96, "--ghost", 6, "--steps", 2, "--iters", 40, "--dt-cells", 1.0, "--reserve-cus", 16)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
 def test_bench_mode_at_128_over_the_rccl_branch(fake, tmp_path):
     """what `bench.py --gpus N` runs (library defaults, 200 Jacobi iterations, G = 8, wall sheets), 128^3, 12 steps, two
     ranks on the RCCL branch against the single-GPU run: RMS of rho, u, v, w exactly 0"""
@@ -129,6 +141,16 @@ def test_bench_gpus_2_runs_the_rccl_branch(fake, tmp_path):
     assert "falling back" not in err, err[-2000:]
     assert b["n_gpus"] == 2 and b["config"]["comm_size"] == 2 and "rccl" in b["config"]["parallelism"].lower()
     assert "FALLBACK" not in b["config"]["parallelism"]
+    # the line diagnoses itself: exposed communication and per-phase times of every rank, the knobs as extra legs
+    d = b["diagnostics"]
+    assert d["steps"] >= 1 and d["comm_exposed_ms_per_step"] >= 0.0 and len(d["per_rank"]) == 2
+    for r in d["per_rank"]:
+        assert r["comm_waits_per_step"] > 0 and r["ghost_MB_sent_per_step"] > 0
+        assert set(r["phase_ms_per_step"]) == {"maps", "advect_compensate", "forces", "projection", "accumulate_reinit"}
+        assert r["phase_ms_per_step"]["projection"] > 0 and sum(r["phase_ms_per_step"].values()) <= 1.05 * r["ms_per_step"]
+    assert {"shallow_exchange_2", "ends_first_off", "reserve_cus_8", "reserve_cus_16"} <= set(b["extra"])
+    assert all(b["extra"][k]["value"] > 0 for k in ("shallow_exchange_2", "ends_first_off", "reserve_cus_8", "reserve_cus_16"))
+    assert b["config"]["rccl_version"] is None or b["config"]["rccl_version"] > 0       # (the stand-in exports no ncclGetVersion)
     for f in sorted(os.listdir(one)):
         _, rec = read_density_dump(os.path.join(one, f))
         parts = sorted(p for p in os.listdir(two) if p.startswith(f[:-4] + ".k"))

@@ -71,6 +71,14 @@ def test_noncubic_two_emitters_blend_substeps():
              0.1, 1.0, 20, 1.0, 3.0, 6)
 
 
+def test_config5_rows_thin_slab_trajectory():
+    """Rows of 1024 / 1025 floats (BASELINE config 5's row geometry) on a grid thin enough for the oracle: two sources that
+    impose the velocity ring, 4 steps -- every field bit-exact, so a kernel that mishandles rows wider than 1024 floats (the
+    u component) cannot hide behind the thick-grid hash test."""
+    run_pair((1024, 24, 16), 1.0, 0.0, 1.0, [(0.15, 0.0117, 0.0078, 0.006, 1.0, 0.0, 1.0, 3), (0.35, 0.0117, 0.0078, 0.006, 1.0, 0.0, -1.0, 3)],
+             0.0, 0.0, 40, 0.5, 2.0, 4)
+
+
 def test_viscous_step():
     run_pair((20, 24, 16), 1.0, 2e-3, 1.0, [(0.5, 0.3, 0.4, 0.15, 1.0, 2.0, 0.0, 2)], 0.0, 1.0, 12, 0.5, 2.0, 4)
 
