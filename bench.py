@@ -392,6 +392,7 @@ def main():
     if multi and dsteps > 0 and args.scheme == "bimocq" and not mg:
         L_ = bq._lib
         own_voxels = nx * ny * (nz_global // nslabs)
+        voxels = nx * ny * nz_global
 
         def leg(setup=None, restore=None):
             if setup:

@@ -78,6 +78,8 @@ HIP_SIGS = {
     "fl_comm_selftest": (c_i, []),
     "gpu_diffuse_sweeps": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_f]),
     "gpu_max_field": (c_f, [VP, C.c_size_t]),
+    "gpu_max_field_owned": (c_f, [VP, c_i, c_i, c_i]),
+    "gpu_map_travel_z": (None, [VP, VP, c_f, c_i, c_i, c_i, C.POINTER(c_f)]),
     "gpu_smoothing_jacobi": (None, [VP, VP, VP, c_d, c_d, c_i, c_i, c_i, c_i]),
     "gpu_gradient_delta": (None, [VP] * 7 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweep_range": (None, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

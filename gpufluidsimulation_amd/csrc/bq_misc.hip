@@ -232,6 +232,42 @@ __global__ __launch_bounds__(256) void max_final_kernel(const float *__restrict_
     }
 }
 
+// How far along z the two maps of a set carry their nodes: max over the nodes of the update window (2 <= i, j, kg <= n - 3:
+// what forward_kernel / dmc_kernel write; border nodes keep zeros or stale values) of |bz - kg h| and
+// |fz - kg h|, per block.  A NaN counts as infinitely far.  Planes [p0, p1) of the local buffers.
+__global__ __launch_bounds__(256) void map_travel_z_kernel(const float *__restrict__ bz, const float *__restrict__ fz, float h,
+                                                           int ni, int nj, int p0, int koff, int nkg, float *__restrict__ part, int nblocks)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + p0, kg = k + koff;
+    float db = 0.f, df = 0.f;
+    if (i > 1 && i < ni - 2 && j > 1 && j < nj - 2 && kg > 1 && kg < nkg - 2) {
+        const size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+        const float z = (float)kg * h;
+        db = fabsf(bz[id] - z); df = fabsf(fz[id] - z);
+        if (db != db) db = __builtin_inff();
+        if (df != df) df = __builtin_inff();
+    }
+    __shared__ float sb[4], sf[4];
+    db = wave_max(db); df = wave_max(df);
+    if (threadIdx.x == 0) { sb[threadIdx.y] = db; sf[threadIdx.y] = df; }
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        part[b] = fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3]));
+        part[nblocks + b] = fmaxf(fmaxf(sf[0], sf[1]), fmaxf(sf[2], sf[3]));
+    }
+}
+__global__ __launch_bounds__(256) void max2_final_kernel(const float *__restrict__ part, int n, float *out)
+{
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { a = fmaxf(a, part[i]); b = fmaxf(b, part[n + i]); }
+    __shared__ float sa[4], sb[4];
+    a = wave_max(a); b = wave_max(b);
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])); out[1] = fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])); }
+}
+
 // slab context of the library: (koff, nkg); single GPU: (0, nk)
 static inline void slab_ctx(int nk, int &koff, int &nkg)
 {
@@ -370,6 +406,56 @@ float gpu_max_field(const float *field, size_t count)
     BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     return host[0];
+}
+
+// gpu_max_field over the planes this rank owns of a scalar-sized field (ni x nj x nk local planes), all-reduced over the slab
+// ranks: estimateDistortion's host scan (Mapping.cpp:500-516) on a z-slab rank.  Single GPU: gpu_max_field of the field.
+float gpu_max_field_owned(const float *field, int ni, int nj, int nk)
+{
+    if (!ensure_ready("gpu_max_field_owned")) return 0.f;
+    if (!field || ni < 1 || nj < 1 || nk < 1) { latch(FL_ERR_BAD_ARGUMENT, "gpu_max_field_owned", "bad argument"); return 0.f; }
+    const Runtime &r = rt();
+    const int p0 = r.slab_on ? r.slab_own0 - r.slab_koff : 0, p1 = r.slab_on ? r.slab_own1 - r.slab_koff : nk;
+    const size_t plane = (size_t)ni * nj;
+    const int blocks = 1024;
+    float *part = (float *)scratch((blocks + 16) * sizeof(float));
+    float *host = (float *)pinned(64);
+    if (!part || !host) return 0.f;
+    hipStream_t st = rt().compute;
+    max_abs3_partial_kernel<<<blocks, 256, 0, st>>>(field + plane * p0, plane * (size_t)(p1 - p0), field, 0, field, 0, part, nullptr);
+    max_final_kernel<<<1, 256, 0, st>>>(part, blocks, 0.f, part + blocks);
+    BQ_LAUNCH_CHECK("max_field_owned");
+    comm_allreduce(part + blocks, 1, false, true, st);
+    BQ_HIP(hipMemcpyAsync(host, part + blocks, sizeof(float), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipStreamSynchronize(st));
+    return host[0];
+}
+
+// out[0] / out[1]: how many CELLS along z the backward / forward map carries a node at most (max |map_z - z| / h over the
+// nodes the map updates write, owned planes, all-reduced over the slab ranks; a NaN counts as infinity).  What a host needs
+// to know to size -- or to refuse -- the ghost zone of maps that live for more than one step.  Blocking.
+void gpu_map_travel_z(const float *bz, const float *fz, float h, int ni, int nj, int nk, float out[2])
+{
+    if (out) out[0] = out[1] = 0.f;
+    if (!ensure_ready("gpu_map_travel_z")) return;
+    if (!bz || !fz || !out || ni < 1 || nj < 1 || nk < 1 || nk >= 65535 || !(h > 0.f)) { latch(FL_ERR_BAD_ARGUMENT, "gpu_map_travel_z", "bad argument"); return; }
+    const Runtime &r = rt();
+    const int p0 = r.slab_on ? r.slab_own0 - r.slab_koff : 0, p1 = r.slab_on ? r.slab_own1 - r.slab_koff : nk;
+    int koff, nkg;
+    slab_ctx(nk, koff, nkg);
+    const dim3 grid = grid3(ni, nj, p1 - p0);
+    const int nblocks = (int)(grid.x * grid.y * grid.z);
+    float *part = (float *)scratch(((size_t)2 * nblocks + 16) * sizeof(float));
+    float *host = (float *)pinned(64);
+    if (!part || !host) return;
+    hipStream_t st = rt().compute;
+    map_travel_z_kernel<<<grid, kBlock3, 0, st>>>(bz, fz, h, ni, nj, p0, koff, nkg, part, nblocks);
+    max2_final_kernel<<<1, 256, 0, st>>>(part, nblocks, part + 2 * nblocks);
+    BQ_LAUNCH_CHECK("map_travel_z");
+    comm_allreduce(part + 2 * nblocks, 2, false, true, st);
+    BQ_HIP(hipMemcpyAsync(host, part + 2 * nblocks, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipStreamSynchronize(st));
+    out[0] = host[0] / h; out[1] = host[1] / h;
 }
 
 } // extern "C"

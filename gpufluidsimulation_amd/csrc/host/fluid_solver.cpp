@@ -303,11 +303,10 @@ bool BimocqGPUSolver::setReinitPolicy(int policy)
     if (steps_taken != 0) { fl_report_error(FL_ERR_BAD_ARGUMENT, "BQ_OPT_REINIT_POLICY must be set before the first advance()"); return false; }
     if (policy != 0 && policy != 1) { fl_report_error(FL_ERR_BAD_ARGUMENT, "BQ_OPT_REINIT_POLICY: 0 or 1"); return false; }
     if (policy == 1) {
-        if (GpuSolver->slab.on && GpuSolver->slab.nranks > 1) {
-            fl_report_error(FL_ERR_UNSUPPORTED, "distortion-driven re-initialisation is single-GPU (maps that live for many steps outgrow the ghost zone)");
-            return false;
-        }
         if (!ScalarAdvector.unshareMaps()) return false;
+        // z-slab ranks: maps that live for many steps must not outgrow the ghost zone -- their z-travel is measured after
+        // every update and a map set is re-initialised before it would (setTravelLimit)
+        if (GpuSolver->slab.on && GpuSolver->slab.nranks > 1 && travel_limit == 0) setTravelLimit(GpuSolver->slab.G);
         DeviceField *sb[] = { &DensityTemp, &TemperatureTemp, &DensityExtern, &TemperatureExtern };
         for (DeviceField *f : sb)
             if (!f->get() && !GpuSolver->allocField(*f, FIELD_S)) return false;
@@ -316,6 +315,15 @@ bool BimocqGPUSolver::setReinitPolicy(int policy)
     }
     reinit_policy = policy;
     return true;
+}
+
+void BimocqGPUSolver::setTravelLimit(int cells)
+{
+    const SlabCtx &sl = GpuSolver->slab;
+    if (cells < 0) cells = 0;
+    if (sl.on && sl.nranks > 1 && (cells == 0 || cells > sl.G)) cells = sl.G;      // a slab rank cannot serve more than its ghost planes
+    travel_limit = cells;
+    VelocityAdvector.measureTravel = ScalarAdvector.measureTravel = cells > 0;
 }
 
 // BimocqGPUSolver.cpp:60-90: p, dir, residual, div, temp0, temp1 (N doubles each), tempResult (4096), and
@@ -665,11 +673,23 @@ void BimocqGPUSolver::advanceBimocq(int framenum, float dt)
         // units of the step's travel, and the CPU solver's thresholds
         gs.addFields(DensityExtern, Density, DensityTemp, -1.f, g.n());
         gs.addFields(TemperatureExtern, Temperature, TemperatureTemp, -1.f, g.n());
+        gs.produced(DensityExtern, std::min(Density.valid, DensityTemp.valid));
+        gs.produced(TemperatureExtern, std::min(Temperature.valid, TemperatureTemp.valid));
         last_vel_distortion = VelocityAdvector.estimateDistortion() / (MaxVelocity * dt);
         last_scalar_distortion = ScalarAdvector.estimateDistortion() / (MaxVelocity * dt);
         velReinit = scalarReinit = false;
         if (last_vel_distortion > 1.f || framenum - vel_lastReinit > 10) { velReinit = true; vel_lastReinit = framenum; proj_coeff = 1.f; }
         if (last_scalar_distortion > 5.f || framenum - scalar_lastReinit > 30) { scalarReinit = true; scalar_lastReinit = framenum; }
+        if (travel_limit > 0) {
+            // BQ_OPT_REINIT_MAX_TRAVEL: the next update samples the velocity up to Dfwd + dcells + 2 planes away and the
+            // next advection its fields up to Dback + dcells + 2 (mapping.cpp: reachField), dcells taken as this step's.
+            // A set that would not fit is re-initialised now -- the same decision on every rank (the travel is all-reduced)
+            // and on one GPU given the same limit.  Should the flow speed up beyond that estimate the next step's require()
+            // refuses ("ghost zone too shallow") rather than compute from missing planes.
+            const auto outgrows = [&](const MapSet &ms) { return std::max(ms.Dback, ms.Dfwd) + dcells + 2 > travel_limit; };
+            if (!velReinit && outgrows(*VelocityAdvector.maps)) { velReinit = true; vel_lastReinit = framenum; proj_coeff = 1.f; forced_reinits++; }
+            if (!scalarReinit && outgrows(*ScalarAdvector.maps)) { scalarReinit = true; scalar_lastReinit = framenum; forced_reinits++; }
+        }
     } else {
         if (framenum - vel_lastReinit > 10) {                // :200-205
             vel_lastReinit = framenum;

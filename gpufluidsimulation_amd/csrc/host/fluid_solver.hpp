@@ -61,6 +61,12 @@ public:
     bool  keep_full_state = false;      // BQ_OPT_FULL_STATE: also compute state nothing reads (see advanceBimocq)
     int   reinit_policy = 0;            // BQ_OPT_REINIT_POLICY
     bool  setReinitPolicy(int policy);
+    // BQ_OPT_REINIT_MAX_TRAVEL (policy 1): a map set is also re-initialised when its measured z-travel (cells) + this step's
+    // CFL travel + the sampling footprint would no longer fit `travel_limit` planes next step.  0 = no such rule (single GPU
+    // default); z-slab ranks: the ghost depth G (default, and the largest value that makes sense there).
+    int   travel_limit = 0;
+    void  setTravelLimit(int cells);
+    int   forced_reinits = 0;           // re-initialisations the travel rule (not the CPU solver's thresholds) caused
     int   vel_reinits = 0, scalar_reinits = 0;
     float last_vel_distortion = 0.f, last_scalar_distortion = 0.f;
     int   steps_taken = 0;

@@ -65,6 +65,14 @@ void MapperBaseGPU::updateMapping(DeviceField &U, DeviceField &V, DeviceField &W
     fl_map_guard_reset(-1);
     maps->backQ4 = maps->backQ4 && ok[0] == 1;       // (border nodes and stale planes keep older values: stay conservative
     maps->fwdQ4 = maps->fwdQ4 && ok[1] == 1;         //  until the next re-initialisation once a value has failed)
+    if (measureTravel) {
+        // the displacement bounds become what the maps really do along z -- the only axis a z-slab's ghost depth cares about
+        // (on a single GPU nothing reads them; the measurement still runs so that the policy decides alike on any rank count)
+        gpu_map_travel_z(maps->BackwardZ, maps->ForwardZ, g.h, g.ni, g.nj, g.nk, lastTravel);
+        const auto cells = [](float t) { return t < 1.0e6f ? (int)std::ceil((double)t) : 1000000; };   // (inf: a NaN in the map)
+        maps->Dback = cells(lastTravel[0]);
+        maps->Dfwd = cells(lastTravel[1]);
+    }
 }
 
 // Mapping.cpp:354-368.  The reference copies x_out -> Backward after every sub-step
@@ -439,10 +447,14 @@ float MapperBaseGPU::estimateDistortion()
 {
     MapSet &m = *maps;
     gpuMapper &gs = *gpuSolver;
+    // z-slab ranks: the forward map is sampled at backward-mapped positions and the other way round
+    gs.require({ &m.ForwardX, &m.ForwardY, &m.ForwardZ }, reachField(m.Dback));
+    gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, reachField(m.Dfwd));
     fl_memset(gs.u_src, 0, g.n() * sizeof(float));
     gpu_estimate_distortion(gs.u_src, m.BackwardX, m.BackwardY, m.BackwardZ, m.ForwardX, m.ForwardY, m.ForwardZ,
                             g.h, g.ni, g.nj, g.nk);
-    return std::sqrt(gpu_max_field(gs.u_src, g.n()));
+    // (owned planes, all-reduced over the slab ranks; single GPU: the whole field)
+    return std::sqrt(gpu_max_field_owned(gs.u_src, g.ni, g.nj, g.nk));
 }
 
 bool MapperBaseGPU::unshareMaps()

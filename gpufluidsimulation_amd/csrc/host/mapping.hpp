@@ -79,6 +79,12 @@ public:
     // parity with the reference); true = keep the incoming border (the evident intent), which is also the
     // only setting under which z-slab ranks reproduce a single GPU bit for bit.
     bool keepDmcBorder = false;
+    // Measure how far along z the maps really carry their nodes after every update (gpu_map_travel_z) and use THAT as
+    // Dback / Dfwd instead of the running sum of CFL travels: maps that live for many steps (BQ_OPT_REINIT_POLICY = 1)
+    // then need ghost planes for what they do, not for the worst they could have done.  One more 8-byte read-back per
+    // update.  Set by the solver together with BQ_OPT_REINIT_MAX_TRAVEL.
+    bool measureTravel = false;
+    float lastTravel[2] = { 0.f, 0.f };      // cells along z: backward, forward map (what the last measurement saw)
     std::shared_ptr<MapSet> maps;
     gpuMapper *gpuSolver = nullptr;
 

@@ -102,6 +102,8 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         s->solver->GpuSolver->jacobi_ends_first = value != 0;
     } else if (option == BQ_OPT_SHALLOW_BLOCKING_EXCHANGE) {
         s->solver->GpuSolver->shallow_blocking = value < 0 ? 0 : value;
+    } else if (option == BQ_OPT_REINIT_MAX_TRAVEL) {
+        s->solver->setTravelLimit(value);
     } else if (option == BQ_OPT_PROFILE_PHASES) {
         s->solver->profile_phases = value != 0;
     } else if (option == BQ_OPT_REINIT_POLICY) {
@@ -122,6 +124,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
     case BQ_OPT_JACOBI_ENDS_FIRST:   return s->solver->GpuSolver->jacobi_ends_first ? 1 : 0;
     case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking;
     case BQ_OPT_PROFILE_PHASES:      return s->solver->profile_phases ? 1 : 0;
+    case BQ_OPT_REINIT_MAX_TRAVEL:   return s->solver->travel_limit;
     default:                         return -1;
     }
 }
@@ -129,6 +132,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
 int bq_solver_reinit_counts(const bq_solver *s, int which)
 {
     if (!s) return 0;
+    if (which == 2) return s->solver->forced_reinits;
     return which ? s->solver->scalar_reinits : s->solver->vel_reinits;
 }
 

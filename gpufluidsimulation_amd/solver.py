@@ -118,7 +118,8 @@ class BimocqGPUSolver:
 
     def setOption(self, option, value):
         """option 1 = BQ_OPT_KEEP_DMC_BORDER, 2 = BQ_OPT_REINIT_POLICY (0 every frame, 1 distortion-driven),
-        3 = BQ_OPT_FULL_STATE, 4 = BQ_OPT_FUSED_HOUSEKEEPING (include/bimocq_solver.h)"""
+        3 = BQ_OPT_FULL_STATE, 4 = BQ_OPT_FUSED_HOUSEKEEPING, 5 = BQ_OPT_OVERLAP_EXCHANGES, 6 = BQ_OPT_SHALLOW_BLOCKING_EXCHANGE,
+        7 = BQ_OPT_JACOBI_ENDS_FIRST, 8 = BQ_OPT_PROFILE_PHASES, 9 = BQ_OPT_REINIT_MAX_TRAVEL (include/bimocq_solver.h)"""
         self.lib.bq_solver_set_option(self.s, option, value)
         self._check()
 
@@ -134,6 +135,10 @@ class BimocqGPUSolver:
     def reinitCounts(self):
         """(velocity map re-initialisations, scalar map re-initialisations) so far"""
         return self.lib.bq_solver_reinit_counts(self.s, 0), self.lib.bq_solver_reinit_counts(self.s, 1)
+
+    def forcedReinits(self):
+        """re-initialisations caused by BQ_OPT_REINIT_MAX_TRAVEL (option 9) rather than by the policy's thresholds"""
+        return self.lib.bq_solver_reinit_counts(self.s, 2)
 
     def lastDistortion(self):
         return self.lib.bq_solver_last_distortion(self.s, 0), self.lib.bq_solver_last_distortion(self.s, 1)

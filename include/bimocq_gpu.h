@@ -418,6 +418,14 @@ void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, doub
  * (Mapping.cpp:500-516) over the buffer gpu_estimate_distortion filled, as a device reduction; blocking.
  * Intended for non-negative data (it reduces |x|).  Not slab-aware. */
 float gpu_max_field(const float *field, size_t count);
+/* the same over the planes this rank OWNS of a scalar-sized field of nk local planes, all-reduced over the slab ranks
+ * (single GPU: the whole field): estimateDistortion on z-slab ranks */
+float gpu_max_field_owned(const float *field, int ni, int nj, int nk);
+/* out[0] / out[1]: how many cells along z the backward / forward map (their z components bz, fz) carries a node at most --
+ * max |map_z - z| / h over the nodes the map updates write (2 <= i, j, k <= n - 3), owned planes, all-reduced over the slab
+ * ranks; a NaN counts as infinity.  Tells a z-slab host whether maps that live for more than one step still fit its ghost
+ * zone (csrc/host/fluid_solver.cpp: BQ_OPT_REINIT_MAX_TRAVEL).  Blocking. */
+void  gpu_map_travel_z(const float *bz, const float *fz, float h, int ni, int nj, int nk, float out[2]);
 /* clamp_extrema_box for a staggered buffer: dz = 1 for the w component (nk+1 planes) */
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk_buffer);
 /* clampExtrema_kernel (GPU_kernel.cu:146-167) on its own: after = clamp(after, min/max27(before)) */

@@ -62,7 +62,7 @@ enum {
      * (BimocqSolver.cpp:165-229): velocity maps when their round-trip error exceeds 1 step-travel or after 10
      * frames, scalar maps above 5 or after 30 frames; the scalar snapshots are taken before the sources act
      * so that emission reaches DensityInit through the accumulation.  Set before the first advance().
-     * Single GPU only. */
+     * z-slab ranks (round 3): maps that live for many steps must still fit the ghost zone, see BQ_OPT_REINIT_MAX_TRAVEL. */
     BQ_OPT_REINIT_POLICY = 2,
     /* 0 (default): state that nothing can read is not computed -- with blend == 1 and a re-initialisation every
      * frame the *Prev fields are never sampled, so the pre-reinit accumulation into *Init (which only survives as
@@ -92,14 +92,22 @@ enum {
     BQ_OPT_JACOBI_ENDS_FIRST = 7,
     /* 1: advanceBimocq brackets its phases with events on the compute stream (read with bq_solver_phase_ms): where the
      * step's time goes on this rank, the waits for ghost planes included in the phase that needs them.  Default 0. */
-    BQ_OPT_PROFILE_PHASES = 8
+    BQ_OPT_PROFILE_PHASES = 8,
+    /* policy 1 only.  T > 0: after every map update the z-travel of both maps of a set is measured (gpu_map_travel_z: max
+     * |map_z - z| / h, all-reduced over the ranks) and replaces the running sum of CFL travels as the set's displacement
+     * bound; a set whose bound + this step's CFL travel + the two cells of the sampling footprint exceeds T is
+     * re-initialised at the end of the step even though the CPU solver's thresholds would let it live on.  z-slab ranks:
+     * default and maximum T = the ghost depth G (what their ghost planes can serve); single GPU: default 0 (no such rule) --
+     * give both the same T and they re-initialise on the same frames and produce the same fields
+     * (tests/test_slab_multirank.py).  bq_solver_reinit_counts(s, 2) counts the re-initialisations this rule caused. */
+    BQ_OPT_REINIT_MAX_TRAVEL = 9
 };
 /* BQ_OPT_PROFILE_PHASES: milliseconds per phase summed over the steps since the last reset -- map update (DMC + RK3,
  * BimocqGPUSolver.cpp:136-139), advection with error compensation (:143-145), sources and forces (:157-177), projection
  * (:179-193), accumulation and re-initialisation (:195-229).  Returns the number of steps summed.  Blocking. */
 enum { BQ_PHASE_MAPS = 0, BQ_PHASE_ADVECT, BQ_PHASE_FORCES, BQ_PHASE_PROJECTION, BQ_PHASE_ACCUMULATE, BQ_PHASE_COUNT };
 long long bq_solver_phase_ms(bq_solver *s, double ms[BQ_PHASE_COUNT], int reset);
-/* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps) and the distortions the
+/* after a step: re-initialisation counts (which: 0 velocity maps, 1 scalar maps, 2 those forced by BQ_OPT_REINIT_MAX_TRAVEL) and the distortions the
  * last step measured (policy 1; 0 otherwise) */
 int   bq_solver_reinit_counts(const bq_solver *s, int which);
 float bq_solver_last_distortion(const bq_solver *s, int which);

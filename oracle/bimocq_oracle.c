@@ -1055,6 +1055,7 @@ struct orc_solver {
     /* 0: re-initialise both map sets every frame (the GPU solver's `if (1)`, BimocqGPUSolver.cpp:218-229);
      * 1: distortion-driven, the CPU solver's thresholds (BimocqSolver.cpp:165-185) */
     int reinit_policy;
+    int travel_limit, forced_reinits;       /* option 4 (host: BQ_OPT_REINIT_MAX_TRAVEL), see solver_advance */
     int scheme;                 /* enum Scheme (BimocqSolver.h:29): 0 BIMOCQ, 3 MAC_REFLECTION */
     float max_v, last_vel_distortion, last_scalar_distortion;
     int vel_reinits, scalar_reinits;
@@ -1154,9 +1155,10 @@ void orc_solver_set_option(orc_solver *s, int option, int value)
     if (option == 1) s->keep_dmc_border = value != 0;
     if (option == 2) s->reinit_policy = value;
     if (option == 3) s->scheme = value;
+    if (option == 4) s->travel_limit = value < 0 ? 0 : value;
 }
 
-int orc_solver_reinit_counts(const orc_solver *s, int which) { return which ? s->scalar_reinits : s->vel_reinits; }
+int orc_solver_reinit_counts(const orc_solver *s, int which) { return which == 2 ? s->forced_reinits : which ? s->scalar_reinits : s->vel_reinits; }
 float orc_solver_last_distortion(const orc_solver *s, int which) { return which ? s->last_scalar_distortion : s->last_vel_distortion; }
 
 /* BimocqGPUSolver.cpp:60-90: the fp64 work arrays and the level pyramid n -> (n - 1) / 2.  Levels that
@@ -1239,6 +1241,28 @@ static float mapper_distortion(orc_solver *s, mapper_t *m)
     float mx = 0.f;
     for (size_t q = 0; q < s->n; q++) if (s->u_src[q] > mx) mx = s->u_src[q];
     return sqrtf(mx);
+}
+
+/* How many cells along z the maps of a set carry a node at most (the host's gpu_map_travel_z: max |map_z - z| / h over the
+ * nodes the map updates write, a NaN counts as infinity), rounded up -- the displacement bound behind option 4. */
+static int mapper_travel_cells(const orc_solver *s, const mapper_t *m)
+{
+    float mb = 0.f, mf = 0.f;
+    for (int k = 2; k < s->nk - 2; k++) {
+        const float z = (float)k * s->h;
+        for (int j = 2; j < s->nj - 2; j++)
+            for (int i = 2; i < s->ni - 2; i++) {
+                const size_t id = (size_t)i + (size_t)s->ni * ((size_t)j + (size_t)s->nj * k);
+                float db = fabsf(m->bz[id] - z), df = fabsf(m->fz[id] - z);
+                if (db != db) db = INFINITY;
+                if (df != df) df = INFINITY;
+                if (db > mb) mb = db;
+                if (df > mf) mf = df;
+            }
+    }
+    const float tb = mb / s->h, tf = mf / s->h;
+    const int cb = tb < 1.0e6f ? (int)ceil((double)tb) : 1000000, cf = tf < 1.0e6f ? (int)ceil((double)tf) : 1000000;
+    return cb > cf ? cb : cf;
 }
 
 /* Mapping.cpp:393-407 + GPU_Advection.h:505-528 */
@@ -1422,6 +1446,18 @@ void orc_solver_advance(orc_solver *s, int framenum, float dt)
         vel_reinit = scalar_reinit = 0;
         if (s->last_vel_distortion > 1.f || framenum - s->vel_last > 10) { vel_reinit = 1; s->vel_last = framenum; proj_coeff = 1.f; }
         if (s->last_scalar_distortion > 5.f || framenum - s->scal_last > 30) { scalar_reinit = 1; s->scal_last = framenum; }
+        if (s->travel_limit > 0) {
+            /* option 4 (not in the reference: what lets z-slab ranks run this policy, csrc/host/fluid_solver.cpp): a map set
+             * whose z-travel + this step's CFL travel + the sampling footprint would not fit `travel_limit` planes next step
+             * is re-initialised now */
+            const int dcells = (int)ceil((double)dt * (double)s->max_v / (double)h) + 1;
+            if (!vel_reinit && mapper_travel_cells(s, &s->vel) + dcells + 2 > s->travel_limit) {
+                vel_reinit = 1; s->vel_last = framenum; proj_coeff = 1.f; s->forced_reinits++;
+            }
+            if (!scalar_reinit && mapper_travel_cells(s, &s->scal) + dcells + 2 > s->travel_limit) {
+                scalar_reinit = 1; s->scal_last = framenum; s->forced_reinits++;
+            }
+        }
     } else {
         if (framenum - s->vel_last > 10) { s->vel_last = framenum; proj_coeff = 1.f; }   /* :200-205 */
         if (framenum - s->scal_last > 30) { s->scal_last = framenum; }                    /* :207-211 */

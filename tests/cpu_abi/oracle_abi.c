@@ -147,7 +147,7 @@ void gpu_multi_grid_conjugate_gradient(float *a, float *b, float *c, double *d, 
   orc_multi_grid_conjugate_gradient(a, b, c, d, e, f, g, h, i, j, (OrcCoarseLevel *)k, l, m, n); }
 
 /* ---- slab context + communicator (mirrors csrc/bq_halo.hip with the custom transport only) ---- */
-static int s_on, s_koff, s_nkg;
+static int s_on, s_koff, s_nkg, s_own0, s_own1;
 static int c_rank, c_nranks = 1;
 static fl_exchange_cb c_exchange;
 static fl_allreduce_cb c_allreduce;
@@ -162,7 +162,7 @@ int fl_set_plane_window(int k0, int k1)
 }
 void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
 {
-    s_on = nk_global > 0; s_koff = koff; s_nkg = nk_global;
+    s_on = nk_global > 0; s_koff = koff; s_nkg = nk_global; s_own0 = own0; s_own1 = own1;
     g_nk_local = nk_global > 0 ? nk_local : 0;
     orc_set_slab(koff, nk_global, own0, own1, nk_local);
 }
@@ -320,6 +320,35 @@ float gpu_max_field(const float *field, size_t count)
     float m = 0.f;
     for (size_t q = 0; q < count; q++) if (fabsf(field[q]) > m) m = fabsf(field[q]);
     return m;
+}
+float gpu_max_field_owned(const float *field, int ni, int nj, int nk)
+{
+    const int p0 = s_on ? s_own0 - s_koff : 0, p1 = s_on ? s_own1 - s_koff : nk;
+    const size_t plane = (size_t)ni * nj;
+    float m = gpu_max_field(field + plane * p0, plane * (size_t)(p1 - p0));
+    if (c_nranks > 1 && c_allreduce) c_allreduce(&m, 1, 0, 1);
+    return m;
+}
+void gpu_map_travel_z(const float *bz, const float *fz, float h, int ni, int nj, int nk, float out[2])
+{
+    const int p0 = s_on ? s_own0 - s_koff : 0, p1 = s_on ? s_own1 - s_koff : nk, nkg = s_on ? s_nkg : nk;
+    float m[2] = { 0.f, 0.f };
+    for (int k = p0; k < p1; k++) {
+        const int kg = k + (s_on ? s_koff : 0);
+        if (!(kg > 1 && kg < nkg - 2)) continue;
+        const float z = (float)kg * h;
+        for (int j = 2; j < nj - 2; j++)
+            for (int i = 2; i < ni - 2; i++) {
+                const size_t id = (size_t)i + (size_t)ni * ((size_t)j + (size_t)nj * k);
+                float db = fabsf(bz[id] - z), df = fabsf(fz[id] - z);
+                if (db != db) db = INFINITY;
+                if (df != df) df = INFINITY;
+                if (db > m[0]) m[0] = db;
+                if (df > m[1]) m[1] = df;
+            }
+    }
+    if (c_nranks > 1 && c_allreduce) c_allreduce(m, 2, 0, 1);
+    out[0] = m[0] / h; out[1] = m[1] / h;
 }
 void gpu_clamp_extrema_box_w(const float *before, float *after, int ni, int nj, int nk)
 { orc_clamp_extrema_box_w(before, after, ni, nj, nk); }

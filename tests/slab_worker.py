@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--shallow", type=int, default=0, help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE")
     ap.add_argument("--ends-first", type=int, default=1, help="BQ_OPT_JACOBI_ENDS_FIRST")
     ap.add_argument("--reserve-cus", type=int, default=0, help="FL_OPT_RESERVE_CUS (gpu backend): CU-masked compute stream")
+    ap.add_argument("--policy", type=int, default=0, help="BQ_OPT_REINIT_POLICY: 1 = distortion-driven re-initialisation (maps live for several steps)")
+    ap.add_argument("--travel-limit", type=int, default=0, help="BQ_OPT_REINIT_MAX_TRAVEL / oracle option 4 (policy 1): 0 = the rank's ghost depth")
     ap.add_argument("--scheme", type=int, default=0, help="0: BiMocq, 3: MAC_REFLECTION (BQ_SCHEME_*)")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
@@ -97,6 +99,11 @@ def main():
                                scheme=a.scheme)
     s.setSmoke(0.05, 1.0, em)
     s.setProjection(a.iters, 0.5)
+    limit = a.travel_limit or a.ghost
+    if a.policy:
+        s.setOption(2, a.policy)
+        s.setOption(9, limit)
+        assert s.getOption(9) == limit
     s.setOption(1, a.keep_dmc_border)
     s.setOption(5, a.overlap)
     s.setOption(6, a.shallow)
@@ -109,6 +116,9 @@ def main():
     o.set_smoke(0.05, 1.0, em)
     o.set_projection(a.iters, 0.5)
     o.set_option(1, a.keep_dmc_border)
+    if a.policy:
+        o.set_option(2, a.policy)
+        o.set_option(4, limit)
     if a.scheme:
         o.set_option(3, a.scheme)
     dt = a.dt_cells * h
@@ -144,6 +154,12 @@ def main():
                 planes = sorted(set((np.nonzero(d)[0] // pe + s.own0).tolist()))
                 print(f"[rank {rank}] step {f}: {name} differs, max|diff| {d.max():.3e} in global planes {planes[:12]}{'...' if len(planes) > 12 else ''}", flush=True)
                 bad += 1
+    if a.policy:
+        mine = s.reinitCounts() + (s.forcedReinits(),) + s.lastDistortion()
+        want = o.reinit_counts() + (o.l.orc_solver_reinit_counts(o.s, 2),) + o.last_distortion()
+        print(f"[rank {rank}] policy {a.policy}, travel limit {limit}: re-initialisations (velocity, scalar, forced) + distortions {mine}, oracle {want}", flush=True)
+        if mine != want or not (0 < mine[0] < a.steps):
+            bad += 1
     if a.backend == "gpu":
         # FL_OPT_PROFILE_COMM was on: every wait of the compute stream on the halo stream was timed
         ms2, n2 = (C.c_double * 2)(), (C.c_longlong * 2)()

@@ -68,6 +68,26 @@ def test_three_ranks_middle_rank_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_distortion_driven_reinit_on_slabs_cpu():
+    """BQ_OPT_REINIT_POLICY = 1 on z-slab ranks (round 3): maps live for several steps, their z-travel is measured after every
+    update (gpu_map_travel_z, all-reduced) and a map set is re-initialised before it would outgrow the ghost zone
+    (BQ_OPT_REINIT_MAX_TRAVEL = G); the single-domain oracle applies the same rule (option 4), so fields, re-initialisation
+    counts and distortions must agree bit for bit.  blend = 1: the two-level look-up of blend < 1 is exact on slabs only with
+    the kept DMC border (second run)."""
+    env = dict(os.environ)
+    os.environ["SLAB_TEST_BLEND"] = "1.0"
+    try:
+        rc, out = launch(2, "--backend", "cpu", "--steps", 14, "--iters", 20, "--policy", 1, "--dt-cells", 1.0)
+    finally:
+        os.environ.clear(); os.environ.update(env)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2 and "policy 1" in out
+    rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 8, "--iters", 12, "--dt-cells", 0.8,
+                     "--policy", 1, "--keep-dmc-border", 1)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
 def test_viscous_diffusion_on_slabs_cpu():
     """nu != 0: the 20 diffusion sweeps per component run in chunks of G with ghost refreshes in between
     (gpu_diffuse_sweeps), including the reference's buffer aliasing; bit-exact on 2 and 3 ranks"""
