@@ -308,8 +308,8 @@ def main():
     else:
         s.setSmoke(0.0, 1.0, rising_smoke(nz_global, h))
     mg = args.projection == "mgcg"
-    if mg and multi:
-        sys.exit("--projection mgcg is single-GPU (the z-slab path runs the Jacobi projection)")
+    # (N > 1 with --projection mgcg: every rank assembles the global velocity and runs the single-GPU solver on it --
+    #  replicated, bit-identical, not scalable: csrc/host/fluid_solver.cpp projectionMgcgSlabs)
     if args.scheme == "reflection":
         args.no_extra = True                    # the extra legs compare BiMocq state-elision variants
     s.setProjection(args.mg_iters if mg else args.jacobi_iters, args.halfrdx, 1 if mg else 0)

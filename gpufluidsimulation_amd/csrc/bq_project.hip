@@ -1205,7 +1205,15 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
         const int ncus = rt().num_cus;
         if (ncus != 256) nchunks = chunks_for_cus(nkr, nby2, target2, 2, ncus, 1);
         int kc = (nkr + nchunks - 1) / nchunks;
-        bool pays = kc >= 16;
+        // Grids too small to give every CU a chunk of 16 planes (128^3: 8 row blocks): the two-row kernel still wins with the
+        // short chunks that fill the chip exactly once -- 128^3: 32 chunks of 4 planes = 256 blocks, 2.99 us per sweep against
+        // 4.41 for the one-row kernel with chunks of 8 (chunks of 2 / 3 / 5 planes: 3.34 / 3.73 / 3.24; the three-sweep kernel
+        // with chunks of 4: 3.21; gpurun_out/r03f/jacobi_tune_128.txt) -- a march this short is bound by the latency of its
+        // 6 plane steps at one wave per SIMD, so what counts is that no CU waits for a second round.
+        // Smaller still (64^3 2.21 against 4.11 us per sweep, 96^3 3.15 / 4.28, 160^3 7.34 / 9.85, 192^3 8.30 / 12.95,
+        // 256 x 256 x 64 5.49 / 6.74; gpurun_out/r03h/jacobi_small.txt): whole arrays always take the two-row kernel,
+        // chunks down to two planes.
+        bool pays = kc >= 16 || whole;
         if (!whole && std::max(lenA, lenB) <= 48) {
             // short ranges (the ends of a split launch): as many chunks as fill the 256 CUs once -- a block marches its
             // chunk plus two warm-up planes, so 2 ranges x 32 row blocks x 4 chunks of 3 planes beat 2 x 32 x 1 of 10

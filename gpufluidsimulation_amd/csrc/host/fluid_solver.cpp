@@ -332,12 +332,15 @@ void BimocqGPUSolver::setTravelLimit(int cells)
 bool BimocqGPUSolver::allocMgcg()
 {
     if (mg.ready) return true;
-    const size_t n = g.n();
+    // a z-slab rank solves on the WHOLE grid (projectionMgcgSlabs): global plane count
+    const bool slabs = GpuSolver->slab.on && GpuSolver->slab.nranks > 1;
+    const int nk_all = slabs ? GpuSolver->slab.nkg : g.nk;
+    const size_t n = (size_t)g.ni * g.nj * nk_all;
     DeviceBytes *full[] = { &mg.div, &mg.p, &mg.dir, &mg.residual, &mg.temp0, &mg.temp1 };
     for (DeviceBytes *f : full)
         if (!f->alloc(n * sizeof(double))) return false;
     if (!mg.result.alloc(4096 * sizeof(double))) return false;
-    int ni = g.ni, nj = g.nj, nk = g.nk;
+    int ni = g.ni, nj = g.nj, nk = nk_all;
     for (int l = 0; l < LEVEL_COUNT; l++) {
         if (l) { ni = (ni - 1) / 2; nj = (nj - 1) / 2; nk = (nk - 1) / 2; }
         if (ni < 1 || nj < 1 || nk < 1) break;
@@ -350,8 +353,63 @@ bool BimocqGPUSolver::allocMgcg()
         L.b = mg.b.back().f64(); L.x = mg.x.back().f64(); L.r = mg.r.back().f64();
         mg.levels.push_back(L);
     }
+    if (slabs) {
+        if (!mg.gu.alloc((size_t)(g.ni + 1) * g.nj * nk_all) || !mg.gv.alloc((size_t)g.ni * (g.nj + 1) * nk_all) ||
+            !mg.gw.alloc((size_t)g.ni * g.nj * (nk_all + 1))) return false;
+    }
     mg.ready = true;
     return true;
+}
+
+// The multigrid-CG projection on z-slab ranks, REPLICATED: every rank assembles the velocity of the whole grid (its own planes
+// + one point-to-point message per peer and component, a single RCCL group: xGMI is a full mesh), runs the very solver a
+// single GPU runs on it (slab context off) and takes its own planes, ghost planes included, back.  Bit-identical to one GPU
+// by construction -- the reference's float-narrowed dot products, its level pyramid n -> (n - 1) / 2 and its interpolation
+// quirks all see the global arrays -- and the first step towards a slab-decomposed V-cycle: the advection
+// scales with the rank count, the solve does not (it costs what it costs on one GPU, plus ~1 ms of gather).
+bool BimocqGPUSolver::projectionMgcgSlabs()
+{
+    gpuMapper &gs = *GpuSolver;
+    const SlabCtx &sl = gs.slab;
+    const int G = sl.G, nkg = sl.nkg, R = sl.nranks;
+    const bool last = sl.own1 == nkg;
+    struct Comp { DeviceField *loc, *glob; size_t plane; int extra; } comps[3] = {
+        { &VelocityU, &mg.gu, (size_t)(g.ni + 1) * g.nj, 0 }, { &VelocityV, &mg.gv, (size_t)g.ni * (g.nj + 1), 0 },
+        { &VelocityW, &mg.gw, (size_t)g.ni * g.nj, 1 } };
+    // planes rank r owns of a component: its cell planes, the w face on top of the grid goes to the last rank
+    const auto own0_of = [&](int r) { return r * (nkg / R); };
+    const auto planes_of = [&](int r, int extra) { return nkg / R + ((extra && r == R - 1) ? 1 : 0); };
+    std::vector<int> peers; std::vector<float *> send, recv; std::vector<size_t> send_count, recv_count;
+    for (const Comp &c : comps) {
+        const size_t mine = c.plane * (size_t)planes_of(sl.rank, c.extra);
+        fl_memcpy_d2d(c.glob->get() + c.plane * (size_t)sl.own0, c.loc->get() + c.plane * (size_t)G, mine * sizeof(float));
+    }
+    for (int r = 0; r < R; r++) {
+        if (r == sl.rank) continue;
+        for (const Comp &c : comps) {
+            peers.push_back(r);
+            send.push_back(c.loc->get() + c.plane * (size_t)G);
+            send_count.push_back(c.plane * (size_t)planes_of(sl.rank, c.extra));
+            recv.push_back(c.glob->get() + c.plane * (size_t)own0_of(r));
+            recv_count.push_back(c.plane * (size_t)planes_of(r, c.extra));
+        }
+    }
+    fl_p2p_exchange((int)peers.size(), peers.data(), send.data(), send_count.data(), recv.data(), recv_count.data());
+    (void)last;
+    fl_set_slab(0, 0, 0, 0, 0);                                         // the solve sees one global grid
+    gpu_multi_grid_conjugate_gradient(mg.gu, mg.gv, mg.gw, mg.div.f64(), mg.p.f64(), mg.dir.f64(),
+                                      mg.residual.f64(), mg.temp0.f64(), mg.temp1.f64(), mg.result.f64(),
+                                      mg.levels.data(), (int)mg.levels.size(), mg_iters, (double)halfrdx);
+    fl_set_slab(sl.koff(), sl.nkg, sl.own0, sl.own1, sl.nk_local());
+    // the projected velocity on this rank's planes, ghost planes included (those outside the grid stay zero)
+    const int k0 = std::max(sl.own0 - G, 0), k1 = std::min(sl.own1 + G, nkg);
+    for (const Comp &c : comps) {
+        const int np = k1 - k0 + ((c.extra && k1 == nkg) ? 1 : 0);
+        fl_memcpy_d2d(c.loc->get() + c.plane * (size_t)(k0 - (sl.own0 - G)), c.glob->get() + c.plane * (size_t)k0,
+                      c.plane * (size_t)np * sizeof(float));
+        gs.produced(*c.loc, G);
+    }
+    return fl_last_error() == FL_OK;
 }
 
 std::vector<double> BimocqGPUSolver::mgHistory() const
@@ -369,11 +427,8 @@ bool BimocqGPUSolver::projection(bool with_delta)
     gpuMapper &gs = *GpuSolver;
     const float alpha = -1.f, beta = (float)(1.0 / 6.0);
     if (projection_kind == BQ_PROJECTION_MGCG) {            // :443-446
-        if (gs.slab.on && gs.slab.nranks > 1) {
-            fl_report_error(FL_ERR_UNSUPPORTED, "the multigrid-CG projection is single-GPU (use the Jacobi projection on z-slabs)");
-            return false;
-        }
         if (!allocMgcg()) return false;
+        if (gs.slab.on && gs.slab.nranks > 1) { projectionMgcgSlabs(); return false; }
         gpu_multi_grid_conjugate_gradient(VelocityU, VelocityV, VelocityW, mg.div.f64(), mg.p.f64(), mg.dir.f64(),
                                           mg.residual.f64(), mg.temp0.f64(), mg.temp1.f64(), mg.result.f64(),
                                           mg.levels.data(), (int)mg.levels.size(), mg_iters, (double)halfrdx);

@@ -106,8 +106,11 @@ public:
         std::vector<DeviceBytes> b, x, r;
         std::vector<SCoarseLevelInfo> levels;
         bool ready = false;
+        // z-slab ranks: the velocity of the WHOLE grid, assembled on every rank for the replicated solve (projectionMgcgSlabs)
+        DeviceField gu, gv, gw;
     } mg;
     bool allocMgcg();
+    bool projectionMgcgSlabs();
     std::vector<double> mgHistory() const;          // tempResult (4096 doubles), downloaded
 
     std::vector<float> host_density, host_u, host_v, host_w;    // outputResult staging (:538-541)

@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--keep-dmc-border", type=int, default=None, help="default: the library's default for this kind of solver")
     ap.add_argument("--rms-tol", type=float, default=1e-5)
     ap.add_argument("--json", default=None, help="rank 0 writes the figures here")
+    ap.add_argument("--projection", choices=["jacobi", "mgcg"], default="jacobi", help="mgcg: --iters outer iterations of the fp64 multigrid-CG projection")
+    ap.add_argument("--scheme", type=int, default=0, help="0 BiMocq, 3 MAC_REFLECTION")
+    ap.add_argument("--hash-case", default=None, metavar="CASE",
+                    help="ranks only, no --reference: stitch the ranks' owned planes on rank 0 and compare their SHA-256 per step with "
+                         "tests/golden/next_row_hashes.json:CASE (grid, scheme, projection, iterations and steps come from the case)")
     return ap.parse_args()
 
 
@@ -55,8 +60,11 @@ def scene(s, dims, iters, which="smoke"):
         s.setSmoke(0.0, 0.0, scenes.leapfrog(nz, 1.0 / nx))              # BASELINE config 5, what bench.py --scene leapfrog runs
     else:
         s.setSmoke(0.0, 1.0, scenes.rising_smoke(nz, 1.0 / nx))          # what bench.py runs
-    s.setProjection(iters, 0.5)
+    s.setProjection(iters, 0.5, 1 if PROJECTION == "mgcg" else 0)
     s.setOption(3, 1)                                                    # BQ_OPT_FULL_STATE, as in bench.py's headline
+
+
+PROJECTION = "jacobi"
 
 
 def checkpoints(a):
@@ -65,7 +73,16 @@ def checkpoints(a):
 
 
 def main():
+    global PROJECTION
     a = parse()
+    PROJECTION = a.projection
+    spec = None
+    if a.hash_case:
+        with open(os.path.join(ROOT, "tests", "golden", "next_row_hashes.json")) as fh:
+            spec = json.load(fh)["cases"][a.hash_case]
+        a.size, a.iters, a.scheme, a.steps = spec["grid"], spec["iterations"], spec["scheme"], len(spec["rows"])
+        PROJECTION = "mgcg" if spec["projection_kind"] == 1 else "jacobi"
+        a.checkpoints = list(range(1, a.steps + 1))
     nx, ny, nz = a.grid if a.grid else (a.size, a.size, a.size)
     dims = (nx, ny, nz)
     dt = 2.0 / nx
@@ -79,7 +96,7 @@ def main():
         os.makedirs(a.make_reference, exist_ok=True)
         lib = bq.hip_lib()
         assert lib.fl_init(0) == 0
-        s = solver.BimocqGPUSolver(nx, ny, nz, 1.0, 0.0, 1.0, device=0)
+        s = solver.BimocqGPUSolver(nx, ny, nz, 1.0, 0.0, 1.0, device=0, scheme=a.scheme)
         scene(s, dims, a.iters, a.scene)
         if a.keep_dmc_border is not None:
             s.setOption(1, a.keep_dmc_border)
@@ -111,7 +128,7 @@ def main():
         tr = None
     else:
         tr = transport.HostStagedTransport(lib, dist)
-    s = solver.BimocqGPUSolver(nx, ny, nz, 1.0, 0.0, 1.0, device=0, rank=rank, nranks=world, ghost=a.ghost)
+    s = solver.BimocqGPUSolver(nx, ny, nz, 1.0, 0.0, 1.0, device=0, rank=rank, nranks=world, ghost=a.ghost, scheme=a.scheme)
     scene(s, dims, a.iters, a.scene)
     if a.keep_dmc_border is not None:
         s.setOption(1, a.keep_dmc_border)
@@ -125,6 +142,24 @@ def main():
             continue
         if a.dump:
             s.outputResult(f, a.dump)
+        if spec is not None:
+            # the ranks' owned planes, stitched in rank order, must hash like the oracle's global fields
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            from make_hashes import FIELDS as HF, digest_hex
+            want = spec["rows"][f]
+            bad = 0 if float(np.float32(s.cfldt)) == want["cfldt"] else 1
+            for name in HF:
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(s.owned(name), parts, dst=0)
+                if rank == 0 and digest_hex(np.concatenate(parts)) != want[name]:
+                    bad += 1
+                    print(f"[slab-hash] step {f + 1}: {name} differs from {a.hash_case}", flush=True)
+            t = torch.tensor([bad])
+            dist.broadcast(t, src=0)
+            worst = max(worst, float(t.item()))
+            if rank == 0:
+                print(f"[slab-hash] step {f + 1}: {'ok' if t.item() == 0 else 'MISMATCH'}", flush=True)
+            continue
         row = {"step": f + 1}
         for name in FIELDS:
             pe = plane.get(name, nx * ny)

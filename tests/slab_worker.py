@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0, help="FL_OPT_RESERVE_CUS (gpu backend): CU-masked compute stream")
     ap.add_argument("--policy", type=int, default=0, help="BQ_OPT_REINIT_POLICY: 1 = distortion-driven re-initialisation (maps live for several steps)")
     ap.add_argument("--travel-limit", type=int, default=0, help="BQ_OPT_REINIT_MAX_TRAVEL / oracle option 4 (policy 1): 0 = the rank's ghost depth")
+    ap.add_argument("--projection-kind", type=int, default=0, help="0 Jacobi (--iters sweeps), 1 fp64 multigrid-CG (--iters outer iterations; "
+                    "replicated solve on slab ranks)")
     ap.add_argument("--scheme", type=int, default=0, help="0: BiMocq, 3: MAC_REFLECTION (BQ_SCHEME_*)")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
@@ -98,7 +100,7 @@ def main():
     s = solver.BimocqGPUSolver(ni, nj, nk, a.L, a.viscosity, BLEND, lib=hostlib, errlib=abilib, rank=rank, nranks=world, ghost=a.ghost,
                                scheme=a.scheme)
     s.setSmoke(0.05, 1.0, em)
-    s.setProjection(a.iters, 0.5)
+    s.setProjection(a.iters, 0.5, a.projection_kind)
     limit = a.travel_limit or a.ghost
     if a.policy:
         s.setOption(2, a.policy)
@@ -114,7 +116,7 @@ def main():
         pass
     o = OracleSolver(ni, nj, nk, a.L, a.viscosity, BLEND)
     o.set_smoke(0.05, 1.0, em)
-    o.set_projection(a.iters, 0.5)
+    o.set_projection(a.iters, 0.5, a.projection_kind)
     o.set_option(1, a.keep_dmc_border)
     if a.policy:
         o.set_option(2, a.policy)
@@ -123,8 +125,10 @@ def main():
         o.set_option(3, a.scheme)
     dt = a.dt_cells * h
     names = ["rho", "T", "div", "p", "u", "v", "w", "uinit", "vinit", "winit", "rhoinit", "Tinit"]
+    if a.projection_kind:
+        names = [n_ for n_ in names if n_ not in ("div", "p")]      # the multigrid solver keeps its own fp64 div / p
     if a.scheme:
-        names = ["rho", "T", "div", "p", "u", "v", "w"]        # the reflection scheme keeps no map state
+        names = [n_ for n_ in ("rho", "T", "div", "p", "u", "v", "w") if n_ in names]        # the reflection scheme keeps no map state
     plane = {"u": (ni + 1) * nj, "uinit": (ni + 1) * nj, "v": ni * (nj + 1), "vinit": ni * (nj + 1)}
     bad = 0
     if os.environ.get("SLAB_TEST_TRACE") == "1":

@@ -96,6 +96,33 @@ def test_reserved_cus_change_no_value_over_the_rccl_branch(fake):
     assert out.count("mismatches=0") == 3
 
 
+def test_multigrid_projection_on_slabs_over_the_rccl_branch(fake):
+    """the fp64 multigrid-CG projection on z-slab ranks (replicated solve: the global velocity assembled with one
+    point-to-point group, csrc/host/fluid_solver.cpp projectionMgcgSlabs): BiMocq on 2 ranks, the reference binary's default
+    configuration (MAC_REFLECTION + multigrid-CG) on 3 -- every field equals the single-domain oracle's"""
+    rc, out = launch_worker(fake, 2, "--steps", 3, "--iters", 4, "--projection-kind", 1)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch_worker(fake, 3, "--dims", 24, 20, 36, "--ghost", 6, "--steps", 2, "--iters", 3, "--dt-cells", 1.0,
+                            "--projection-kind", 1, "--scheme", 3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_slab_ranks_reproduce_the_mgcg_128_hashes(fake, nranks):
+    """BASELINE-size evidence for the same: 2 and 4 z-slab ranks of the 128^3 rising-smoke run with the multigrid-CG projection
+    (50 outer iterations, 6 levels), their owned planes stitched on rank 0, hash like the CPU oracle's global fields
+    (tests/golden/next_row_hashes.json: mgcg_128 -- no oracle in the loop)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", BQ_RCCL_LIBRARY=fake)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "tests", "slab_deviation_worker.py"), "--hash-case", "mgcg_128", "--rms-tol", "0"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("[slab-hash] step") >= 2 and "MISMATCH" not in r.stdout
+
+
 def test_bench_mode_at_128_over_the_rccl_branch(fake, tmp_path):
     """what `bench.py --gpus N` runs (library defaults, 200 Jacobi iterations, G = 8, wall sheets), 128^3, 12 steps, two
     ranks on the RCCL branch against the single-GPU run: RMS of rho, u, v, w exactly 0"""

@@ -88,6 +88,20 @@ def test_distortion_driven_reinit_on_slabs_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_multigrid_projection_replicated_on_slabs_cpu():
+    """the fp64 multigrid-CG projection (what the reference's binary ships) on z-slab ranks: every rank assembles the global
+    velocity (one point-to-point message per peer and component), runs the single-domain solver on it and takes its planes
+    back -- bit-identical to the single-domain oracle, with the BiMocq scheme (2 ranks) and the reflection scheme, the
+    reference binary's default configuration (3 ranks: two projections per step)"""
+    rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--iters", 4, "--projection-kind", 1)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 2, "--iters", 3, "--dt-cells", 1.0,
+                     "--projection-kind", 1, "--scheme", 3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+
+
 def test_viscous_diffusion_on_slabs_cpu():
     """nu != 0: the 20 diffusion sweeps per component run in chunks of G with ghost refreshes in between
     (gpu_diffuse_sweeps), including the reference's buffer aliasing; bit-exact on 2 and 3 ranks"""
