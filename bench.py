@@ -383,6 +383,19 @@ def main():
         el_fast = time.perf_counter() - t2
         lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
         extra = (extra_steps, el_extra, el_fast)
+    # ---- one GPU: where the step's time goes, and the second kernel family against its own bounds (outside the timed region) ----
+    phase_ms = None
+    if world == 1 and not emul and args.scheme == "bimocq" and not mg and not args.no_extra:
+        n_ph = max(1, min(10, args.steps))
+        s.setOption(3, 1)                                   # the headline's full sequence
+        s.setOption(8, 1)                                   # BQ_OPT_PROFILE_PHASES
+        s.phaseMs(reset=True)
+        barrier()
+        run(n_ph)
+        barrier()
+        phases, psteps = s.phaseMs(reset=True)
+        s.setOption(8, 0)
+        phase_ms = {k: round(v / max(1, psteps), 3) for k, v in phases.items()}
     # ---- diagnostics for z-slab runs: what the timed region alone cannot tell (outside it: the event pairs cost ~1 %) ----
     # One leg with the run's own settings -- communication no kernel hid (the compute stream's waits on the halo stream),
     # the in-stream all-reduces, milliseconds per phase of the step, on EVERY rank -- and one short leg per knob whose best
@@ -563,6 +576,28 @@ def main():
                                                           "sweeps would move; above 1 only because a fused launch moves one sweep's bytes"},
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
                             "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3)}
+    if phase_ms:
+        # The nine-point gather family (advect / compensate / cumulate + the limiter: the advection phase) is NOT bound by
+        # HBM: algorithmic bytes per SURVEY 8(d) -- 20 B/voxel per advected component + ~60 B per compensate chain, 5
+        # components -- over the phase time give a small fraction of the HBM peak; what binds it is VALU instruction issue
+        # (the reference's double-rounded lerp: 5 instructions each, 63 per sampled field and node) together with the
+        # texture-addresser path of its 36 dwordx2 corner loads per field, both ~80 % busy (committed counter passes).
+        vox = nx * ny * nz_global
+        alg = (5 * 20.0 + 5 * 60.0) * vox
+        t_ms = phase_ms["advect_compensate"]
+        line["phase_ms_per_step"] = phase_ms
+        line["roofline_gather"] = {
+            "bound": "valu-issue + texture-addresser (not hbm)", "phase": "advect_compensate",
+            "launches": "12 nine-point gathers (advect, compensate-error, cumulate; 1- and 2-field) + 5 limiter launches per step",
+            "ms_per_step": t_ms, "algorithmic_bytes_per_step": int(alg),
+            "achieved": round(alg / (t_ms * 1e-3) / 1e9, 1) if t_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t_ms > 0 else None,
+            "counters": {"source": "committed rocprofv3 --pmc passes at 256^3, NOT this run: profiles/r01_n_gather_sq_counters.json "
+                                   "(SQ_INSTS_VALU, SQ_BUSY_CYCLES), profiles/r02_j_gather_ta_tcp_counters.txt (TA_BUSY, TCP_TCC_READ_REQ)",
+                         "valu_issue_busy": {"single_field": [0.92, 1.0], "two_field": [0.81, 0.89]},
+                         "ta_busy": [0.74, 0.80], "l1_to_l2_bytes_over_algorithmic": 3.2,
+                         "issue_floor_cycles_per_node_wave": 3800},
+            "note": "measured in a separate leg of min(steps, 10) steps after the timed region (event pairs per phase)"}
     if rank == 0 and world == 1 and not emul and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -40,6 +40,10 @@ HIP_SIGS = {
     "gpu_conjugate_gradient": (None, [VP] * 8 + [c_i, c_i, c_i, c_i, c_f]),
     "gpu_multi_grid_conjugate_gradient": (None, [VP] * 11 + [c_i, c_i, c_d]),
     # 2. runtime
+    "fl_context_create": (VP, [c_i]),
+    "fl_context_make_current": (None, [VP]),
+    "fl_context_current": (VP, []),
+    "fl_context_destroy": (None, [VP]),
     "fl_init": (c_i, [c_i]),
     "fl_shutdown": (None, []),
     "fl_malloc": (VP, [C.c_size_t]),

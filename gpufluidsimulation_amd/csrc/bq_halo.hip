@@ -42,33 +42,69 @@ struct Rccl {
     int (*GetVersion)(int *) = nullptr;         // optional (reports only)
 };
 
-static Rccl g_rccl;
+static Rccl g_rccl;                          // the dlopen'ed library: one per process
 static void allreduce_span(hipEvent_t a, hipEvent_t b);
-static ncclComm_t g_comm = nullptr;
-static int g_rank = 0, g_nranks = 1;
-// optional host-side transport (fl_comm_set_custom): used instead of RCCL when set
-static fl_exchange_cb g_custom_exchange = nullptr;
-static fl_allreduce_cb g_custom_allreduce = nullptr;
-// Every exchange gets its own (ready, done) event pair from a small ring: an exchange that is still in flight when the
-// next one is issued keeps its events (the ring is far longer than the number of exchanges a step ever overlaps).
+// Everything else is per CONTEXT (bq_host.h: Runtime::halo_state): communicator, rank, transport hooks, the event ring,
+// traffic counters, FL_OPT_PROFILE_COMM spans.  The g_* names below are kept as accessors of the current context's state.
 struct EvPair { hipEvent_t ready = nullptr, done = nullptr; };
 static constexpr int kEvRing = 16;
-static EvPair g_ev[kEvRing];
-static int g_ev_next = 0;
-static hipEvent_t g_ev_pending = nullptr;   // `done` of the newest exchange nobody has waited for yet (fl_halo_wait)
-static bool g_null_transport = false;       // fl_comm_set_null: exchanges and all-reduces are skipped (timing aid)
-static fl_p2p_cb g_custom_p2p = nullptr;
-// traffic counters (fl_comm_stats): exchanges issued, bytes this rank sent in them, wall-sheet message groups, bytes sent in them
-static long long g_stat[4] = { 0, 0, 0, 0 };
-
-// FL_OPT_PROFILE_COMM: every place where the COMPUTE stream waits for the halo stream is bracketed by two timing events
-// on the compute stream.  The first completes when the compute stream has run dry up to the wait, the second when the
-// wait has been satisfied: their distance is communication time that no kernel hid ("exposed").  Summed by
-// fl_comm_profile().  A host-side transport blocks the host instead; that wall time is counted the same way.
 struct WaitSpan { hipEvent_t a, b; };
-static std::vector<WaitSpan> g_wait_spans;
-static double g_wait_host_ms = 0.0;
-static long long g_wait_host_count = 0;
+struct HaloState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    // optional host-side transport (fl_comm_set_custom): used instead of RCCL when set
+    fl_exchange_cb custom_exchange = nullptr;
+    fl_allreduce_cb custom_allreduce = nullptr;
+    fl_p2p_cb custom_p2p = nullptr;
+    // Every exchange gets its own (ready, done) event pair from a small ring: an exchange that is still in flight when the
+    // next one is issued keeps its events (the ring is far longer than the number of exchanges a step ever overlaps).
+    EvPair ev[kEvRing];
+    int ev_next = 0;
+    hipEvent_t ev_pending = nullptr;        // `done` of the newest exchange nobody has waited for yet (fl_halo_wait)
+    bool null_transport = false;            // fl_comm_set_null: exchanges and all-reduces are skipped (timing aid)
+    // traffic counters (fl_comm_stats): exchanges issued, bytes this rank sent in them, wall-sheet message groups, bytes sent in them
+    long long stat[4] = { 0, 0, 0, 0 };
+    // FL_OPT_PROFILE_COMM: every place where the COMPUTE stream waits for the halo stream is bracketed by two timing events
+    // on the compute stream.  The first completes when the compute stream has run dry up to the wait, the second when the
+    // wait has been satisfied: their distance is communication time that no kernel hid ("exposed").  Summed by
+    // fl_comm_profile().  A host-side transport blocks the host instead; that wall time is counted the same way.
+    std::vector<WaitSpan> wait_spans, allreduce_spans;
+    double wait_host_ms = 0.0;
+    long long wait_host_count = 0;
+};
+static HaloState &hs()
+{
+    Runtime &r = rt();
+    if (!r.halo_state) r.halo_state = new HaloState();
+    return *static_cast<HaloState *>(r.halo_state);
+}
+#define g_comm (hs().comm)
+#define g_rank (hs().rank)
+#define g_nranks (hs().nranks)
+#define g_custom_exchange (hs().custom_exchange)
+#define g_custom_allreduce (hs().custom_allreduce)
+#define g_custom_p2p (hs().custom_p2p)
+#define g_ev (hs().ev)
+#define g_ev_next (hs().ev_next)
+#define g_ev_pending (hs().ev_pending)
+#define g_null_transport (hs().null_transport)
+#define g_stat (hs().stat)
+#define g_wait_spans (hs().wait_spans)
+#define g_allreduce_spans (hs().allreduce_spans)
+#define g_wait_host_ms (hs().wait_host_ms)
+#define g_wait_host_count (hs().wait_host_count)
+
+void halo_release_state(Runtime &r)
+{
+    HaloState *h = static_cast<HaloState *>(r.halo_state);
+    if (!h) return;
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (EvPair &e : h->ev) { if (e.ready) (void)hipEventDestroy(e.ready); if (e.done) (void)hipEventDestroy(e.done); }
+    for (std::vector<WaitSpan> *v : { &h->wait_spans, &h->allreduce_spans })
+        for (const WaitSpan &sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    delete h;
+    r.halo_state = nullptr;
+}
 
 static void compute_waits_for(hipEvent_t done)
 {
@@ -82,7 +118,6 @@ static void compute_waits_for(hipEvent_t done)
     g_wait_spans.push_back(sp);
 }
 
-static std::vector<WaitSpan> g_allreduce_spans;
 static void allreduce_span(hipEvent_t a, hipEvent_t b) { g_allreduce_spans.push_back(WaitSpan{a, b}); }
 
 struct HostWaitTimer {                      // wall time of a blocking host-side transport call

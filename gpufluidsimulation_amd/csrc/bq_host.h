@@ -50,6 +50,11 @@ struct Runtime {
     size_t scratch_bytes = 0;
     void  *pinned = nullptr;            // host-pinned mirror for blocking reductions
     size_t pinned_bytes = 0;
+    // state the other translation units keep PER CONTEXT (fl_context_*): the communicator and its event ring (bq_halo.hip),
+    // the sweep-profile spans and plane range (bq_project.hip), the cached V-cycle graphs (bq_mgcg.hip).  Allocated on first
+    // use, released by fl_shutdown through the *_release hooks below.
+    void  *halo_state = nullptr, *project_state = nullptr, *mgcg_state = nullptr;
+    int    nonfinite_seen = 0;          // sticky: a gpu_max_abs3 met a NaN or an Inf (fl_nonfinite_seen)
 };
 
 Runtime &rt();
@@ -60,7 +65,10 @@ void *pinned(size_t bytes);
 // bq_halo.hip: in-stream all-reduce of device values across slab ranks (no-op on one rank)
 bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStream_t st);
 int  comm_ranks();
-void mgcg_release_graph();              // bq_mgcg.hip: drop the cached V-cycle graph (fl_free / fl_shutdown)
+void mgcg_release_graph();              // bq_mgcg.hip: drop the cached V-cycle graphs of the current context (fl_free / fl_shutdown)
+void mgcg_release_state(Runtime &r);    // ... and free the per-context state itself (fl_shutdown)
+void halo_release_state(Runtime &r);    // bq_halo.hip
+void project_release_state(Runtime &r); // bq_project.hip
 // bq_project.hip: FL_OPT_PROFILE_JACOBI spans -- an event pair around a loop of sweep launches on the compute
 // stream, summed by fl_jacobi_profile().  profile_begin returns false when profiling is off.
 struct ProfileSpan { hipEvent_t a = nullptr, b = nullptr; };

@@ -1243,7 +1243,15 @@ struct VCycleGraph {
     SCoarseLevelInfo levels[LEVEL_COUNT];
     int levelnum = 0, fuse = 0, rows = 0, kchunk2 = 0, tile = 0;
 };
-static VCycleGraph g_vcgs[2];                                // [copy_b]
+// the two cached graphs ([copy_b]) of the CURRENT context (bq_host.h: Runtime::mgcg_state)
+struct MgcgState { VCycleGraph vcgs[2]; };
+static MgcgState &ms()
+{
+    Runtime &r = rt();
+    if (!r.mgcg_state) r.mgcg_state = new MgcgState();
+    return *static_cast<MgcgState *>(r.mgcg_state);
+}
+#define g_vcgs (ms().vcgs)
 
 static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
 {
@@ -1286,8 +1294,18 @@ static void v_cycle_replayed(const double *b, double *x, double *residual, const
 
 void mgcg_release_graph()
 {
+    if (!rt().mgcg_state) return;
     for (VCycleGraph &g_vcg : g_vcgs)
         if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
+}
+void mgcg_release_state(Runtime &r)
+{
+    MgcgState *st = static_cast<MgcgState *>(r.mgcg_state);
+    if (!st) return;
+    for (VCycleGraph &g : st->vcgs)
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    delete st;
+    r.mgcg_state = nullptr;
 }
 
 } // namespace bq

@@ -286,7 +286,7 @@ static inline int stream_blocks(size_t n)
 
 using namespace bq;
 
-static int g_nonfinite_seen = 0;    // sticky: a gpu_max_abs3 met a NaN or an Inf in the velocity (fl_nonfinite_seen)
+#define g_nonfinite_seen (rt().nonfinite_seen)    // sticky, per context: a gpu_max_abs3 met a NaN or an Inf (fl_nonfinite_seen)
 
 extern "C" {
 

@@ -685,7 +685,7 @@ __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, f
     return R4{s0, s1};
 }
 
-// PF: how many planes ahead the loads run (1 or 2; 3 and 4 measured no better anywhere, tools/r02_m.sh).  The rings hold 3 + PF planes and the loop is unrolled 3 + PF times.
+// PF: how many planes ahead the loads run (1 or 2; 3 and 4 measured no better anywhere, tools/batches/r02_m.sh).  The rings hold 3 + PF planes and the loop is unrolled 3 + PF times.
 template <bool WIDE, int PF>
 __global__ __launch_bounds__(256) void jacobi_lean2r_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                             float *__restrict__ out, int nx, int ny, int nz,
@@ -1077,7 +1077,31 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
     return true;
 }
 
-static int g_klo = 0, g_khi = 1 << 30;      // plane range of the next sweep launches (gpu_jacobi_sweep_range)
+// per-context state of this file (bq_host.h: Runtime::project_state), behind the names it always had
+struct SweepSpan { hipEvent_t a, b; long long launches, sweeps; };
+struct ProjectState {
+    int klo = 0, khi = 1 << 30;             // plane range of the next sweep launches (gpu_jacobi_sweep_range)
+    const char *last_pair_kernel = "";      // name of the fused sweep kernel launched last (fl_jacobi_kernel_name)
+    std::vector<SweepSpan> spans;           // FL_OPT_PROFILE_JACOBI
+};
+static ProjectState &ps()
+{
+    Runtime &r = rt();
+    if (!r.project_state) r.project_state = new ProjectState();
+    return *static_cast<ProjectState *>(r.project_state);
+}
+#define g_klo (ps().klo)
+#define g_khi (ps().khi)
+#define g_last_pair_kernel (ps().last_pair_kernel)
+#define g_spans (ps().spans)
+void project_release_state(Runtime &r)
+{
+    ProjectState *st = static_cast<ProjectState *>(r.project_state);
+    if (!st) return;
+    for (const SweepSpan &sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    delete st;
+    r.project_state = nullptr;
+}
 
 static inline Slab slab_of(int nk)
 {
@@ -1162,7 +1186,6 @@ static int chunks_for_cus(int nkr, int nrow, int target, int warm, int ncus, int
     return best_n;
 }
 
-static const char *g_last_pair_kernel = "";     // name of the fused sweep kernel launched last (fl_jacobi_kernel_name)
 
 // Two sweeps in one launch (in -> out holds iterate +2) when the fused kernel applies; returns false
 // (nothing launched) otherwise.  The caller guarantees that both buffers carry the same boundary layer.
@@ -1341,8 +1364,6 @@ static void residual_norms_async(const float *div, const float *p, int ni, int n
 
 // hipEvent pairs around the sweep loops of gpu_projection_jacobi (FL_OPT_PROFILE_JACOBI):
 // lets bench.py price the dominant kernel inside the timed region, on the launch stream.
-struct SweepSpan { hipEvent_t a, b; long long launches, sweeps; };
-static std::vector<SweepSpan> g_spans;
 
 bool profile_begin(ProfileSpan &sp)
 {

@@ -4,15 +4,22 @@
 // copies, event timing -- plus the error latch the reference lacks.
 #include "bq_host.h"
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
 namespace bq {
 
-static Runtime g_rt;
+// The library's state lives in contexts (include/bimocq_gpu.h: fl_context_*).  The DEFAULT context is what every call used
+// before contexts existed and what a program that never creates one keeps using; fl_context_make_current switches the calling
+// THREAD to another one (thread-local, like a HIP device): one process can then drive several devices, or several solvers on
+// one device, side by side behind the same C ABI.
+static Runtime g_default_rt;
+static thread_local Runtime *t_current = nullptr;
 static std::mutex g_mu;
 
-Runtime &rt() { return g_rt; }
+Runtime &rt() { return t_current ? *t_current : g_default_rt; }
+#define g_rt (::bq::rt())
 
 void latch(int code, const char *what, const char *detail)
 {
@@ -72,7 +79,6 @@ static bool create_compute_stream()
 
 } // namespace bq
 
-using bq::g_rt;
 
 extern "C" {
 
@@ -112,7 +118,9 @@ void fl_shutdown(void)
     (void)hipStreamSynchronize(g_rt.compute);
     (void)hipStreamSynchronize(g_rt.halo);
     (void)hipStreamSynchronize(g_rt.copy);
-    bq::mgcg_release_graph();
+    bq::mgcg_release_state(g_rt);
+    bq::halo_release_state(g_rt);
+    bq::project_release_state(g_rt);
     if (g_rt.scratch) (void)hipFree(g_rt.scratch);
     if (g_rt.pinned) (void)hipHostFree(g_rt.pinned);
     if (g_rt.map_guard) (void)hipFree(g_rt.map_guard);
@@ -125,6 +133,53 @@ void fl_shutdown(void)
     g_rt.pinned = nullptr; g_rt.pinned_bytes = 0;
     g_rt.compute = nullptr; g_rt.halo = nullptr;
     g_rt.ready = false; g_rt.device = -1;
+}
+
+// ---- contexts -------------------------------------------------------------------------------------------------------
+struct fl_context { bq::Runtime rt; };
+
+fl_context *fl_context_create(int device)
+{
+    fl_context *c = new fl_context();
+    bq::Runtime *prev = bq::t_current;
+    bq::t_current = &c->rt;
+    const int rc = fl_init(device);
+    if (rc != FL_OK) {
+        // report on the caller's context, where it will look
+        char text[256];
+        snprintf(text, sizeof text, "%s", c->rt.err_text);
+        bq::t_current = prev;
+        bq::latch(rc, "fl_context_create", text);
+        delete c;
+        return nullptr;
+    }
+    bq::t_current = prev;
+    return c;
+}
+
+void fl_context_make_current(fl_context *c)
+{
+    bq::t_current = c ? &c->rt : nullptr;
+    bq::Runtime &r = bq::rt();
+    if (r.ready) (void)hipSetDevice(r.device);
+}
+
+fl_context *fl_context_current(void)
+{
+    // (the Runtime is the first member of fl_context)
+    return bq::t_current ? reinterpret_cast<fl_context *>(bq::t_current) : nullptr;
+}
+
+void fl_context_destroy(fl_context *c)
+{
+    if (!c) return;
+    bq::Runtime *prev = bq::t_current == &c->rt ? nullptr : bq::t_current;
+    bq::t_current = &c->rt;
+    fl_comm_destroy();
+    fl_shutdown();
+    bq::t_current = prev;
+    if (prev && prev->ready) (void)hipSetDevice(prev->device);
+    delete c;
 }
 
 void *fl_malloc(size_t bytes)

@@ -9,7 +9,11 @@ using namespace bqhost;
 struct bq_solver {
     std::unique_ptr<gpuMapper> mapper;
     std::unique_ptr<BimocqGPUSolver> solver;
+    fl_context *ctx = nullptr;          // the context that was current when the solver was created (NULL: the default one)
 };
+// every entry point below acts on the solver's own context: several solvers -- on one device or on several -- can be driven
+// from one thread in any order
+#define BQ_ENTER(s) do { if (s) fl_context_make_current((s)->ctx); } while (0)
 
 extern "C" {
 
@@ -33,6 +37,7 @@ bq_solver *bq_solver_create_slab(int device, int nx, int ny, int nz, float L, fl
         sl.own0 = rank * (nz / nranks); sl.own1 = sl.own0 + nz / nranks;
     }
     auto s = std::make_unique<bq_solver>();
+    s->ctx = fl_context_current();
     s->mapper = std::make_unique<gpuMapper>(device, nx, ny, nz, L / nx, sl);   // main.cpp:151 / :37 (h = L/ni)
     if (!s->mapper->ok()) return nullptr;
     s->solver = std::make_unique<BimocqGPUSolver>(nx, ny, nz, L, viscosity, blend, scheme == BQ_SCHEME_MAC_REFLECTION ? MAC_REFLECTION : BIMOCQ, s->mapper.get());
@@ -42,6 +47,7 @@ bq_solver *bq_solver_create_slab(int device, int nx, int ny, int nz, float L, fl
 
 void bq_solver_destroy(bq_solver *s)
 {
+    BQ_ENTER(s);
     if (!s) return;
     fl_sync();
     s->solver.reset();
@@ -84,6 +90,7 @@ void bq_solver_set_projection(bq_solver *s, int kind, int iters, float halfrdx)
 
 void bq_solver_set_option(bq_solver *s, int option, int value)
 {
+    BQ_ENTER(s);
     if (!s) return;
     if (option == BQ_OPT_KEEP_DMC_BORDER) {
         s->solver->VelocityAdvector.keepDmcBorder = value != 0;
@@ -144,28 +151,33 @@ float bq_solver_last_distortion(const bq_solver *s, int which)
 
 void bq_solver_advance(bq_solver *s, int framenum, float dt)
 {
+    BQ_ENTER(s);
     if (s) s->solver->advance(framenum, dt);
 }
 
 long bq_solver_output_result(bq_solver *s, unsigned frame, const char *path)
 {
+    BQ_ENTER(s);
     if (!s) return -1;
     return s->solver->outputResult(frame, path ? std::string(path) : std::string());
 }
 
 int bq_solver_output_result_async(bq_solver *s, unsigned frame, const char *path)
 {
+    BQ_ENTER(s);
     if (!s) return 0;
     return s->solver->outputResultAsync(frame, path ? std::string(path) : std::string()) ? 1 : 0;
 }
 
 long bq_solver_output_wait(bq_solver *s)
 {
+    BQ_ENTER(s);
     return s ? s->solver->waitOutput() : -1;
 }
 
 long bq_solver_download(bq_solver *s, int which, float *host, long capacity)
 {
+    BQ_ENTER(s);
     if (!s) return 0;
     BimocqGPUSolver &b = *s->solver;
     MapSet &m = *b.VelocityAdvector.maps;
@@ -191,6 +203,7 @@ void bq_solver_slab_info(const bq_solver *s, int out[8])
 
 long bq_solver_mg_history(const bq_solver *s, double *host, long capacity)
 {
+    BQ_ENTER(s);
     if (!s || !s->solver->mg.ready) return 0;
     const std::vector<double> h = s->solver->mgHistory();
     if (host)
@@ -200,6 +213,7 @@ long bq_solver_mg_history(const bq_solver *s, double *host, long capacity)
 
 long long bq_solver_phase_ms(bq_solver *s, double ms[BQ_PHASE_COUNT], int reset)
 {
+    BQ_ENTER(s);
     if (!s || !ms) return 0;
     long long steps = 0;
     s->solver->phaseTotals(ms, &steps, reset != 0);

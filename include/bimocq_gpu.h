@@ -225,6 +225,22 @@ enum {
     FL_ERR_COMM = 5             /* RCCL failure                                               */
 };
 
+/* ---- contexts (round 3) ----
+ * All state of this library -- device, the three streams, the option table, the error latch, the z-slab context and plane
+ * window, the communicator, profiles, cached graphs -- belongs to a CONTEXT.  A program that never creates one uses the
+ * default context and notices nothing.  fl_context_create(device) makes another (its own streams on `device`; NULL on
+ * failure, the error latched on the caller's context), fl_context_make_current switches the calling THREAD to it (NULL: back
+ * to the default context; thread-local, like hipSetDevice -- which it also calls), and every fl_* / gpu_* call of that thread
+ * then acts on it.  One process can so drive several devices (SURVEY section 5's "single process, 8 devices": one context
+ * and communicator per device, one thread each or one thread switching) or several solvers on one device side by side.
+ * The host solver's C API (bimocq_solver.h) remembers the context a solver was created under and switches to it in every
+ * call.  Buffers belong to the device, not to a context; a context must be current when its resources are used or freed. */
+typedef struct fl_context fl_context;
+fl_context *fl_context_create(int device);
+void        fl_context_make_current(fl_context *ctx);
+fl_context *fl_context_current(void);
+void        fl_context_destroy(fl_context *ctx);       /* synchronises, destroys its communicator and streams */
+
 /* Select device `device` (findCudaDevice, GPU_Advection.h:214-226), create the compute and
  * halo streams.  Returns FL_OK or an error code (the reference exit()s; we report). */
 int   fl_init(int device);

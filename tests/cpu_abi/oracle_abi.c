@@ -153,6 +153,9 @@ static fl_exchange_cb c_exchange;
 static fl_allreduce_cb c_allreduce;
 
 void fl_report_error(int code, const char *text) { latch(code, text ? text : ""); }
+/* no contexts in the stand-in: the host solver's C API only asks which one is current and switches back to it */
+fl_context *fl_context_current(void) { return NULL; }
+void fl_context_make_current(fl_context *c) { (void)c; }
 int fl_set_plane_window(int k0, int k1)
 {
     if (g_nk_local <= 0) return 0;  /* only meaningful on a slab rank */

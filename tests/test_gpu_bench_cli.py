@@ -37,6 +37,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["frac"] < 1.0 and rf["compulsory_bytes_per_launch"] == 12 * 64 ** 3 and "algorithmic_equiv" in rf
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    # the second kernel family against ITS bounds: phase times of the step and the gather family's object
+    ph, rg = line["phase_ms_per_step"], line["roofline_gather"]
+    assert set(ph) == {"maps", "advect_compensate", "forces", "projection", "accumulate_reinit"} and ph["advect_compensate"] > 0
+    assert rg["frac"] < 0.5 and "NOT this run" in rg["counters"]["source"] and rg["ms_per_step"] == ph["advect_compensate"]
 
 
 def test_multi_rank_bench_launches_itself():

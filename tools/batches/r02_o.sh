@@ -6,4 +6,4 @@ timeout -k 10 900 python -m pytest tests/test_gpu_mgcg.py tests/test_gpu_solver.
 tail -2 $O/tests.log
 timeout -k 10 300 python bench.py --projection mgcg --steps 4 --warmup 2 --no-extra --no-cpu-baseline > $O/mgcg_l2.json 2> $O/mgcg_l2.err || { tail -20 $O/mgcg_l2.err; exit 1; }
 python -c "import json,sys; d=json.loads(open('$O/mgcg_l2.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
-bash tools/r02_n2.sh
+bash tools/batches/r02_n2.sh
