@@ -106,7 +106,21 @@ int fl_init(int device)
     g_rt.device_cus = prop.multiProcessorCount;
     if (!bq::create_compute_stream()) return FL_ERR_HIP;
     if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.halo, hipStreamNonBlocking))) return FL_ERR_HIP;
-    if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.copy, hipStreamNonBlocking))) return FL_ERR_HIP;
+    // The copy stream carries the dump's device -> host download.  The runtime executes a large copy to pinned memory with
+    // a blit KERNEL whose workgroups, stalled on PCIe, occupy every CU they are given: at 1024 x 1024 x 80 planes a 335 MB
+    // download ran 6.1 ms and the compute kernels beside it crawled (the CFL reduction 6.1 ms instead of 0.2;
+    // gpurun_out/r03a).  PCIe needs no more than a few CUs, so the stream is created with a mask of eight -- one per XCD
+    // (KFD deals the mask's bits round-robin over the XCDs, tools/cu_mask_probe.hip) -- and falls back to a plain stream
+    // where the runtime refuses masks.
+    {
+        uint32_t mask[16] = { 0 };
+        mask[0] = 0xffu;
+        const int words = (prop.multiProcessorCount + 31) / 32;
+        if (hipExtStreamCreateWithCUMask(&g_rt.copy, (uint32_t)words, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.copy, hipStreamNonBlocking))) return FL_ERR_HIP;
+        }
+    }
     g_rt.device = device;
     g_rt.ready = true;
     return FL_OK;
