@@ -992,6 +992,156 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
 #undef BQ_SL3
 }
 
+// ---- THREE sweeps per launch, the intermediate levels' neighbour rows exchanged through LDS (round 3) ------------------
+// jacobi_lean3r_kernel is bound by instruction ISSUE: a thread that owns rows j, j+1 evaluates the first sweep on six rows and
+// the second on four to produce the third on two -- 12 evaluations for 6 useful ones -- and its ~400 registers leave one wave
+// per SIMD, where an instruction costs ~5 cycles instead of ~2.5.  Here every wave evaluates each level on ITS OWN two rows
+// only and fetches the two neighbouring rows of the level below from LDS, where the waves that own them have put them:
+//   block = W + 2 waves: W row pairs that produce output + one HALO wave at either end, which evaluates the first two levels
+//           on the two rows outside the block (the block's edge pairs need them) and stores nothing;
+//   per plane step q, per wave: L1(q) on its rows -> LDS A[q & 1]; L2(q-1) on its rows from L1(q-1) (own rows: registers,
+//           rows j-1, j+2: A[(q-1) & 1]) -> LDS B[(q-1) & 1]; L3(q-2) from L2(q-2) (own: registers, neighbours: B[q & 1]) ->
+//           global; ONE barrier.  Each buffer written in step q was last read in step q-1, before that step's barrier.
+// 6 evaluations and 6 float4 loads per plane and wave instead of 12 and 14, ~190 registers: two waves per SIMD.  Every value
+// is jacobi_kernel's expression on the same operands, boundary rows / planes / columns keep their input through all three
+// levels: bit-identical to three single sweeps (and to the other fused kernels).  Rows of one wave, whole arrays; same
+// precondition as the other fused kernels (both buffers carry the same boundary layer).
+// R: rows per wave (2: a wave owns a row pair and has one neighbour row of each level in its own registers; 1: one row per
+// wave, both neighbour rows come from LDS -- twice the waves for the same work, i.e. two working waves per SIMD at 256^3,
+// where 128 row pairs x 8 chunks are exactly one).  H = 2 / R halo waves at either end of a block (two halo ROWS per side:
+// the first level is needed two rows outside the block, the second one).
+template <int W, int R>
+__global__ __launch_bounds__((W + 2 * (2 / R)) * 64) void jacobi_lds3_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                                  float *__restrict__ out, int nx, int ny, int nz,
+                                                                  int nby, int nblk, int kchunk, float alpha, float beta, Slab sl)
+{
+    static_assert(R == 1 || R == 2, "one or two rows per wave");
+    constexpr int H = 2 / R, NW = W + 2 * H, NS = NW * R, P = 4;    // NS LDS row slots; ring period: planes q-1, q, q+1 live, q+2 arriving
+    __shared__ v4f ldsA[2][NS][64], ldsB[2][NS][64];
+    // XCD-contiguous block order: the grid is padded to a multiple of 8 blocks (nblk real ones), XCD x = blockIdx % 8 works
+    // through its own run of consecutive (row block, chunk) pairs -- neighbouring row blocks share their halo rows in one L2
+    const int per = (int)gridDim.x >> 3;
+    const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (b >= nblk) return;                                          // padding (block-uniform, before any barrier)
+    const int by = b % nby, bz = b / nby;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int jb = by * (W * R);                                    // first output row of the block
+    const int j = jb + R * (wv - H);                                // this wave's rows: j .. j + R - 1 (halo waves: outside the block)
+    const bool halo = wv < H || wv >= NW - H;
+    const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;                                       // (block-uniform: no barrier is skipped by part of a block)
+    const int xraw = 4 * lane;
+    const bool xok = xraw < nx;
+    const int x = xok ? xraw : nx - 4;                              // out-of-range lanes, rows, planes: clamped into the array
+    const bool xlo = x == 0, xhi = x + 3 == nx - 1;
+    bool active[R], rowb[R];                                        // rowb: boundary (or outside) rows keep L0
+#pragma unroll
+    for (int a = 0; a < R; a++) {
+        active[a] = xok && !halo && j + a >= 1 && j + a <= ny - 2;
+        rowb[a] = j + a <= 0 || j + a >= ny - 1;
+    }
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 4u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    unsigned vo[R + 2];                                             // byte offsets of this thread's column in rows j-1 .. j+R
+#pragma unroll
+    for (int a = 0; a < R + 2; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 4u;
+    // only blocks that touch the first or last row of the grid (their halo rows included) pay the boundary-row selects
+    const bool edge_block = jb - 2 <= 0 || jb + W * R + 1 >= ny - 1;
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 4u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    // LDS rows: slot R wv + a holds row j + a; the neighbours j - 1 and j + R are the slots below and above (the outermost halo
+    // row has no neighbour on its far side: it reads a clamped slot, and what it computes from that is never used)
+    const int r0 = R * wv, rlo = max(r0 - 1, 0), rhi = min(r0 + R, NS - 1);
+    auto put = [&](v4f (*buf)[64], int a, R4 v) { buf[r0 + a][lane] = v4f{v.a.x, v.a.y, v.b.x, v.b.y}; };
+    auto get = [&](v4f (*buf)[64], int r) -> R4 { const v4f v = buf[r][lane]; return R4{v2f{v.x, v.y}, v2f{v.z, v.w}}; };
+
+    auto run = [&](auto EDGE_T) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
+    R4 L0[P][R + 2], D[P][R], L1[P][R], L2[P][R];
+    const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+#pragma unroll
+    for (int a = 0; a < P; a++)
+#pragma unroll
+        for (int c = 0; c < R; c++) { L1[a][c] = zero; L2[a][c] = zero; D[a][c] = zero; }
+    int q = kbeg - 2;
+#define BQ_SL4(T, d) ((((T) + (d)) % P + P) % P)
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {                                 // prologue: planes q-1, q, q+1 of p; div of plane q
+        const int sl_ = BQ_SL4(0, d);
+        const unsigned pp = po(q + d);
+#pragma unroll
+        for (int a = 0; a < R + 2; a++) L0[sl_][a] = ld_r4(rp, vo[a], pp);
+        if (d == 0) {
+#pragma unroll
+            for (int a = 0; a < R; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
+        }
+    }
+#define BQ_LDS3_PHASE(T)                                                                                            \
+    {                                                                                                               \
+        constexpr int im = BQ_SL4(T, -1), ic = BQ_SL4(T, 0), in_ = BQ_SL4(T, 1), ia = BQ_SL4(T, 2);                   \
+        constexpr int imm = BQ_SL4(T, -2), i3 = BQ_SL4(T, -3);                                                      \
+        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        _Pragma("unroll") for (int a = 0; a < R + 2; a++) L0[ia][a] = ld_r4(rp, vo[a], pa);                           \
+        _Pragma("unroll") for (int a = 0; a < R; a++) D[in_][a] = ld_r4(rd, vo[a + 1], pb);                           \
+        /* first sweep on plane q, own rows */                                                                       \
+        if (q < kA || q >= kB) {                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < R; a++) L1[ic][a] = L0[ic][a + 1];                                  \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int a = 0; a < R; a++) {                                                          \
+                D[ic][a].a = alpha * D[ic][a].a; D[ic][a].b = alpha * D[ic][a].b;                                   \
+                L1[ic][a] = jac_r4<false, true>(L0[ic][a + 1], L0[ic][a], L0[ic][a + 2], L0[im][a + 1], L0[in_][a + 1], D[ic][a], alpha, beta, xlo, xhi); \
+                if (EDGE && rowb[a]) L1[ic][a] = L0[ic][a + 1];                                                     \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int a = 0; a < R; a++) put(ldsA[q & 1], a, L1[ic][a]);                                 \
+        /* second sweep on plane q-1: rows j-1, j+R of L1(q-1) were put into A[(q-1) & 1] before the last barrier */  \
+        {                                                                                                           \
+            const R4 nlo = get(ldsA[(q - 1) & 1], rlo), nhi = get(ldsA[(q - 1) & 1], rhi);                          \
+            if (q - 1 < kA || q - 1 >= kB) {                                                                        \
+                _Pragma("unroll") for (int a = 0; a < R; a++) L2[im][a] = L1[im][a];                                  \
+            } else {                                                                                                \
+                _Pragma("unroll") for (int a = 0; a < R; a++) {                                                      \
+                    const R4 fr = a == 0 ? nlo : L1[im][a == 0 ? 0 : a - 1], bk = a == R - 1 ? nhi : L1[im][a == R - 1 ? a : a + 1]; \
+                    L2[im][a] = jac_r4<false, true>(L1[im][a], fr, bk, L1[imm][a], L1[ic][a], D[im][a], alpha, beta, xlo, xhi); \
+                    if (EDGE && rowb[a]) L2[im][a] = L1[im][a];                                                     \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int a = 0; a < R; a++) put(ldsB[(q - 1) & 1], a, L2[im][a]);                           \
+        /* third sweep on plane q-2: stored */                                                                       \
+        {                                                                                                           \
+            const int k = q - 2;                                                                                    \
+            if (k >= kbeg && k < kend) {                                                                            \
+                const R4 nlo = get(ldsB[q & 1], rlo), nhi = get(ldsB[q & 1], rhi);                                  \
+                const unsigned pk = pstride * (unsigned)k;                                                          \
+                _Pragma("unroll") for (int a = 0; a < R; a++) {                                                      \
+                    const R4 fr = a == 0 ? nlo : L2[imm][a == 0 ? 0 : a - 1], bk = a == R - 1 ? nhi : L2[imm][a == R - 1 ? a : a + 1]; \
+                    const R4 o = jac_r4<false, true>(L2[imm][a], fr, bk, L2[i3][a], L2[im][a], D[imm][a], alpha, beta, xlo, xhi); \
+                    if (active[a]) st_r4(o, ro, vo[a + 1], pk);                                                     \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        __syncthreads();                                                                                            \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        BQ_LDS3_PHASE(0)
+        if (q > kend + 1) break;
+        BQ_LDS3_PHASE(1)
+        if (q > kend + 1) break;
+        BQ_LDS3_PHASE(2)
+        if (q > kend + 1) break;
+        BQ_LDS3_PHASE(3)
+        if (q > kend + 1) break;
+    }
+    };
+    if (edge_block) run(std::true_type{}); else run(std::false_type{});
+#undef BQ_LDS3_PHASE
+#undef BQ_SL4
+}
+
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
 // update_residual_kernel / calc_poisson_value arithmetic (GPU_kernel.cu:1048-1060,1239-1249);
 // the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
@@ -1304,10 +1454,49 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     return true;
 }
 
+// Three sweeps in one launch through jacobi_lds3_kernel (neighbour rows of the intermediate levels via LDS); false = not applicable.
+// FL_OPT_JACOBI_ROWS: 4 forces it wherever it applies, 5 keeps it off (A/B timing); auto: see jacobi_sweep_triple.
+static bool jacobi_sweep_triple_lds(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
+{
+    // block shape: FL_OPT_JACOBI_KCHUNK = 10 R + W selects R rows per wave and W output waves per block for A/B timing
+    // (24 / 25 / 26: row pairs, 4 / 5 / 6 of them; 18 / 19: single rows, 8 / 12 of them); default 18.  256^3, us per sweep
+    // (gpurun_out/r03l, r03m): 18 with chunks of 32 planes 10.79, 24 11.06, 25 11.59, 26 with chunks of 26 11.88, 19 11.23 --
+    // against 13.1-13.6 for jacobi_lean3r_kernel and 15.6 for the two-sweep kernel.  A launch then takes 32.4 us for 201 MB of
+    // compulsory traffic = 6.2 TB/s: like the two-sweep kernel (31.4 us per launch) it sits on the fabric, so what is left is
+    // more sweeps per launch, not a better schedule.
+    int shape = rt().opt_jacobi_kchunk;
+    if (shape != 24 && shape != 25 && shape != 26 && shape != 18 && shape != 19) shape = 18;
+    const int R = shape / 10, W = shape == 19 ? 12 : shape % 10;        // (19: single rows, 12 of them: 16 waves per block)
+    const int rows_per_block = W * R;
+    if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && nj >= rows_per_block && nk >= 12 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
+    if (g_klo != 0 || g_khi < nk) return false;              // plane ranges: the two-sweep kernels
+    const int nby = (nj + rows_per_block - 1) / rows_per_block;
+    // one block per CU (LDS, registers): as many k-chunks as fill the chip once
+    const int ncus = rt().num_cus;
+    int nbz = std::max(1, ncus / nby);
+    int kc = (nk + nbz - 1) / nbz;
+    if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
+    // four warm-up planes per chunk and one block per CU: below ~24 planes per chunk the short-march two-row kernel wins
+    // (128^3: 4.5 us per sweep with chunks of 8 against 3.1); a forced chunk length (tests, tuning) may go down to 8
+    if (kc < (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24)) return false;
+    nbz = (nk + kc - 1) / kc;
+    const int nblk = nby * nbz, grid = 8 * ((nblk + 7) / 8);
+    hipStream_t st = rt().compute;
+#define BQ_LDS3(WV, RV) jacobi_lds3_kernel<WV, RV><<<grid, (WV + 2 * (2 / RV)) * 64, 0, st>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk))
+    if (shape == 24) BQ_LDS3(4, 2); else if (shape == 25) BQ_LDS3(5, 2); else if (shape == 26) BQ_LDS3(6, 2);
+    else if (shape == 19) BQ_LDS3(12, 1); else BQ_LDS3(8, 1);
+#undef BQ_LDS3
+    BQ_LAUNCH_CHECK("jacobi_lds3_kernel");
+    g_last_pair_kernel = "jacobi_lds3_kernel";
+    return true;
+}
+
 // Three sweeps in one launch (in -> out holds iterate +3), whole array, rows of one wave; false = not applicable
 static bool jacobi_sweep_triple(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
 {
     if (ni < 3 || nj < 4 || nk < 3) return false;
+    if ((rt().opt_jacobi_rows == 4 || rt().opt_jacobi_rows == 0) && (rt().opt_jacobi_variant == 0 || rt().opt_jacobi_variant == 3) &&
+        jacobi_sweep_triple_lds(in, div, out, ni, nj, nk, alpha, beta)) return true;
     const int variant = rt().opt_jacobi_variant;
     if ((variant != 0 && variant != 3) || rt().opt_jacobi_rows == 1 || rt().opt_jacobi_rows == 3) return false;
     if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && aligned16(in) && aligned16(div) && aligned16(out))) return false;

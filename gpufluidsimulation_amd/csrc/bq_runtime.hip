@@ -5,6 +5,7 @@
 #include "bq_host.h"
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -113,10 +114,15 @@ int fl_init(int device)
     // (KFD deals the mask's bits round-robin over the XCDs, tools/cu_mask_probe.hip) -- and falls back to a plain stream
     // where the runtime refuses masks.
     {
+        // BQ_COPY_STREAM_CUS = n (environment; default 8, 0 = a plain stream): how many CUs the copy stream may use
+        const char *env = getenv("BQ_COPY_STREAM_CUS");
+        int ncopy = env && *env ? atoi(env) : 8;
+        if (ncopy < 0) ncopy = 0;
+        if (ncopy > 32) ncopy = 32;
         uint32_t mask[16] = { 0 };
-        mask[0] = 0xffu;
+        mask[0] = ncopy >= 32 ? 0xffffffffu : ((1u << ncopy) - 1u);
         const int words = (prop.multiProcessorCount + 31) / 32;
-        if (hipExtStreamCreateWithCUMask(&g_rt.copy, (uint32_t)words, mask) != hipSuccess) {
+        if (ncopy == 0 || hipExtStreamCreateWithCUMask(&g_rt.copy, (uint32_t)words, mask) != hipSuccess) {
             (void)hipGetLastError();
             if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.copy, hipStreamNonBlocking))) return FL_ERR_HIP;
         }

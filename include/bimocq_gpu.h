@@ -282,7 +282,9 @@ enum {
     FL_OPT_PROFILE_JACOBI  = 4, /* record a hipEvent pair around each projection's sweep loop      */
     FL_OPT_JACOBI_KCHUNK   = 5, /* planes marched per block in the tiled kernel (0 = auto); for the fused kernels (which take
                                    their chunk length from FL_OPT_JACOBI_KCHUNK2): 1 / 2 = loads run one / two planes ahead */
-    FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread: tiled kernel 1, 2, 4; fused kernel 1, 2 (0 = auto) */
+    FL_OPT_JACOBI_ROWS     = 6, /* float4 rows per thread: tiled kernel 1, 2, 4; fused kernels 1, 2 (0 = auto); 4 = the three-sweep kernel
+                                   that exchanges the intermediate levels' neighbour rows through LDS wherever it applies (auto: whole
+                                   arrays with chunks of >= 24 planes), 5 = never that kernel (A/B timing) */
     FL_OPT_STRUCTURED_MAPS = 7, /* 9-point kernels: compile-time taps when h is a power of two (1)  */
     FL_OPT_JACOBI_FUSE     = 8, /* two or three sweeps per launch (4: at most two): 0 never, 1 in gpu_projection_jacobi after it has checked that p and
                                    p_temp carry the same boundary shell (default), 2 there without the check and also in

@@ -291,6 +291,43 @@ def test_fused_pair_on_plane_ranges(hip, ni, nj, nk, rows):
     bq.check()
 
 
+@pytest.mark.parametrize("ni,nj,nk,kc", [(64, 48, 40, 10), (256, 32, 30, 8), (128, 37, 19, 8), (32, 12, 12, 12), (36, 25, 50, 9),
+                                        (256, 100, 64, 16), (200, 13, 33, 16), (256, 256, 40, 10)])
+@pytest.mark.parametrize("sweeps", [3, 7])
+@pytest.mark.parametrize("shape", [24, 26, 18, 19])
+def test_fused_three_sweep_lds_kernel(hip, ni, nj, nk, kc, sweeps, shape):
+    """jacobi_lds3_kernel (round 3): three sweeps per launch, every wave evaluates each level on its own two rows and takes
+    the neighbouring rows of the level below from LDS (blocks of 6 row pairs + a halo wave at either end, one barrier per
+    plane; shape = 10 R + W: R rows per wave, W output waves per block -- 24 / 26: row pairs, 18 / 19: single rows, 8 / 12 of
+    them with two halo waves per side).  Against single oracle sweeps: row counts that leave the last block partly or wholly outside the grid, rows
+    shorter than a wave, chunks whose warm-up planes reach below plane 0, an odd remainder swept by the other kernels."""
+    import gpufluidsimulation_amd as bq
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    a, b = p0.copy(), p0.copy()
+    for _ in range(sweeps):
+        oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+        a, b = b, a
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 4)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, kc)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, shape)
+    if nj < (12 if shape in (26, 19) else 8):
+        pytest.skip("fewer rows than one block of this shape")
+    dp, dd, dt = dev(p0, div, p0)
+    where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 3, ALPHA, BETA)      # one triple: names the kernel
+    name = hip.fl_jacobi_kernel_name().decode()
+    where2 = hip.gpu_jacobi_sweeps((dt if where else dp).ptr, dd.ptr, (dp if where else dt).ptr, ni, nj, nk, sweeps - 3, ALPHA, BETA)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0)
+    assert name == "jacobi_lds3_kernel", name
+    newest = (dt if where else dp) if not where2 else (dp if where else dt)
+    assert F.same(a, newest.numpy()), (ni, nj, nk, sweeps)
+    bq.check()
+
+
 def test_fused_pair_ranges_reports_when_it_does_not_apply(hip):
     """rows that are not a multiple of 4 floats cannot take the fused kernel: 0 is returned and nothing is written"""
     import gpufluidsimulation_amd as bq
