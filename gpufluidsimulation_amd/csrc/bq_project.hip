@@ -1007,17 +1007,19 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
 // levels: bit-identical to three single sweeps (and to the other fused kernels).  Rows of one wave, whole arrays; same
 // precondition as the other fused kernels (both buffers carry the same boundary layer).
 // R: rows per wave (2: a wave owns a row pair and has one neighbour row of each level in its own registers; 1: one row per
-// wave, both neighbour rows come from LDS -- twice the waves for the same work, i.e. two working waves per SIMD at 256^3,
-// where 128 row pairs x 8 chunks are exactly one).  H = 2 / R halo waves at either end of a block (two halo ROWS per side:
-// the first level is needed two rows outside the block, the second one).
-template <int W, int R>
-__global__ __launch_bounds__((W + 2 * (2 / R)) * 64) void jacobi_lds3_kernel(const float *__restrict__ p, const float *__restrict__ div,
+// wave, both neighbour rows come from LDS -- twice the waves for the same work).  S: sweeps per launch (3 or 4): level s is
+// needed S - s rows outside the block, so a block carries H = ceil((S - 1) / R) halo waves at either end; a chunk marches
+// 2 (S - 1) warm-up planes.  All rings have period 4 (planes q-1, q, q+1 of the input live, q+2 arriving; three planes of every
+// intermediate level; div of the S planes the levels are working on -- with S = 4 the slot of the oldest one is refilled at
+// the END of the step, after the last level has used it).
+template <int W, int R, int S>
+__global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_lds_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                   float *__restrict__ out, int nx, int ny, int nz,
                                                                   int nby, int nblk, int kchunk, float alpha, float beta, Slab sl)
 {
-    static_assert(R == 1 || R == 2, "one or two rows per wave");
-    constexpr int H = 2 / R, NW = W + 2 * H, NS = NW * R, P = 4;    // NS LDS row slots; ring period: planes q-1, q, q+1 live, q+2 arriving
-    __shared__ v4f ldsA[2][NS][64], ldsB[2][NS][64];
+    static_assert((R == 1 || R == 2) && (S == 3 || S == 4), "one or two rows per wave, three or four sweeps per launch");
+    constexpr int H = (S - 1 + R - 1) / R, NW = W + 2 * H, NS = NW * R, P = 4;
+    __shared__ v4f lds[S - 1][2][NS][64];                           // [level - 1][plane parity][row slot][lane]
     // XCD-contiguous block order: the grid is padded to a multiple of 8 blocks (nblk real ones), XCD x = blockIdx % 8 works
     // through its own run of consecutive (row block, chunk) pairs -- neighbouring row blocks share their halo rows in one L2
     const int per = (int)gridDim.x >> 3;
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__((W + 2 * (2 / R)) * 64) void jacobi_lds3_kernel(con
 #pragma unroll
     for (int a = 0; a < R + 2; a++) vo[a] = ((unsigned)x + (unsigned)nx * (unsigned)min(max(j - 1 + a, 0), ny - 1)) * 4u;
     // only blocks that touch the first or last row of the grid (their halo rows included) pay the boundary-row selects
-    const bool edge_block = jb - 2 <= 0 || jb + W * R + 1 >= ny - 1;
+    const bool edge_block = jb - H * R <= 0 || jb + W * R + H * R - 1 >= ny - 1;
     const unsigned pstride = (unsigned)nx * (unsigned)ny * 4u;
     auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
     // LDS rows: slot R wv + a holds row j + a; the neighbours j - 1 and j + R are the slots below and above (the outermost halo
@@ -1059,13 +1061,17 @@ __global__ __launch_bounds__((W + 2 * (2 / R)) * 64) void jacobi_lds3_kernel(con
 
     auto run = [&](auto EDGE_T) {
     constexpr bool EDGE = decltype(EDGE_T)::value;
-    R4 L0[P][R + 2], D[P][R], L1[P][R], L2[P][R];
+    R4 L0[P][R + 2], D[P][R], Lv[S][P][R];                          // Lv[s]: level s (1 .. S-1) on the wave's own rows
     const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
     for (int a = 0; a < P; a++)
 #pragma unroll
-        for (int c = 0; c < R; c++) { L1[a][c] = zero; L2[a][c] = zero; D[a][c] = zero; }
-    int q = kbeg - 2;
+        for (int c = 0; c < R; c++) {
+            D[a][c] = zero;
+#pragma unroll
+            for (int l = 0; l < S; l++) Lv[l][a][c] = zero;
+        }
+    int q = kbeg - (S - 1);
 #define BQ_SL4(T, d) ((((T) + (d)) % P + P) % P)
 #pragma unroll
     for (int d = -1; d <= 1; d++) {                                 // prologue: planes q-1, q, q+1 of p; div of plane q
@@ -1078,67 +1084,62 @@ __global__ __launch_bounds__((W + 2 * (2 / R)) * 64) void jacobi_lds3_kernel(con
             for (int a = 0; a < R; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
         }
     }
-#define BQ_LDS3_PHASE(T)                                                                                            \
+#define BQ_LDS_PHASE(T)                                                                                             \
     {                                                                                                               \
         constexpr int im = BQ_SL4(T, -1), ic = BQ_SL4(T, 0), in_ = BQ_SL4(T, 1), ia = BQ_SL4(T, 2);                   \
-        constexpr int imm = BQ_SL4(T, -2), i3 = BQ_SL4(T, -3);                                                      \
         const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
         _Pragma("unroll") for (int a = 0; a < R + 2; a++) L0[ia][a] = ld_r4(rp, vo[a], pa);                           \
-        _Pragma("unroll") for (int a = 0; a < R; a++) D[in_][a] = ld_r4(rd, vo[a + 1], pb);                           \
+        if (S == 3) { _Pragma("unroll") for (int a = 0; a < R; a++) D[in_][a] = ld_r4(rd, vo[a + 1], pb); }           \
+        /* the neighbour rows every later level of this step needs were put into LDS before the last barrier: fetch them   \
+           all now, ahead of the first level's arithmetic (the compiler cannot hoist them over this step's own puts) */     \
+        R4 nlo[S + 1], nhi[S + 1];                                                                                  \
+        _Pragma("unroll") for (int s = 2; s <= S; s++) {                                                             \
+            nlo[s] = get(lds[s - 2][(q - (s - 1)) & 1], rlo); nhi[s] = get(lds[s - 2][(q - (s - 1)) & 1], rhi);     \
+        }                                                                                                           \
         /* first sweep on plane q, own rows */                                                                       \
         if (q < kA || q >= kB) {                                                                                    \
-            _Pragma("unroll") for (int a = 0; a < R; a++) L1[ic][a] = L0[ic][a + 1];                                  \
+            _Pragma("unroll") for (int a = 0; a < R; a++) Lv[1][ic][a] = L0[ic][a + 1];                               \
         } else {                                                                                                    \
             _Pragma("unroll") for (int a = 0; a < R; a++) {                                                          \
                 D[ic][a].a = alpha * D[ic][a].a; D[ic][a].b = alpha * D[ic][a].b;                                   \
-                L1[ic][a] = jac_r4<false, true>(L0[ic][a + 1], L0[ic][a], L0[ic][a + 2], L0[im][a + 1], L0[in_][a + 1], D[ic][a], alpha, beta, xlo, xhi); \
-                if (EDGE && rowb[a]) L1[ic][a] = L0[ic][a + 1];                                                     \
+                Lv[1][ic][a] = jac_r4<false, true>(L0[ic][a + 1], L0[ic][a], L0[ic][a + 2], L0[im][a + 1], L0[in_][a + 1], D[ic][a], alpha, beta, xlo, xhi); \
+                if (EDGE && rowb[a]) Lv[1][ic][a] = L0[ic][a + 1];                                                  \
             }                                                                                                       \
         }                                                                                                           \
-        _Pragma("unroll") for (int a = 0; a < R; a++) put(ldsA[q & 1], a, L1[ic][a]);                                 \
-        /* second sweep on plane q-1: rows j-1, j+R of L1(q-1) were put into A[(q-1) & 1] before the last barrier */  \
-        {                                                                                                           \
-            const R4 nlo = get(ldsA[(q - 1) & 1], rlo), nhi = get(ldsA[(q - 1) & 1], rhi);                          \
-            if (q - 1 < kA || q - 1 >= kB) {                                                                        \
-                _Pragma("unroll") for (int a = 0; a < R; a++) L2[im][a] = L1[im][a];                                  \
-            } else {                                                                                                \
+        _Pragma("unroll") for (int a = 0; a < R; a++) put(lds[0][q & 1], a, Lv[1][ic][a]);                            \
+        /* sweep s on plane q - (s - 1): rows j-1, j+R of level s-1 on that plane were put into LDS before the last barrier */ \
+        _Pragma("unroll") for (int s = 2; s <= S; s++) {                                                             \
+            const int ps = q - (s - 1);                                                                             \
+            const int cs = BQ_SL4(T, -(s - 1)), us = BQ_SL4(T, -(s - 2)), ds = BQ_SL4(T, -s);                       \
+            if (s < S || (ps >= kbeg && ps < kend)) {   /* (a step without these two wave-uniform branches measured slower) */ \
+                const bool keep = ps < kA || ps >= kB;                                                              \
                 _Pragma("unroll") for (int a = 0; a < R; a++) {                                                      \
-                    const R4 fr = a == 0 ? nlo : L1[im][a == 0 ? 0 : a - 1], bk = a == R - 1 ? nhi : L1[im][a == R - 1 ? a : a + 1]; \
-                    L2[im][a] = jac_r4<false, true>(L1[im][a], fr, bk, L1[imm][a], L1[ic][a], D[im][a], alpha, beta, xlo, xhi); \
-                    if (EDGE && rowb[a]) L2[im][a] = L1[im][a];                                                     \
+                    const R4 ce = Lv[s - 1][cs][a];                                                                 \
+                    const R4 fr = a == 0 ? nlo[s] : Lv[s - 1][cs][a == 0 ? 0 : a - 1], bk = a == R - 1 ? nhi[s] : Lv[s - 1][cs][a == R - 1 ? a : a + 1]; \
+                    R4 v = jac_r4<false, true>(ce, fr, bk, Lv[s - 1][ds][a], Lv[s - 1][us][a], D[cs][a], alpha, beta, xlo, xhi); \
+                    if (keep || (EDGE && rowb[a])) v = ce;                                                          \
+                    if (s < S) { Lv[s][cs][a] = v; put(lds[s - 1][ps & 1], a, v); }                                 \
+                    else if (active[a]) st_r4(v, ro, vo[a + 1], pstride * (unsigned)ps);                            \
                 }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
-        _Pragma("unroll") for (int a = 0; a < R; a++) put(ldsB[(q - 1) & 1], a, L2[im][a]);                           \
-        /* third sweep on plane q-2: stored */                                                                       \
-        {                                                                                                           \
-            const int k = q - 2;                                                                                    \
-            if (k >= kbeg && k < kend) {                                                                            \
-                const R4 nlo = get(ldsB[q & 1], rlo), nhi = get(ldsB[q & 1], rhi);                                  \
-                const unsigned pk = pstride * (unsigned)k;                                                          \
-                _Pragma("unroll") for (int a = 0; a < R; a++) {                                                      \
-                    const R4 fr = a == 0 ? nlo : L2[imm][a == 0 ? 0 : a - 1], bk = a == R - 1 ? nhi : L2[imm][a == R - 1 ? a : a + 1]; \
-                    const R4 o = jac_r4<false, true>(L2[imm][a], fr, bk, L2[i3][a], L2[im][a], D[imm][a], alpha, beta, xlo, xhi); \
-                    if (active[a]) st_r4(o, ro, vo[a + 1], pk);                                                     \
-                }                                                                                                   \
-            }                                                                                                       \
-        }                                                                                                           \
+        if (S == 4) { _Pragma("unroll") for (int a = 0; a < R; a++) D[in_][a] = ld_r4(rd, vo[a + 1], pb); }           \
         __syncthreads();                                                                                            \
         q++;                                                                                                        \
     }
     while (true) {
-        BQ_LDS3_PHASE(0)
-        if (q > kend + 1) break;
-        BQ_LDS3_PHASE(1)
-        if (q > kend + 1) break;
-        BQ_LDS3_PHASE(2)
-        if (q > kend + 1) break;
-        BQ_LDS3_PHASE(3)
-        if (q > kend + 1) break;
+        BQ_LDS_PHASE(0)
+        if (q > kend + S - 2) break;
+        BQ_LDS_PHASE(1)
+        if (q > kend + S - 2) break;
+        BQ_LDS_PHASE(2)
+        if (q > kend + S - 2) break;
+        BQ_LDS_PHASE(3)
+        if (q > kend + S - 2) break;
     }
     };
     if (edge_block) run(std::true_type{}); else run(std::false_type{});
-#undef BQ_LDS3_PHASE
+#undef BQ_LDS_PHASE
 #undef BQ_SL4
 }
 
@@ -1454,19 +1455,20 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
     return true;
 }
 
-// Three sweeps in one launch through jacobi_lds3_kernel (neighbour rows of the intermediate levels via LDS); false = not applicable.
+// Three or four sweeps in one launch through jacobi_lds_kernel (neighbour rows of the intermediate levels via LDS); false = not applicable.
 // FL_OPT_JACOBI_ROWS: 4 forces it wherever it applies, 5 keeps it off (A/B timing); auto: see jacobi_sweep_triple.
-static bool jacobi_sweep_triple_lds(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
+static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta, int S)
 {
     // block shape: FL_OPT_JACOBI_KCHUNK = 10 R + W selects R rows per wave and W output waves per block for A/B timing
-    // (24 / 25 / 26: row pairs, 4 / 5 / 6 of them; 18 / 19: single rows, 8 / 12 of them); default 18.  256^3, us per sweep
-    // (gpurun_out/r03l, r03m): 18 with chunks of 32 planes 10.79, 24 11.06, 25 11.59, 26 with chunks of 26 11.88, 19 11.23 --
-    // against 13.1-13.6 for jacobi_lean3r_kernel and 15.6 for the two-sweep kernel.  A launch then takes 32.4 us for 201 MB of
-    // compulsory traffic = 6.2 TB/s: like the two-sweep kernel (31.4 us per launch) it sits on the fabric, so what is left is
-    // more sweeps per launch, not a better schedule.
+    // (24 / 25 / 26: row pairs, 4 / 5 / 6 of them; 18 / 19: single rows, 8 / 12 of them); default 18 for three sweeps, 24 for four.
+    // 256^3, three sweeps, us per sweep (gpurun_out/r03l, r03m): 18 with chunks of 32 planes 10.79, 24 11.06, 25 11.59, 26 with
+    // chunks of 26 11.88, 19 11.23 -- against 13.1-13.6 for jacobi_lean3r_kernel and 15.6 for the two-sweep kernel.  A launch
+    // then takes 32.4 us for 201 MB of compulsory traffic = 6.2 TB/s: like the two-sweep kernel (31.4 us per launch) it sits on
+    // the fabric, so what is left is more sweeps per launch, not a better schedule -- hence S = 4.
     int shape = rt().opt_jacobi_kchunk;
-    if (shape != 24 && shape != 25 && shape != 26 && shape != 18 && shape != 19) shape = 18;
-    const int R = shape / 10, W = shape == 19 ? 12 : shape % 10;        // (19: single rows, 12 of them: 16 waves per block)
+    if (shape != 24 && shape != 25 && shape != 26 && shape != 18 && shape != 19) shape = S == 4 ? 24 : 18;
+    if (S == 4 && shape != 24 && shape != 18) shape = 24;        // (row pairs, 6 of them: 10 waves at 168 registers spill)
+    const int R = shape / 10, W = shape == 19 ? 12 : (S == 4 && shape == 18 ? 6 : shape % 10);        // (19: single rows, 12 of them: 16 waves per block)
     const int rows_per_block = W * R;
     if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && nj >= rows_per_block && nk >= 12 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
     if (g_klo != 0 || g_khi < nk) return false;              // plane ranges: the two-sweep kernels
@@ -1476,27 +1478,38 @@ static bool jacobi_sweep_triple_lds(const float *in, const float *div, float *ou
     int nbz = std::max(1, ncus / nby);
     int kc = (nk + nbz - 1) / nbz;
     if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
-    // four warm-up planes per chunk and one block per CU: below ~24 planes per chunk the short-march two-row kernel wins
+    // 2 (S - 1) warm-up planes per chunk and one block per CU: below ~24 planes per chunk the short-march two-row kernel wins
     // (128^3: 4.5 us per sweep with chunks of 8 against 3.1); a forced chunk length (tests, tuning) may go down to 8
     if (kc < (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24)) return false;
     nbz = (nk + kc - 1) / kc;
     const int nblk = nby * nbz, grid = 8 * ((nblk + 7) / 8);
     hipStream_t st = rt().compute;
-#define BQ_LDS3(WV, RV) jacobi_lds3_kernel<WV, RV><<<grid, (WV + 2 * (2 / RV)) * 64, 0, st>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk))
-    if (shape == 24) BQ_LDS3(4, 2); else if (shape == 25) BQ_LDS3(5, 2); else if (shape == 26) BQ_LDS3(6, 2);
-    else if (shape == 19) BQ_LDS3(12, 1); else BQ_LDS3(8, 1);
-#undef BQ_LDS3
-    BQ_LAUNCH_CHECK("jacobi_lds3_kernel");
-    g_last_pair_kernel = "jacobi_lds3_kernel";
+#define BQ_LDS(WV, RV, SV) jacobi_lds_kernel<WV, RV, SV><<<grid, (WV + 2 * ((SV - 1 + RV - 1) / RV)) * 64, 0, st>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk))
+    if (S == 4) {
+        if (shape == 24) BQ_LDS(4, 2, 4); else BQ_LDS(6, 1, 4);      // (18 with four sweeps: 6 single rows + 6 halo waves)
+    } else {
+        if (shape == 24) BQ_LDS(4, 2, 3); else if (shape == 25) BQ_LDS(5, 2, 3); else if (shape == 26) BQ_LDS(6, 2, 3);
+        else if (shape == 19) BQ_LDS(12, 1, 3); else BQ_LDS(8, 1, 3);
+    }
+#undef BQ_LDS
+    BQ_LAUNCH_CHECK("jacobi_lds_kernel");
+    g_last_pair_kernel = S == 4 ? "jacobi_lds_kernel<4 sweeps>" : "jacobi_lds3_kernel";
     return true;
+}
+
+// Four sweeps in one launch (jacobi_lds_kernel<.., 4>): on request only for now (FL_OPT_JACOBI_ROWS = 6)
+static bool jacobi_sweep_quad(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
+{
+    if (rt().opt_jacobi_rows != 6 || (rt().opt_jacobi_variant != 0 && rt().opt_jacobi_variant != 3)) return false;
+    return jacobi_sweep_lds(in, div, out, ni, nj, nk, alpha, beta, 4);
 }
 
 // Three sweeps in one launch (in -> out holds iterate +3), whole array, rows of one wave; false = not applicable
 static bool jacobi_sweep_triple(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta)
 {
     if (ni < 3 || nj < 4 || nk < 3) return false;
-    if ((rt().opt_jacobi_rows == 4 || rt().opt_jacobi_rows == 0) && (rt().opt_jacobi_variant == 0 || rt().opt_jacobi_variant == 3) &&
-        jacobi_sweep_triple_lds(in, div, out, ni, nj, nk, alpha, beta)) return true;
+    if ((rt().opt_jacobi_rows == 4 || rt().opt_jacobi_rows == 6 || rt().opt_jacobi_rows == 0) && (rt().opt_jacobi_variant == 0 || rt().opt_jacobi_variant == 3) &&
+        jacobi_sweep_lds(in, div, out, ni, nj, nk, alpha, beta, 3)) return true;
     const int variant = rt().opt_jacobi_variant;
     if ((variant != 0 && variant != 3) || rt().opt_jacobi_rows == 1 || rt().opt_jacobi_rows == 3) return false;
     if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
@@ -1601,6 +1614,11 @@ int gpu_jacobi_sweeps(float *p, const float *div, float *p_temp, int ni, int nj,
     const bool prof = sweeps > 0 && profile_begin(span);      // FL_OPT_PROFILE_JACOBI (the z-slab projection runs through here)
     // FL_OPT_JACOBI_FUSE == 2: the caller vouches that p and p_temp carry the same boundary layer
     // (FL_OPT_JACOBI_FUSE: 2 = pairs and triples, 4 = pairs only)
+    // FL_OPT_JACOBI_ROWS = 6: four sweeps per launch where jacobi_lds_kernel applies (rows 0: auto, see jacobi_sweep_quad)
+    while (rt().opt_jacobi_fuse >= 2 && rt().opt_jacobi_fuse != 4 && s + 4 <= sweeps && jacobi_sweep_quad(in, div, out, ni, nj, nk, alpha, beta)) {
+        s += 4; launches++;                        // iterate +4 sits in `out`: swap
+        float *t = in; in = out; out = t;
+    }
     while (rt().opt_jacobi_fuse >= 2 && rt().opt_jacobi_fuse != 4 && s + 3 <= sweeps && jacobi_sweep_triple(in, div, out, ni, nj, nk, alpha, beta)) {
         float *t = in; in = out; out = t;          // iterate +3 sits in the former `out`
         s += 3; launches++;

@@ -328,6 +328,39 @@ def test_fused_three_sweep_lds_kernel(hip, ni, nj, nk, kc, sweeps, shape):
     bq.check()
 
 
+@pytest.mark.parametrize("ni,nj,nk,kc", [(64, 48, 40, 10), (256, 32, 30, 8), (128, 37, 19, 8), (32, 12, 12, 12), (36, 25, 50, 9),
+                                        (256, 100, 64, 16), (200, 13, 33, 16), (256, 256, 40, 10)])
+@pytest.mark.parametrize("sweeps", [4, 9])
+@pytest.mark.parametrize("shape", [24, 18])
+def test_fused_four_sweep_lds_kernel(hip, ni, nj, nk, kc, sweeps, shape):
+    """jacobi_lds_kernel<W, R, 4>: FOUR sweeps per launch (FL_OPT_JACOBI_ROWS = 6) -- three intermediate levels exchanged
+    through LDS, three halo rows per block side (two halo waves of row pairs, or three of single rows), six warm-up planes per
+    chunk; a remainder of 1-3 sweeps goes to the other kernels.  Against single oracle sweeps."""
+    import gpufluidsimulation_amd as bq
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    a, b = p0.copy(), p0.copy()
+    for _ in range(sweeps):
+        oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+        a, b = b, a
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 6)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, kc)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, shape)
+    dp, dd, dt = dev(p0, div, p0)
+    where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 4, ALPHA, BETA)      # one quad: names the kernel
+    name = hip.fl_jacobi_kernel_name().decode()
+    where2 = hip.gpu_jacobi_sweeps((dt if where else dp).ptr, dd.ptr, (dp if where else dt).ptr, ni, nj, nk, sweeps - 4, ALPHA, BETA)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK, 0)
+    assert name == "jacobi_lds_kernel<4 sweeps>", name
+    newest = (dt if where else dp) if not where2 else (dp if where else dt)
+    assert F.same(a, newest.numpy()), (ni, nj, nk, sweeps)
+    bq.check()
+
+
 def test_fused_pair_ranges_reports_when_it_does_not_apply(hip):
     """rows that are not a multiple of 4 floats cannot take the fused kernel: 0 is returned and nothing is written"""
     import gpufluidsimulation_amd as bq
