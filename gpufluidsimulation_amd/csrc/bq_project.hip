@@ -659,10 +659,43 @@ __device__ __forceinline__ void st_r4(R4 v, v4i rs, unsigned voff, unsigned soff
 // value, supplied by that lane itself (edgeL / edgeR mark the two lanes)
 // PRE: dv already holds alpha * div (the product is formed once per loaded div value and reused by every level that needs
 // it -- the same float either way)
-template <bool WIDE = false, bool PRE = false>
+// own + (value of `from` in lane - 1) / (lane + 1), the neighbour taken through the add's own DPP operand: one instruction
+// where a DPP move, a move to pair the operands and a packed add stood.  A lane without a source lane (0 / 63) reads 0
+// (bound_ctrl): those are x-boundary or out-of-range columns, whose result is replaced or never stored.  The s_nop covers the
+// two wait states a DPP read needs after a VALU write of its source, which the compiler cannot see inside the asm.
+__device__ __forceinline__ float add_from_left_lane(float from, float own)
+{
+    float r;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(from), "v"(own));
+    return r;
+}
+__device__ __forceinline__ float add_from_right_lane(float from, float own)
+{
+    float r;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(from), "v"(own));
+    return r;
+}
+
+// DPPADD (rows of one wave only): the l + r stage as four scalar adds, the two outer ones with a DPP operand
+template <bool WIDE = false, bool PRE = false, bool DPPADD = false>
 __device__ __forceinline__ R4 jac_r4(R4 ce, R4 fr, R4 bk, R4 dn, R4 up, R4 dv, float alpha, float beta, bool xlo, bool xhi,
                                      float outside = 0.f, bool edgeL = false, bool edgeR = false)
 {
+    if (DPPADD && !WIDE) {
+        // (l + r) per cell: cell 0 = left + x1, 1 = x0 + x2, 2 = x1 + x3, 3 = x2 + right -- the same sums as below
+        v2f s0 = v2f{add_from_left_lane(ce.b.y, ce.a.y), ce.a.x + ce.b.x};
+        v2f s1 = v2f{ce.a.y + ce.b.y, add_from_right_lane(ce.a.x, ce.b.x)};
+        s0 = s0 + fr.a; s1 = s1 + fr.b;
+        s0 = s0 + bk.a; s1 = s1 + bk.b;
+        s0 = s0 + dn.a; s1 = s1 + dn.b;
+        s0 = s0 + up.a; s1 = s1 + up.b;
+        if (PRE) { s0 = s0 + dv.a; s1 = s1 + dv.b; }
+        else     { s0 = s0 + alpha * dv.a; s1 = s1 + alpha * dv.b; }
+        s0 = s0 * beta; s1 = s1 * beta;
+        if (xlo) s0.x = ce.a.x;
+        if (xhi) s1.y = ce.b.y;
+        return R4{s0, s1};
+    }
     float left = lane_up(ce.b.y), right = lane_down(ce.a.x);
     if (WIDE) {
         if (edgeL) left = outside;
@@ -1102,7 +1135,7 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
         } else {                                                                                                    \
             _Pragma("unroll") for (int a = 0; a < R; a++) {                                                          \
                 D[ic][a].a = alpha * D[ic][a].a; D[ic][a].b = alpha * D[ic][a].b;                                   \
-                Lv[1][ic][a] = jac_r4<false, true>(L0[ic][a + 1], L0[ic][a], L0[ic][a + 2], L0[im][a + 1], L0[in_][a + 1], D[ic][a], alpha, beta, xlo, xhi); \
+                Lv[1][ic][a] = jac_r4<false, true, true>(L0[ic][a + 1], L0[ic][a], L0[ic][a + 2], L0[im][a + 1], L0[in_][a + 1], D[ic][a], alpha, beta, xlo, xhi); \
                 if (EDGE && rowb[a]) Lv[1][ic][a] = L0[ic][a + 1];                                                  \
             }                                                                                                       \
         }                                                                                                           \
@@ -1116,7 +1149,7 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
                 _Pragma("unroll") for (int a = 0; a < R; a++) {                                                      \
                     const R4 ce = Lv[s - 1][cs][a];                                                                 \
                     const R4 fr = a == 0 ? nlo[s] : Lv[s - 1][cs][a == 0 ? 0 : a - 1], bk = a == R - 1 ? nhi[s] : Lv[s - 1][cs][a == R - 1 ? a : a + 1]; \
-                    R4 v = jac_r4<false, true>(ce, fr, bk, Lv[s - 1][ds][a], Lv[s - 1][us][a], D[cs][a], alpha, beta, xlo, xhi); \
+                    R4 v = jac_r4<false, true, true>(ce, fr, bk, Lv[s - 1][ds][a], Lv[s - 1][us][a], D[cs][a], alpha, beta, xlo, xhi); \
                     if (keep || (EDGE && rowb[a])) v = ce;                                                          \
                     if (s < S) { Lv[s][cs][a] = v; put(lds[s - 1][ps & 1], a, v); }                                 \
                     else if (active[a]) st_r4(v, ro, vo[a + 1], pstride * (unsigned)ps);                            \
