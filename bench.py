@@ -384,7 +384,7 @@ def main():
         lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
         extra = (extra_steps, el_extra, el_fast)
     # ---- one GPU: where the step's time goes, and the second kernel family against its own bounds (outside the timed region) ----
-    phase_ms = None
+    phase_ms, quad_leg = None, None
     if world == 1 and not emul and args.scheme == "bimocq" and not mg and not args.no_extra:
         n_ph = max(1, min(10, args.steps))
         s.setOption(3, 1)                                   # the headline's full sequence
@@ -396,6 +396,29 @@ def main():
         phases, psteps = s.phaseMs(reset=True)
         s.setOption(8, 0)
         phase_ms = {k: round(v / max(1, psteps), 3) for k, v in phases.items()}
+        # ... and the same sequence with FOUR Jacobi sweeps per launch where the LDS-exchanged kernel applies
+        # (FL_OPT_JACOBI_ROWS = 6): fewer microseconds per sweep, but a launch that moves the same bytes takes longer --
+        # the per-launch roofline fraction falls while the loop gets faster.  Extra information; the headline keeps the default.
+        n_q = max(1, min(20, args.steps))
+        lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 6)
+        run(2)
+        lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
+        barrier()
+        tq = time.perf_counter()
+        run(n_q)
+        barrier()
+        el_q = time.perf_counter() - tq
+        lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 0)
+        lib.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
+        qms, ql, qs = C.c_double(0.0), C.c_longlong(0), C.c_longlong(0)
+        lib.fl_jacobi_profile(C.byref(qms), C.byref(ql), C.byref(qs))
+        if ql.value > 0 and qs.value > 0:
+            quad_leg = {"value": round(nx * ny * nz_global * n_q / el_q / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(el_q / n_q * 1e3, 3),
+                        "steps": n_q, "sweeps_per_launch": round(qs.value / ql.value, 3), "us_per_sweep": round(qms.value * 1e3 / qs.value, 3),
+                        "us_per_launch": round(qms.value * 1e3 / ql.value, 3),
+                        "note": "FL_OPT_JACOBI_ROWS = 6: four sweeps per launch (jacobi_lds_kernel<4, 2, 4>) where it applies, same results bit for bit"}
+        else:
+            quad_leg = None
     # ---- diagnostics for z-slab runs: what the timed region alone cannot tell (outside it: the event pairs cost ~1 %) ----
     # One leg with the run's own settings -- communication no kernel hid (the compute stream's waits on the halo stream),
     # the in-stream all-reduces, milliseconds per phase of the step, on EVERY rank -- and one short leg per knob whose best
@@ -519,6 +542,8 @@ def main():
                                                "note": "FL_OPT_FAST_LERP = 1 on top of the elision: every lerp of the gather kernels is "
                                                        "one fp32 fma; NOT the reference arithmetic (DESIGN.md section 12: deviation "
                                                        "from the exact fields measured per grid size, tolerance 1e-5 RMS)"}})
+    if phase_ms and quad_leg:
+        line.setdefault("extra", {})["jacobi_four_sweeps_per_launch"] = quad_leg
     if launches.value > 0 and mg:
         # dominant kernel: the level-0 fp64 smoothing sweep, two per launch of mg_lean2r_kernel (mg_smooth2_kernel with FL_OPT_JACOBI_ROWS = 3): one launch reads x and
         # rhs and writes x' once (24 B/cell compulsory), which is 24 B/cell/sweep x 2 sweeps in SURVEY 8(d)'s per-sweep
@@ -568,8 +593,9 @@ def main():
                                             "by the fabric/Infinity Cache, not by DRAM; the HBM peak is the yardstick BASELINE names"
                                             if resident else f"p, p', div = {compulsory / 1e6:.0f} MB: HBM-resident")
                                            + (f"; {spl:.2f} sweeps per launch: a fused launch moves ONE sweep's bytes, so `frac` falls as "
-                                              "more sweeps are fused while the time per sweep (us_per_sweep) improves -- the three-sweep "
-                                              "kernel is bound by instruction issue at one wave per SIMD, not by memory" if spl > 2.5 else "")),
+                                              "more sweeps are fused while the time per sweep (us_per_sweep) improves -- the LDS-exchanged "
+                                              "three-sweep kernel keeps VALU, LDS and the L1 path each 25-40 % busy between one barrier per "
+                                              "plane (DESIGN.md section 4), it is not bound by memory" if spl > 2.5 else "")),
                             "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
                                                   "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                   "note": "SURVEY 8(d): 12 B/voxel/SWEEP x sweeps per launch -- the bytes unfused "

@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
                                                                   int nby, int nblk, int kchunk, float alpha, float beta, Slab sl)
 {
     static_assert((R == 1 || R == 2) && (S == 3 || S == 4), "one or two rows per wave, three or four sweeps per launch");
-    constexpr int H = (S - 1 + R - 1) / R, NW = W + 2 * H, NS = NW * R, P = 4;
+    constexpr int H = (S - 1 + R - 1) / R, NW = W + 2 * H, NS = NW * R, P = 4, A = P - 2;   // A: the plane loaded in step q is q + A
     __shared__ v4f lds[S - 1][2][NS][64];                           // [level - 1][plane parity][row slot][lane]
     // XCD-contiguous block order: the grid is padded to a multiple of 8 blocks (nblk real ones), XCD x = blockIdx % 8 works
     // through its own run of consecutive (row block, chunk) pairs -- neighbouring row blocks share their halo rows in one L2
@@ -1064,6 +1064,9 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
     const int jb = by * (W * R);                                    // first output row of the block
     const int j = jb + R * (wv - H);                                // this wave's rows: j .. j + R - 1 (halo waves: outside the block)
     const bool halo = wv < H || wv >= NW - H;
+    // a halo wave whose nearest row lies dn rows outside the block owes the block levels 1 .. S - dn only (wave-uniform)
+    const int dn = wv < H ? R * (H - wv) - (R - 1) : (wv >= NW - H ? R * (wv - (NW - H)) + 1 : 0);
+    const int smax = S - dn;
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
     const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
     if (kbeg >= kend) return;                                       // (block-uniform: no barrier is skipped by part of a block)
@@ -1092,8 +1095,9 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
     auto put = [&](v4f (*buf)[64], int a, R4 v) { buf[r0 + a][lane] = v4f{v.a.x, v.a.y, v.b.x, v.b.y}; };
     auto get = [&](v4f (*buf)[64], int r) -> R4 { const v4f v = buf[r][lane]; return R4{v2f{v.x, v.y}, v2f{v.z, v.w}}; };
 
-    auto run = [&](auto EDGE_T) {
+    auto run = [&](auto EDGE_T, auto SM_T) __attribute__((always_inline)) {
     constexpr bool EDGE = decltype(EDGE_T)::value;
+    constexpr int SM = decltype(SM_T)::value;                       // the levels this wave evaluates (halo waves: fewer than S)
     R4 L0[P][R + 2], D[P][R], Lv[S][P][R];                          // Lv[s]: level s (1 .. S-1) on the wave's own rows
     const R4 zero = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
@@ -1107,26 +1111,26 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
     int q = kbeg - (S - 1);
 #define BQ_SL4(T, d) ((((T) + (d)) % P + P) % P)
 #pragma unroll
-    for (int d = -1; d <= 1; d++) {                                 // prologue: planes q-1, q, q+1 of p; div of plane q
+    for (int d = -1; d <= A - 1; d++) {                             // prologue: planes q-1 .. q+A-1 of p; div of planes q .. q+A-2
         const int sl_ = BQ_SL4(0, d);
         const unsigned pp = po(q + d);
 #pragma unroll
         for (int a = 0; a < R + 2; a++) L0[sl_][a] = ld_r4(rp, vo[a], pp);
-        if (d == 0) {
+        if (d >= 0 && d <= A - 2) {
 #pragma unroll
             for (int a = 0; a < R; a++) D[sl_][a] = ld_r4(rd, vo[a + 1], pp);
         }
     }
 #define BQ_LDS_PHASE(T)                                                                                             \
     {                                                                                                               \
-        constexpr int im = BQ_SL4(T, -1), ic = BQ_SL4(T, 0), in_ = BQ_SL4(T, 1), ia = BQ_SL4(T, 2);                   \
-        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        constexpr int im = BQ_SL4(T, -1), ic = BQ_SL4(T, 0), in_ = BQ_SL4(T, 1), ia = BQ_SL4(T, A), id_ = BQ_SL4(T, A - 1); \
+        const unsigned pa = po(q + A), pb = po(q + A - 1);                                                          \
         _Pragma("unroll") for (int a = 0; a < R + 2; a++) L0[ia][a] = ld_r4(rp, vo[a], pa);                           \
-        if (S == 3) { _Pragma("unroll") for (int a = 0; a < R; a++) D[in_][a] = ld_r4(rd, vo[a + 1], pb); }           \
+        if (S == 3) { _Pragma("unroll") for (int a = 0; a < R; a++) D[id_][a] = ld_r4(rd, vo[a + 1], pb); }           \
         /* the neighbour rows every later level of this step needs were put into LDS before the last barrier: fetch them   \
            all now, ahead of the first level's arithmetic (the compiler cannot hoist them over this step's own puts) */     \
         R4 nlo[S + 1], nhi[S + 1];                                                                                  \
-        _Pragma("unroll") for (int s = 2; s <= S; s++) {                                                             \
+        _Pragma("unroll") for (int s = 2; s <= SM; s++) {                                                            \
             nlo[s] = get(lds[s - 2][(q - (s - 1)) & 1], rlo); nhi[s] = get(lds[s - 2][(q - (s - 1)) & 1], rhi);     \
         }                                                                                                           \
         /* first sweep on plane q, own rows */                                                                       \
@@ -1144,7 +1148,7 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
         _Pragma("unroll") for (int s = 2; s <= S; s++) {                                                             \
             const int ps = q - (s - 1);                                                                             \
             const int cs = BQ_SL4(T, -(s - 1)), us = BQ_SL4(T, -(s - 2)), ds = BQ_SL4(T, -s);                       \
-            if (s < S || (ps >= kbeg && ps < kend)) {   /* (a step without these two wave-uniform branches measured slower) */ \
+            if (s <= SM && (s < S || (ps >= kbeg && ps < kend))) {   /* (a step without the two wave-uniform plane tests measured slower) */ \
                 const bool keep = ps < kA || ps >= kB;                                                              \
                 _Pragma("unroll") for (int a = 0; a < R; a++) {                                                      \
                     const R4 ce = Lv[s - 1][cs][a];                                                                 \
@@ -1156,7 +1160,7 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
                 }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
-        if (S == 4) { _Pragma("unroll") for (int a = 0; a < R; a++) D[in_][a] = ld_r4(rd, vo[a + 1], pb); }           \
+        if (S == 4) { _Pragma("unroll") for (int a = 0; a < R; a++) D[id_][a] = ld_r4(rd, vo[a + 1], pb); }           \
         __syncthreads();                                                                                            \
         q++;                                                                                                        \
     }
@@ -1171,7 +1175,14 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
         if (q > kend + S - 2) break;
     }
     };
-    if (edge_block) run(std::true_type{}); else run(std::false_type{});
+    // one instance of the march per number of levels: the waves of a block run different code between the same barriers
+    auto go = [&](auto E) __attribute__((always_inline)) {
+        if (smax >= S) run(E, std::integral_constant<int, S>{});
+        else if (smax == 1) run(E, std::integral_constant<int, 1>{});
+        else if (smax == 2) run(E, std::integral_constant<int, 2>{});
+        else run(E, std::integral_constant<int, 3>{});
+    };
+    if (edge_block) go(std::true_type{}); else go(std::false_type{});
 #undef BQ_LDS_PHASE
 #undef BQ_SL4
 }
@@ -1522,7 +1533,8 @@ static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int 
         if (shape == 24) BQ_LDS(4, 2, 4); else BQ_LDS(6, 1, 4);      // (18 with four sweeps: 6 single rows + 6 halo waves)
     } else {
         if (shape == 24) BQ_LDS(4, 2, 3); else if (shape == 25) BQ_LDS(5, 2, 3); else if (shape == 26) BQ_LDS(6, 2, 3);
-        else if (shape == 19) BQ_LDS(12, 1, 3); else BQ_LDS(8, 1, 3);
+        else if (shape == 19) BQ_LDS(12, 1, 3);
+        else BQ_LDS(8, 1, 3);
     }
 #undef BQ_LDS
     BQ_LAUNCH_CHECK("jacobi_lds_kernel");
