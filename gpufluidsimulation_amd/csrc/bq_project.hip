@@ -1045,6 +1045,9 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
 // 2 (S - 1) warm-up planes.  All rings have period 4 (planes q-1, q, q+1 of the input live, q+2 arriving; three planes of every
 // intermediate level; div of the S planes the levels are working on -- with S = 4 the slot of the oldest one is refilled at
 // the END of the step, after the last level has used it).
+// A halo wave whose nearest row lies dn rows outside the block owes the block levels 1 .. S - dn only: the march is instantiated
+// once per level count and a block's waves run different code between the same barriers (S = 4 in row pairs: 11.4 -> 10.0 us
+// per sweep at 256^3; S = 3 unchanged, 10.7 -- its waves wait for each other, not for the VALU).
 template <int W, int R, int S>
 __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_lds_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                   float *__restrict__ out, int nx, int ny, int nz,
@@ -1509,6 +1512,12 @@ static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int 
     // chunks of 26 11.88, 19 11.23 -- against 13.1-13.6 for jacobi_lean3r_kernel and 15.6 for the two-sweep kernel.  A launch
     // then takes 32.4 us for 201 MB of compulsory traffic = 6.2 TB/s: like the two-sweep kernel (31.4 us per launch) it sits on
     // the fabric, so what is left is more sweeps per launch, not a better schedule -- hence S = 4.
+    // Later in round 3 (gpurun_out/r03r .. r03v): the l + r stage through v_add_f32_dpp 10.79 -> 10.71; input rings of 5 / 6
+    // planes (loads one / two steps further ahead) 11.00 / 11.19; the step's prefetch issued last 11.11, the first level ahead
+    // of the LDS reads 10.76; blocks of 4 single rows, two per CU 11.83; halo waves that skip the levels nobody needs: S = 3
+    // 10.69, S = 4 in row pairs 11.40 -> 9.98 (39.9 us per launch).  SQ counters: a wave issues 24-28 % of its cycles, is
+    // parked on waitcnt / barrier 40 % and stalled at issue 33 % (the L1 path: with the prefetch last the stall moves to the
+    // barrier) -- VALU, LDS and L1 path are each 25-40 % busy but take turns between the barriers.
     int shape = rt().opt_jacobi_kchunk;
     if (shape != 24 && shape != 25 && shape != 26 && shape != 18 && shape != 19) shape = S == 4 ? 24 : 18;
     if (S == 4 && shape != 24 && shape != 18) shape = 24;        // (row pairs, 6 of them: 10 waves at 168 registers spill)
