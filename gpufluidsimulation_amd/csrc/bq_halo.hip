@@ -496,7 +496,10 @@ int fl_comm_selftest(void)
         for (int i = 0; i < n; i++) { host[i] = 0.25f * i - 3.f; host[n + i] = -1.f; }
         double hd[2] = { 1.0 / 3.0, -7.5 };
         double *dd = (double *)(buf + 2 * n);
-        bool ok = BQ_HIP(hipMemcpy(buf, host, sizeof host, hipMemcpyHostToDevice)) && BQ_HIP(hipMemcpy(dd, hd, sizeof hd, hipMemcpyHostToDevice));
+        // on the compute stream, behind fl_malloc's asynchronous clear of the buffer (a copy on the null stream is not ordered
+        // against it: the clear could land on top of the test pattern), and complete before the halo stream touches the data
+        bool ok = BQ_HIP(hipMemcpyAsync(buf, host, sizeof host, hipMemcpyHostToDevice, r.compute)) &&
+                  BQ_HIP(hipMemcpyAsync(dd, hd, sizeof hd, hipMemcpyHostToDevice, r.compute)) && BQ_HIP(hipStreamSynchronize(r.compute));
         ok = ok && nccl_ok(g_rccl.AllReduce(dd, dd, 2, ncclDouble, ncclSum, comm, r.halo), "selftest AllReduce(double,sum)");
         ok = ok && nccl_ok(g_rccl.AllReduce(buf, buf, 8, ncclFloat, ncclMax, comm, r.halo), "selftest AllReduce(float,max)");
         ok = ok && BQ_NCCL(GroupStart());
