@@ -416,7 +416,9 @@ def main():
             quad_leg = {"value": round(nx * ny * nz_global * n_q / el_q / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(el_q / n_q * 1e3, 3),
                         "steps": n_q, "sweeps_per_launch": round(qs.value / ql.value, 3), "us_per_sweep": round(qms.value * 1e3 / qs.value, 3),
                         "us_per_launch": round(qms.value * 1e3 / ql.value, 3),
-                        "note": "FL_OPT_JACOBI_ROWS = 6: four sweeps per launch (jacobi_lds_kernel<4, 2, 4>) where it applies, same results bit for bit"}
+                        "note": "FL_OPT_JACOBI_ROWS = 6: four sweeps per launch (jacobi_lds_kernel<4, 2, 4>) where it applies, same results bit for bit; "
+                                "these are LATER steps of the scene than the timed region's (more DMC sub-steps per step): compare us_per_sweep with "
+                                "roofline.us_per_sweep, not `value` with the headline"}
         else:
             quad_leg = None
     # ---- diagnostics for z-slab runs: what the timed region alone cannot tell (outside it: the event pairs cost ~1 %) ----
@@ -639,6 +641,9 @@ def main():
             print("[bench] WARNING: a NaN or an Inf appeared in the velocity field during this run (fl_nonfinite_seen): the "
                   "timings are those of a broken simulation", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
+    # streams, events and cached graphs are released while the HIP runtime is still whole (under rocprofv3 the runtime's own
+    # exit-time teardown of the CU-masked copy stream crashed after the profile had been written)
+    lib.fl_shutdown()
 
 
 if __name__ == "__main__":
