@@ -69,6 +69,7 @@ HIP_SIGS = {
     "fl_get_option": (c_i, [c_i]),
     "fl_jacobi_profile": (None, [C.POINTER(c_d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "fl_jacobi_kernel_name": (C.c_char_p, []),
+    "fl_mg_smooth_kernel_name": (C.c_char_p, []),
     # 3. additive
     "gpu_init_maps": (None, [VP, VP, VP] + _G),
     "gpu_maps_quarter_safe": (c_i, [VP, VP, VP] + _G),

@@ -55,6 +55,7 @@ struct Runtime {
     // use, released by fl_shutdown through the *_release hooks below.
     void  *halo_state = nullptr, *project_state = nullptr, *mgcg_state = nullptr;
     int    nonfinite_seen = 0;          // sticky: a gpu_max_abs3 met a NaN or an Inf (fl_nonfinite_seen)
+    const char *mg_smooth_kernel = ""; // the fused kernel the last fp64 smoothing call launched first (fl_mg_smooth_kernel_name)
 };
 
 Runtime &rt();

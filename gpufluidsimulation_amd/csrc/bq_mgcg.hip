@@ -622,6 +622,190 @@ __global__ __launch_bounds__(256) void mg_lean2r_kernel(const double *__restrict
 }
 
 
+// ---- THREE sweeps per launch, the intermediate levels' neighbour rows exchanged through LDS ------------------------------
+// The fp64 twin of jacobi_lds_kernel<W, 1, 3> (bq_project.hip): a block is W output waves + two halo waves at either end, a
+// wave owns ONE row; per plane step it evaluates level 1 on its row (neighbour rows: global loads) and puts it into LDS,
+// level 2 one plane behind (neighbour rows of level 1 out of LDS), puts that, level 3 two planes behind and stores it; one
+// barrier per step, LDS double-buffered by plane parity.  Rows of 130 .. 256 doubles: lane l holds the cells 2l, 2l+1
+// (segment A) AND 128 + 2l, 128 + 2l + 1 (segment B) of its row, so every load is a fully coalesced 16-byte column and the
+// row needs no second wave; the x-neighbours across the segment seam travel by wave rotation (lane 63 receives lane 0's
+// segment-B cell, lane 0 lane 63's segment-A cell).  Every value is mg_smooth_kernel's expression on the same operands
+// (alpha * b is multiplied once and reused by the three levels: the same product); boundary rows / planes / columns keep
+// their input through all levels.  Preconditions as for mg_lean2r_kernel (both buffers carry the same boundary layer).
+struct D4 { D2 a, b; };                                     // segment A and segment B of a row (two cells each)
+__device__ __forceinline__ double lane_rol(double x)        // lane l receives lane l+1's x, lane 63 lane 0's (wave_rol:1)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)h2 << 32) | l2));
+}
+__device__ __forceinline__ double lane_ror(double x)        // lane l receives lane l-1's x, lane 0 lane 63's (wave_ror:1)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)h2 << 32) | l2));
+}
+// smoothing_jacobi_kernel's expression (:1443-1461) on the four cells of a lane; adv = alpha * b
+__device__ __forceinline__ D4 jac_d4(D4 ce, D4 fr, D4 bk, D4 dn, D4 up, D4 adv, double beta, bool xlo, bool xhi, bool first, bool last)
+{
+    const double leftA = lane_up(ce.a.b);
+    const double rightA = lane_rol(first ? ce.b.a : ce.a.a);    // lane 63: cell 128, which lane 0 holds in segment B
+    const double leftB = lane_ror(last ? ce.a.b : ce.b.b);      // lane 0: cell 127, which lane 63 holds in segment A
+    const double rightB = lane_down(ce.b.a);
+    D4 o;
+    o.a.a = ((leftA + ce.a.b + fr.a.a + bk.a.a + dn.a.a + up.a.a) + adv.a.a) * beta;
+    o.a.b = ((ce.a.a + rightA + fr.a.b + bk.a.b + dn.a.b + up.a.b) + adv.a.b) * beta;
+    o.b.a = ((leftB + ce.b.b + fr.b.a + bk.b.a + dn.b.a + up.b.a) + adv.b.a) * beta;
+    o.b.b = ((ce.b.a + rightB + fr.b.b + bk.b.b + dn.b.b + up.b.b) + adv.b.b) * beta;
+    if (xlo) o.a.a = ce.a.a;
+    if (xhi) o.b.b = ce.b.b;
+    return o;
+}
+
+template <int W, bool ZIN>
+__global__ __launch_bounds__((W + 4) * 64) void mg_lds3_kernel(const double *__restrict__ p, const double *__restrict__ div,
+                                                               double *__restrict__ out, int nx, int ny, int nz,
+                                                               int nby, int nblk, int kchunk, double alpha, double beta)
+{
+    constexpr int S = 3, H = 2, NW = W + 2 * H, P = 4;
+    // [level][plane parity][row slot][segment][lane]; level 0 is the INPUT: a wave loads its own row only and takes the two
+    // neighbouring rows of the centre plane out of LDS like those of the later levels (three row loads fewer per plane, 48
+    // registers fewer: twelve waves per block fit three to a SIMD).  The outermost halo waves have no neighbour wave on their far
+    // side: they fetch that one row from memory themselves.
+    __shared__ v2d lds[S][2][NW][2][64];
+    const int per = (int)gridDim.x >> 3;                            // XCD-contiguous block order (grid padded to 8 k blocks)
+    const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (b >= nblk) return;
+    const int by = b % nby, bz = b / nby;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int jb = by * W;
+    const int j = jb + (wv - H);                                    // this wave's row (halo waves: outside the block)
+    const bool halo = wv < H || wv >= NW - H;
+    const int dn = wv < H ? H - wv : (wv >= NW - H ? wv - (NW - H) + 1 : 0);
+    const int smax = S - dn;                                        // a halo wave dn rows outside owes levels 1 .. S - dn
+    const bool low_end = wv == 0;                                   // (of the two outermost waves)
+    const int kA = 1, kB = nz - 1;
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;                                       // (block-uniform)
+    const int xA = 2 * lane, xBraw = 128 + 2 * lane;
+    const bool okB = xBraw < nx;
+    const int xB = okB ? xBraw : nx - 2;                            // out-of-range lanes, rows, planes: clamped into the array
+    const bool xlo = lane == 0, xhi = okB && xBraw + 1 == nx - 1;
+    const bool first = lane == 0, last = lane == 63;
+    const bool row_in = !halo && j >= 1 && j <= ny - 2;
+    const bool rowb = j <= 0 || j >= ny - 1;
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 8u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    // byte offsets of this lane's columns in its own row and (outermost halo waves) in the row on the far side
+    const unsigned row_own = (unsigned)nx * (unsigned)min(max(j, 0), ny - 1);
+    const unsigned row_far = (unsigned)nx * (unsigned)min(max(low_end ? j - 1 : j + 1, 0), ny - 1);
+    const unsigned voA = ((unsigned)xA + row_own) * 8u, voB = ((unsigned)xB + row_own) * 8u;
+    const unsigned vfA = ((unsigned)xA + row_far) * 8u, vfB = ((unsigned)xB + row_far) * 8u;
+    const bool edge_block = jb - H <= 0 || jb + W + H - 1 >= ny - 1;
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 8u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    const int rlo = max(wv - 1, 0), rhi = min(wv + 1, NW - 1);
+    auto put = [&](v2d (*buf)[2][64], D4 v) { buf[wv][0][lane] = v2d{v.a.a, v.a.b}; buf[wv][1][lane] = v2d{v.b.a, v.b.b}; };
+    auto get = [&](v2d (*buf)[2][64], int r) -> D4 { const v2d u = buf[r][0][lane], w = buf[r][1][lane]; return D4{D2{u.x, u.y}, D2{w.x, w.y}}; };
+    const D4 zero = D4{D2{0.0, 0.0}, D2{0.0, 0.0}};
+    auto ld_own = [&](v4i rs, unsigned pp) -> D4 { return D4{ld_d2(rs, voA, pp), ld_d2(rs, voB, pp)}; };
+    auto ld_far = [&](unsigned pp) -> D4 { return D4{ld_d2(rp, vfA, pp), ld_d2(rp, vfB, pp)}; };
+
+    auto run = [&](auto EDGE_T, auto SM_T) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
+    constexpr int SM = decltype(SM_T)::value;                       // the levels this wave evaluates
+    constexpr bool OUTER = SM == 1;                                 // an outermost halo wave (dn == H)
+    D4 L0[P], Lx[P], D[P], L1[P], L2[P];
+#pragma unroll
+    for (int a = 0; a < P; a++) { D[a] = zero; L1[a] = zero; L2[a] = zero; Lx[a] = zero; }
+    int q = kbeg - (S - 1);
+#define MG_SL4(T, d) ((((T) + (d)) % P + P) % P)
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {                                 // prologue: planes q-1, q, q+1 of x; b of plane q
+        const int sl_ = MG_SL4(0, d);
+        const unsigned pp = po(q + d);
+        L0[sl_] = ZIN ? zero : ld_own(rp, pp);
+        if (OUTER && d >= 0) Lx[sl_] = ZIN ? zero : ld_far(pp);
+        if (d == 0) D[sl_] = ld_own(rd, pp);
+    }
+    if (!ZIN) { put(lds[0][q & 1], L0[MG_SL4(0, 0)]); __syncthreads(); }    // the first step's centre plane for the neighbours
+#define MG_LDS_PHASE(T)                                                                                             \
+    {                                                                                                               \
+        constexpr int im = MG_SL4(T, -1), ic = MG_SL4(T, 0), in_ = MG_SL4(T, 1), ia = MG_SL4(T, 2);                   \
+        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        L0[ia] = ZIN ? zero : ld_own(rp, pa);                                                                       \
+        if (OUTER) Lx[ia] = ZIN ? zero : ld_far(pa);                                                                \
+        D[in_] = ld_own(rd, pb);                                                                                    \
+        D4 fr0 = zero, bk0 = zero, nlo2 = zero, nhi2 = zero, nlo3 = zero, nhi3 = zero;                              \
+        if (!ZIN) {                                                                                                 \
+            if (!OUTER || !low_end) fr0 = get(lds[0][q & 1], rlo);                                                  \
+            if (!OUTER || low_end) bk0 = get(lds[0][q & 1], rhi);                                                   \
+            if (OUTER) { if (low_end) fr0 = Lx[ic]; else bk0 = Lx[ic]; }                                            \
+        }                                                                                                           \
+        if (!ZIN) put(lds[0][(q + 1) & 1], L0[in_]);            /* the next step's centre plane */                   \
+        /* first sweep on plane q */                                                                                \
+        if (q < kA || q >= kB) {                                                                                    \
+            L1[ic] = L0[ic];                                                                                        \
+        } else {                                                                                                    \
+            D[ic].a.a = alpha * D[ic].a.a; D[ic].a.b = alpha * D[ic].a.b;                                           \
+            D[ic].b.a = alpha * D[ic].b.a; D[ic].b.b = alpha * D[ic].b.b;                                           \
+            L1[ic] = jac_d4(L0[ic], fr0, bk0, L0[im], L0[in_], D[ic], beta, xlo, xhi, first, last);                 \
+            if (EDGE && rowb) L1[ic] = L0[ic];                                                                      \
+        }                                                                                                           \
+        /* (the later levels' neighbour rows are fetched level by level: six rows in flight at once cost 25 registers too many) */ \
+        if (SM >= 2) { nlo2 = get(lds[1][(q - 1) & 1], rlo); nhi2 = get(lds[1][(q - 1) & 1], rhi); }                \
+        put(lds[1][q & 1], L1[ic]);                                                                                 \
+        if (SM >= 2) {      /* second sweep on plane q - 1 */                                                       \
+            constexpr int cs = MG_SL4(T, -1), us = MG_SL4(T, 0), ds = MG_SL4(T, -2);                                 \
+            const int ps = q - 1;                                                                                   \
+            D4 v = jac_d4(L1[cs], nlo2, nhi2, L1[ds], L1[us], D[cs], beta, xlo, xhi, first, last);                  \
+            if (ps < kA || ps >= kB || (EDGE && rowb)) v = L1[cs];                                                  \
+            L2[cs] = v;                                                                                             \
+            if (SM >= 3) { nlo3 = get(lds[2][(q - 2) & 1], rlo); nhi3 = get(lds[2][(q - 2) & 1], rhi); }            \
+            put(lds[2][ps & 1], v);                                                                                 \
+        }                                                                                                           \
+        if (SM >= 3) {      /* third sweep on plane q - 2 */                                                        \
+            constexpr int cs = MG_SL4(T, -2), us = MG_SL4(T, -1), ds = MG_SL4(T, -3);                                \
+            const int ps = q - 2;                                                                                   \
+            if (ps >= kbeg && ps < kend) {                                                                          \
+                D4 v = jac_d4(L2[cs], nlo3, nhi3, L2[ds], L2[us], D[cs], beta, xlo, xhi, first, last);              \
+                if (EDGE && rowb) v = L2[cs];                                                                       \
+                if (row_in) {                                                                                       \
+                    const unsigned pk = pstride * (unsigned)ps;                                                     \
+                    st_d2<2>(v.a, ro, voA, pk);                                                                     \
+                    if (okB) st_d2<2>(v.b, ro, voB, pk);                                                            \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        __syncthreads();                                                                                            \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        MG_LDS_PHASE(0)
+        if (q > kend + S - 2) break;
+        MG_LDS_PHASE(1)
+        if (q > kend + S - 2) break;
+        MG_LDS_PHASE(2)
+        if (q > kend + S - 2) break;
+        MG_LDS_PHASE(3)
+        if (q > kend + S - 2) break;
+    }
+    };
+    auto go = [&](auto E) __attribute__((always_inline)) {
+        if (smax >= S) run(E, std::integral_constant<int, S>{});
+        else if (smax == 1) run(E, std::integral_constant<int, 1>{});
+        else run(E, std::integral_constant<int, 2>{});
+    };
+    if (edge_block) go(std::true_type{}); else go(std::false_type{});
+#undef MG_LDS_PHASE
+#undef MG_SL4
+}
+
 // ---- residual / A x in the marching form ------------------------------------------------------------------------------
 // mg_residual_kernel and mg_poisson_kernel give every cell a thread that loads its seven points: 3.8 TB/s at 256^3.  Here
 // a thread owns the double2 columns of rows j, j+1 as in mg_lean2r_kernel and marches along z with x of the planes q-1, q,
@@ -1002,6 +1186,7 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
     double *in = x, *out = temp;
     int s = 0;
     bool cleared = clear == 0;
+    rt().mg_smooth_kernel = "";
     // two sweeps per launch where the fused kernel applies (FL_OPT_JACOBI_FUSE != 0): rows of at most 256
     // lanes; double2 lanes when the rows are 16-byte aligned (even nx), else one cell per lane
     // Worth it on large levels only (measured at 256^3: 60 vs 92 us per sweep; at 127^3 and below the
@@ -1045,8 +1230,46 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
             ProfileSpan span;
             const bool prof = big && iter >= 4 && profile_begin(span);
             const int s_begin = s;
-            for (; s + 4 <= iter; s += 4)
-                for (int h = 0; h < 2; h++) {
+            long long launches = 0;
+            bool planned = false;
+            // three sweeps per launch through mg_lds3_kernel where it applies (rows of 130 .. 256 doubles, chunks of >= 24 planes
+            // at one block per CU; FL_OPT_JACOBI_ROWS = 5 keeps it off for A/B timing): as many triples as leave an even
+            // number of launches in total, so that the newest iterate still ends in x -- 32 sweeps = 8 triples + 4 pairs
+            if (vec == 2 && ni >= 130 && ni <= 256 && nj >= 4 && nk >= 12 && rt().opt_jacobi_rows != 5 && cleared) {
+                // FL_OPT_JACOBI_KCHUNK = 14: blocks of 4 output rows (8 waves) instead of 8 (12 waves), for A/B timing
+                const int LW = rt().opt_jacobi_kchunk == 14 ? 4 : 8;
+                const int nbyl = (nj + LW - 1) / LW;
+                int nbzl = std::max(1, rt().num_cus / nbyl);
+                int kcl = (nk + nbzl - 1) / nbzl;
+                if (rt().opt_jacobi_kchunk2 > 0) kcl = rt().opt_jacobi_kchunk2;
+                // A call that starts from a cleared x (V_Cycle's way down) is free of the parity rule: its first launch does not
+                // read its input, so with an odd number of launches it writes straight into x -- 32 sweeps = 10 triples + 1 pair.
+                int triples = 0;
+                if (kcl >= (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24))
+                    for (int a = (iter - s) / 3; a > 0 && !triples; a--) {
+                        const int rest = iter - s - 3 * a;
+                        if (rest % 2 == 0 && (zin || (rest / 2 + a) % 2 == 0)) triples = a;
+                    }
+                if (triples && zin && ((iter - s - 3 * triples) / 2 + triples) % 2 == 1) { double *t2 = in; in = out; out = t2; }
+                nbzl = (nk + kcl - 1) / kcl;
+                const int nblk = nbyl * nbzl, gridl = 8 * ((nblk + 7) / 8);
+                for (int t = 0; t < triples; t++) {
+#define MG_L3(WV, Z) mg_lds3_kernel<WV, Z><<<gridl, (WV + 4) * 64, 0, rt().compute>>>(in, b, out, ni, nj, nk, nbyl, nblk, kcl, alpha, beta)
+                    if (LW == 4) { if (zin) MG_L3(4, true); else MG_L3(4, false); }
+                    else         { if (zin) MG_L3(8, true); else MG_L3(8, false); }
+#undef MG_L3
+                    zin = false;
+                    double *t2 = in; in = out; out = t2;
+                    s += 3; launches++;
+                }
+                if (triples) { BQ_LAUNCH_CHECK("mg_lds3_kernel"); rt().mg_smooth_kernel = "mg_lds3_kernel"; planned = true; }
+            }
+            // (without triples the pairs come in twos, so that the newest iterate ends in x; with them the plan above has
+            // settled the parity and the remaining pairs are counted one by one)
+            const int pair_group = planned ? 1 : 2;
+            for (; s + 2 * pair_group <= iter; s += 2 * pair_group)
+                for (int h = 0; h < pair_group; h++) {
+                    launches++;
 #define MG_L2(W, F, Z) mg_lean2r_kernel<W, F, Z><<<nby2 * nbz, 256, 0, rt().compute>>>(in, b, out, ni, nj, nk, cw, nby2, kc, alpha, beta)
                     if (zin) {
                         if (wide) { if (pf == 1) MG_L2(true, 1, true); else MG_L2(true, 2, true); }
@@ -1059,8 +1282,9 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
 #undef MG_L2
                     double *t = in; in = out; out = t;
                 }
-            if (prof) profile_end(span, (s - s_begin) / 2, s - s_begin);
+            if (prof) profile_end(span, launches, s - s_begin);
             BQ_LAUNCH_CHECK("mg_lean2r_kernel");
+            if (launches && !rt().mg_smooth_kernel[0]) rt().mg_smooth_kernel = "mg_lean2r_kernel";
         }
         if (!cleared) { if (clear & 1) mg_zero(temp, cells); if (clear & 2) mg_zero(x, cells); cleared = true; }
         const int lanes = (ni + vec - 1) / vec;
@@ -1313,6 +1537,8 @@ void mgcg_release_state(Runtime &r)
 using namespace bq;
 
 extern "C" {
+
+const char *fl_mg_smooth_kernel_name(void) { return rt().mg_smooth_kernel; }
 
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta,
                           int ni, int nj, int nk, int iter)

@@ -329,6 +329,9 @@ int  fl_get_option(int option);
 void fl_jacobi_profile(double *total_ms, long long *launches, long long *sweeps);
 /* name of the two-sweep kernel the projection launched last ("" before the first; for reports) */
 const char *fl_jacobi_kernel_name(void);
+/* name of the fused kernel the last fp64 smoothing call (gpu_smoothing_jacobi, V_Cycle) launched first ("" if none; for
+ * reports and tests) */
+const char *fl_mg_smooth_kernel_name(void);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Additive entry points (no reference counterpart)

@@ -103,6 +103,21 @@ def test_mgcg_with_fused_smoothing_on_every_level(hip):
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
 
 
+@pytest.mark.parametrize("ni,nj,nk,levels", [(136, 24, 24, 2), (256, 16, 20, 2), (200, 12, 32, 3)])
+def test_mgcg_with_three_sweep_lds_smoother(hip, ni, nj, nk, levels):
+    """the whole operator with level 0 smoothed by mg_lds3_kernel (forced on small grids through the chunk-length option):
+    V_Cycle's 32 sweeps from a cleared x run as 10 triples + 1 pair -- an ODD number of launches, the first of which does not
+    read its input and writes straight into x -- its 4 sweeps on the way up as two pairs; bit-identical to the oracle, twice"""
+    import gpufluidsimulation_amd as bq
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 12)
+    try:
+        test_mgcg_matches_oracle(hip, ni, nj, nk, levels, 2, 0.5)
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+
+
 @pytest.mark.parametrize("ni,nj,nk,levels,iters", [(64, 64, 64, 4, 2), (72, 40, 24, 3, 2), (129, 33, 17, 3, 1), (40, 36, 32, 3, 2),
                                                    (24, 20, 16, 2, 2), (16, 16, 16, 1, 1)])
 def test_mgcg_tile_smoother_on_and_off(hip, ni, nj, nk, levels, iters):
@@ -169,3 +184,42 @@ def test_smoothing_fused_pairs(hip, ni, nj, nk, iters):
         if not fuse:
             assert F.same(tr, dt.numpy())           # sweep by sweep the older iterate matches too
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+
+
+@pytest.mark.parametrize("ni,nj,nk,kc", [(256, 12, 30, 10), (130, 9, 24, 8), (200, 21, 40, 13), (254, 8, 16, 16), (256, 64, 48, 24),
+                                        (132, 4, 12, 12), (256, 7, 13, 8)])
+@pytest.mark.parametrize("iters", [6, 10, 32, 12, 4])
+def test_smoothing_lds_triples(hip, ni, nj, nk, kc, iters):
+    """mg_lds3_kernel (round 3): THREE fp64 smoothing sweeps per launch, a wave owns one row of 130 .. 256 doubles as two
+    coalesced segments (the x-neighbours across the seam by wave rotation), the neighbouring rows of the intermediate levels
+    come out of LDS; as many triples as leave an even number of launches, pairs for the rest.  Against the oracle's
+    sweep-by-sweep smoothing: rows that end inside segment B, row counts that leave the last block partly outside the grid,
+    chunks whose warm-up planes reach below plane 0, a cleared input (the ZIN form)."""
+    import gpufluidsimulation_amd as bq
+    rng = np.random.default_rng(ni * 5 + nk)
+    n = ni * nj * nk
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n).reshape(nk, nj, ni)
+    t0 = np.zeros_like(x0)
+    t0[0], t0[-1], t0[:, 0], t0[:, -1], t0[:, :, 0], t0[:, :, -1] = x0[0], x0[-1], x0[:, 0], x0[:, -1], x0[:, :, 0], x0[:, :, -1]
+    x0, t0 = x0.ravel().copy(), t0.ravel().copy()
+    xr, tr = x0.copy(), t0.copy()
+    oracle().orc_mg_smooth(dp(xr), dp(b), dp(tr), -8.0, 1.0 / 6.0, ni, nj, nk, iters)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, kc)
+    dx, db, dt = Dev(hip, x0), Dev(hip, b), Dev(hip, t0)
+    hip.gpu_smoothing_jacobi(dx.ptr, db.ptr, dt.ptr, -8.0, 1.0 / 6.0, ni, nj, nk, iters)
+    name = hip.fl_mg_smooth_kernel_name().decode()
+    # the same call with the triples off: same bits, the pair kernel
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 5)
+    dx2, dt2 = Dev(hip, x0), Dev(hip, t0)
+    hip.gpu_smoothing_jacobi(dx2.ptr, db.ptr, dt2.ptr, -8.0, 1.0 / 6.0, ni, nj, nk, iters)
+    name2 = hip.fl_mg_smooth_kernel_name().decode()
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_ROWS, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+    bq.check()
+    assert name == ("mg_lds3_kernel" if iters >= 6 else "mg_lean2r_kernel"), name
+    assert name2 == "mg_lean2r_kernel", name2
+    assert F.same(xr, dx.numpy())
+    assert F.same(xr, dx2.numpy())

@@ -19,7 +19,8 @@ def main():
     host = np.random.default_rng(1).standard_normal(cells)
     lib.fl_memcpy_h2d(bufs[1], host.ctypes.data, cells * 8)
     e0, e1 = lib.fl_event_create(), lib.fl_event_create()
-    # (fuse, rows option, kchunk2, prefetch distance); rows 0 = the lean two-row kernel, 3 = mg_smooth2_kernel with 4 waves
+    # (fuse, rows option, kchunk2, prefetch distance); rows 0 = triples through mg_lds3_kernel + the lean two-row kernel, 5 = the lean
+    # two-row kernel only, 3 = mg_smooth2_kernel with 4 waves
     variants = [(0, 0, 0, 0), (1, 3, 64, 0), (1, 8, 64, 0)] + [(1, 0, k, pf) for pf in (1, 2) for k in (0, 32, 43, 64, 86, 128)]
     if a.variants:
         variants = [tuple(int(x) for x in v.split(':')) for v in a.variants.split(',')]
