@@ -626,6 +626,35 @@ def main():
                          "ta_busy": [0.74, 0.80], "l1_to_l2_bytes_over_algorithmic": 3.2,
                          "issue_floor_cycles_per_node_wave": 3800},
             "note": "measured in a separate leg of min(steps, 10) steps after the timed region (event pairs per phase)"}
+    # ---- the one-GPU point of the 512^3 strong-scaling curve (N > 1 runs ONE 512^3 grid in N slabs; this run's headline is
+    # config 3's 256^3): a short leg of the same scene at 512^3 on this GPU, so that SCALE's N >= 2 values have their anchor ----
+    if rank == 0 and world == 1 and not emul and not args.no_extra and args.scene == "smoke" and args.scheme == "bimocq" and not mg \
+            and (nx, ny, nz_global) == (256, 256, 256) and not args.dump:
+        try:
+            s.close()
+            big = 512
+            s5 = BimocqGPUSolver(big, big, big, 1.0, 0.0, 1.0, device=local_rank, scheme=0)
+            s5.setSmoke(0.0, 1.0, rising_smoke(big, 1.0 / big))
+            s5.setProjection(args.jacobi_iters, args.halfrdx, 0)
+            s5.setOption(3, 1)
+            n5, w5 = max(1, min(8, args.steps)), max(1, min(4, args.warmup))
+            f5 = 0
+            for _ in range(w5):
+                s5.advance(f5, 2.0 / big); f5 += 1
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(n5):
+                s5.advance(f5, 2.0 / big); f5 += 1
+            barrier()
+            el5 = time.perf_counter() - t5
+            s5.close()
+            line.setdefault("extra", {})["single_gpu_512_anchor"] = {
+                "value": round(big ** 3 * n5 / el5 / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(el5 / n5 * 1e3, 3), "steps": n5,
+                "warmup": w5, "note": "BASELINE config 4's grid (512^3 rising smoke, 200 Jacobi iterations, full state) on ONE GPU: the N = 1 "
+                                      "point of the strong-scaling curve that `bench.py --gpus N` (N > 1) measures on the same grid; early "
+                                      "steps of the scene (steps " + f"{w5}-{w5 + n5}" + ")"}
+        except Exception as e:                  # extra information only
+            line.setdefault("extra", {})["single_gpu_512_anchor"] = {"value": None, "note": f"failed: {e}"}
     if rank == 0 and world == 1 and not emul and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -1190,6 +1190,187 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
 #undef BQ_SL4
 }
 
+// ---- THREE sweeps per launch for rows of 260 .. 512 floats: two float4 segments per lane -----------------------------------
+// jacobi_lds_kernel needs a row to fit one wave.  Here lane l holds the cells 4l .. 4l+3 (segment A) AND 256 + 4l .. 256 + 4l + 3
+// (segment B) of its wave's row, so a 512-float row still belongs to ONE wave and every access is a coalesced 16-byte column;
+// the x-neighbours across the seam travel through the adds' DPP operand with a wave rotation (lane 63 receives lane 0's cell
+// 256, lane 0 lane 63's cell 255).  Twice the registers per row, so the neighbour rows of ALL levels come out of LDS -- the
+// input too: a wave loads its own row only (the outermost halo waves also the one row beyond them) -- and twelve waves of 8
+// output rows + two halo rows at either end fit three to a SIMD.  Same arithmetic, same boundary handling, same precondition
+// as jacobi_lds_kernel; the fp64 smoother mg_lds3_kernel (bq_mgcg.hip) is this kernel's twin.
+struct R8 { R4 a, b; };
+__device__ __forceinline__ float add_rol(float from, float own)      // own + `from` of lane + 1 (lane 63: of lane 0)
+{
+    float r;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_rol:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from), "v"(own));
+    return r;
+}
+__device__ __forceinline__ float add_ror(float from, float own)      // own + `from` of lane - 1 (lane 0: of lane 63)
+{
+    float r;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from), "v"(own));
+    return r;
+}
+// jacobi_kernel's expression on the eight cells of a lane; adv = alpha * div
+__device__ __forceinline__ R8 jac_r8(R8 ce, R8 fr, R8 bk, R8 dn, R8 up, R8 adv, float beta, bool xlo, bool xhi, bool first, bool last)
+{
+    const float uR = first ? ce.b.a.x : ce.a.a.x;                   // lane 63's right neighbour: cell 256, lane 0's segment B
+    const float uL = last ? ce.a.b.y : ce.b.b.y;                    // lane 0's left neighbour in segment B: cell 255, lane 63's segment A
+    v2f s0 = v2f{add_from_left_lane(ce.a.b.y, ce.a.a.y), ce.a.a.x + ce.a.b.x};
+    v2f s1 = v2f{ce.a.a.y + ce.a.b.y, add_rol(uR, ce.a.b.x)};
+    v2f t0 = v2f{add_ror(uL, ce.b.a.y), ce.b.a.x + ce.b.b.x};
+    v2f t1 = v2f{ce.b.a.y + ce.b.b.y, add_from_right_lane(ce.b.a.x, ce.b.b.x)};
+    s0 = s0 + fr.a.a; s1 = s1 + fr.a.b; t0 = t0 + fr.b.a; t1 = t1 + fr.b.b;
+    s0 = s0 + bk.a.a; s1 = s1 + bk.a.b; t0 = t0 + bk.b.a; t1 = t1 + bk.b.b;
+    s0 = s0 + dn.a.a; s1 = s1 + dn.a.b; t0 = t0 + dn.b.a; t1 = t1 + dn.b.b;
+    s0 = s0 + up.a.a; s1 = s1 + up.a.b; t0 = t0 + up.b.a; t1 = t1 + up.b.b;
+    s0 = s0 + adv.a.a; s1 = s1 + adv.a.b; t0 = t0 + adv.b.a; t1 = t1 + adv.b.b;
+    s0 = s0 * beta; s1 = s1 * beta; t0 = t0 * beta; t1 = t1 * beta;
+    if (xlo) s0.x = ce.a.a.x;
+    if (xhi) t1.y = ce.b.b.y;
+    return R8{R4{s0, s1}, R4{t0, t1}};
+}
+
+template <int W>
+__global__ __launch_bounds__((W + 4) * 64) void jacobi_lds2seg_kernel(const float *__restrict__ p, const float *__restrict__ div,
+                                                                      float *__restrict__ out, int nx, int ny, int nz,
+                                                                      int nby, int nblk, int kchunk, float alpha, float beta, Slab sl)
+{
+    constexpr int S = 3, H = 2, NW = W + 2 * H, P = 4;
+    __shared__ v4f lds[S][2][NW][2][64];                            // [level][plane parity][row slot][segment][lane]; level 0: the input
+    const int per = (int)gridDim.x >> 3;                            // XCD-contiguous block order (grid padded to 8 k blocks)
+    const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (b >= nblk) return;
+    const int by = b % nby, bz = b / nby;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int jb = by * W;
+    const int j = jb + (wv - H);                                    // this wave's row (halo waves: outside the block)
+    const bool halo = wv < H || wv >= NW - H;
+    const int dn_rows = wv < H ? H - wv : (wv >= NW - H ? wv - (NW - H) + 1 : 0);
+    const int smax = S - dn_rows;                                   // a halo wave dn rows outside owes levels 1 .. S - dn
+    const bool low_end = wv == 0;
+    const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
+    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    if (kbeg >= kend) return;                                       // (block-uniform)
+    const int xA = 4 * lane, xBraw = 256 + 4 * lane;
+    const bool okB = xBraw < nx;
+    const int xB = okB ? xBraw : nx - 4;                            // out-of-range lanes, rows, planes: clamped into the array
+    const bool xlo = lane == 0, xhi = okB && xBraw + 3 == nx - 1;
+    const bool first = lane == 0, last = lane == 63;
+    const bool row_in = !halo && j >= 1 && j <= ny - 2;
+    const bool rowb = j <= 0 || j >= ny - 1;
+    const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 4u;
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    const unsigned row_own = (unsigned)nx * (unsigned)min(max(j, 0), ny - 1);
+    const unsigned row_far = (unsigned)nx * (unsigned)min(max(low_end ? j - 1 : j + 1, 0), ny - 1);
+    const unsigned voA = ((unsigned)xA + row_own) * 4u, voB = ((unsigned)xB + row_own) * 4u;
+    const unsigned vfA = ((unsigned)xA + row_far) * 4u, vfB = ((unsigned)xB + row_far) * 4u;
+    const bool edge_block = jb - H <= 0 || jb + W + H - 1 >= ny - 1;
+    const unsigned pstride = (unsigned)nx * (unsigned)ny * 4u;
+    auto po = [&](int pl) -> unsigned { return pstride * (unsigned)min(max(pl, 0), nz - 1); };
+    const int rlo = max(wv - 1, 0), rhi = min(wv + 1, NW - 1);
+    auto put = [&](v4f (*buf)[2][64], R8 v) {
+        buf[wv][0][lane] = v4f{v.a.a.x, v.a.a.y, v.a.b.x, v.a.b.y}; buf[wv][1][lane] = v4f{v.b.a.x, v.b.a.y, v.b.b.x, v.b.b.y};
+    };
+    auto get = [&](v4f (*buf)[2][64], int r) -> R8 {
+        const v4f u = buf[r][0][lane], w = buf[r][1][lane];
+        return R8{R4{v2f{u.x, u.y}, v2f{u.z, u.w}}, R4{v2f{w.x, w.y}, v2f{w.z, w.w}}};
+    };
+    const R4 z4 = R4{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    const R8 zero = R8{z4, z4};
+    auto ld_own = [&](v4i rs, unsigned pp) -> R8 { return R8{ld_r4(rs, voA, pp), ld_r4(rs, voB, pp)}; };
+    auto ld_far = [&](unsigned pp) -> R8 { return R8{ld_r4(rp, vfA, pp), ld_r4(rp, vfB, pp)}; };
+
+    auto run = [&](auto EDGE_T, auto SM_T) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(EDGE_T)::value;
+    constexpr int SM = decltype(SM_T)::value;                       // the levels this wave evaluates
+    constexpr bool OUTER = SM == 1;                                 // an outermost halo wave
+    R8 L0[P], Lx[P], D[P], L1[P], L2[P];
+#pragma unroll
+    for (int a = 0; a < P; a++) { D[a] = zero; L1[a] = zero; L2[a] = zero; Lx[a] = zero; }
+    int q = kbeg - (S - 1);
+#define BQ_SL4(T, d) ((((T) + (d)) % P + P) % P)
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {                                 // prologue: planes q-1, q, q+1 of p; div of plane q
+        const int sl_ = BQ_SL4(0, d);
+        const unsigned pp = po(q + d);
+        L0[sl_] = ld_own(rp, pp);
+        if (OUTER && d >= 0) Lx[sl_] = ld_far(pp);
+        if (d == 0) D[sl_] = ld_own(rd, pp);
+    }
+    put(lds[0][q & 1], L0[BQ_SL4(0, 0)]);                           // the first step's centre plane for the neighbours
+    __syncthreads();
+#define BQ_L2S_PHASE(T)                                                                                             \
+    {                                                                                                               \
+        constexpr int im = BQ_SL4(T, -1), ic = BQ_SL4(T, 0), in_ = BQ_SL4(T, 1), ia = BQ_SL4(T, 2);                   \
+        const unsigned pa = po(q + 2), pb = po(q + 1);                                                              \
+        L0[ia] = ld_own(rp, pa);                                                                                    \
+        if (OUTER) Lx[ia] = ld_far(pa);                                                                             \
+        D[in_] = ld_own(rd, pb);                                                                                    \
+        R8 fr0 = zero, bk0 = zero, nlo2 = zero, nhi2 = zero, nlo3 = zero, nhi3 = zero;                              \
+        if (!OUTER || !low_end) fr0 = get(lds[0][q & 1], rlo);                                                      \
+        if (!OUTER || low_end) bk0 = get(lds[0][q & 1], rhi);                                                       \
+        if (OUTER) { if (low_end) fr0 = Lx[ic]; else bk0 = Lx[ic]; }                                                \
+        put(lds[0][(q + 1) & 1], L0[in_]);                      /* the next step's centre plane */                   \
+        /* first sweep on plane q */                                                                                \
+        if (q < kA || q >= kB) {                                                                                    \
+            L1[ic] = L0[ic];                                                                                        \
+        } else {                                                                                                    \
+            D[ic].a.a = alpha * D[ic].a.a; D[ic].a.b = alpha * D[ic].a.b;                                           \
+            D[ic].b.a = alpha * D[ic].b.a; D[ic].b.b = alpha * D[ic].b.b;                                           \
+            L1[ic] = jac_r8(L0[ic], fr0, bk0, L0[im], L0[in_], D[ic], beta, xlo, xhi, first, last);                 \
+            if (EDGE && rowb) L1[ic] = L0[ic];                                                                      \
+        }                                                                                                           \
+        /* (the later levels' neighbour rows are fetched level by level: six rows in flight at once cost too many registers) */ \
+        if (SM >= 2) { nlo2 = get(lds[1][(q - 1) & 1], rlo); nhi2 = get(lds[1][(q - 1) & 1], rhi); }                \
+        put(lds[1][q & 1], L1[ic]);                                                                                 \
+        if (SM >= 2) {      /* second sweep on plane q - 1 */                                                       \
+            constexpr int cs = BQ_SL4(T, -1), us = BQ_SL4(T, 0), ds = BQ_SL4(T, -2);                                 \
+            const int ps = q - 1;                                                                                   \
+            R8 v = jac_r8(L1[cs], nlo2, nhi2, L1[ds], L1[us], D[cs], beta, xlo, xhi, first, last);                  \
+            if (ps < kA || ps >= kB || (EDGE && rowb)) v = L1[cs];                                                  \
+            L2[cs] = v;                                                                                             \
+            if (SM >= 3) { nlo3 = get(lds[2][(q - 2) & 1], rlo); nhi3 = get(lds[2][(q - 2) & 1], rhi); }            \
+            put(lds[2][ps & 1], v);                                                                                 \
+        }                                                                                                           \
+        if (SM >= 3) {      /* third sweep on plane q - 2 */                                                        \
+            constexpr int cs = BQ_SL4(T, -2), us = BQ_SL4(T, -1), ds = BQ_SL4(T, -3);                                \
+            const int ps = q - 2;                                                                                   \
+            if (ps >= kbeg && ps < kend) {                                                                          \
+                R8 v = jac_r8(L2[cs], nlo3, nhi3, L2[ds], L2[us], D[cs], beta, xlo, xhi, first, last);              \
+                if (EDGE && rowb) v = L2[cs];                                                                       \
+                if (row_in) {                                                                                       \
+                    const unsigned pk = pstride * (unsigned)ps;                                                     \
+                    st_r4<2>(v.a, ro, voA, pk);                                                                     \
+                    if (okB) st_r4<2>(v.b, ro, voB, pk);                                                            \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        __syncthreads();                                                                                            \
+        q++;                                                                                                        \
+    }
+    while (true) {
+        BQ_L2S_PHASE(0)
+        if (q > kend + S - 2) break;
+        BQ_L2S_PHASE(1)
+        if (q > kend + S - 2) break;
+        BQ_L2S_PHASE(2)
+        if (q > kend + S - 2) break;
+        BQ_L2S_PHASE(3)
+        if (q > kend + S - 2) break;
+    }
+    };
+    auto go = [&](auto E) __attribute__((always_inline)) {
+        if (smax >= S) run(E, std::integral_constant<int, S>{});
+        else if (smax == 1) run(E, std::integral_constant<int, 1>{});
+        else run(E, std::integral_constant<int, 2>{});
+    };
+    if (edge_block) go(std::true_type{}); else go(std::false_type{});
+#undef BQ_L2S_PHASE
+#undef BQ_SL4
+}
+
 // ---- residual norms (A15 re-specified): r = div - (sum6 p - 6p), sum r^2 and max|r| --------
 // update_residual_kernel / calc_poisson_value arithmetic (GPU_kernel.cu:1048-1060,1239-1249);
 // the reduction is ours: wave64 shuffles -> one partial per block -> fixed-order final pass.
@@ -1518,6 +1699,22 @@ static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int 
     // 10.69, S = 4 in row pairs 11.40 -> 9.98 (39.9 us per launch).  SQ counters: a wave issues 24-28 % of its cycles, is
     // parked on waitcnt / barrier 40 % and stalled at issue 33 % (the L1 path: with the prefetch last the stall moves to the
     // barrier) -- VALU, LDS and L1 path are each 25-40 % busy but take turns between the barriers.
+    // rows of 260 .. 512 floats: the two-segment kernel (three sweeps only), 8 output rows per block
+    if (S == 3 && ni > 256 && ni <= 512 && ni % 4 == 0 && nj >= 8 && nk >= 12 && aligned16(in) && aligned16(div) && aligned16(out) &&
+        g_klo == 0 && g_khi >= nk && (double)ni * nj * nk * 4.0 < 2147483648.0) {
+        constexpr int LW = 8;
+        const int nby = (nj + LW - 1) / LW;
+        int nbz = std::max(1, rt().num_cus / nby);
+        int kc = (nk + nbz - 1) / nbz;
+        if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
+        if (kc < (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24)) return false;
+        nbz = (nk + kc - 1) / kc;
+        const int nblk = nby * nbz, grid = 8 * ((nblk + 7) / 8);
+        jacobi_lds2seg_kernel<LW><<<grid, (LW + 4) * 64, 0, rt().compute>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk));
+        BQ_LAUNCH_CHECK("jacobi_lds2seg_kernel");
+        g_last_pair_kernel = "jacobi_lds2seg_kernel";
+        return true;
+    }
     int shape = rt().opt_jacobi_kchunk;
     if (shape != 24 && shape != 25 && shape != 26 && shape != 18 && shape != 19) shape = S == 4 ? 24 : 18;
     if (S == 4 && shape != 24 && shape != 18) shape = 24;        // (row pairs, 6 of them: 10 waves at 168 registers spill)

@@ -6,6 +6,7 @@ velocity through the emitter's acosf / cosf:
   tests/golden/config5_hashes.json by tests/golden/make_config5_hashes.py (no oracle in the loop here);
 * two z-slab ranks of 1024 x 1024 x 32 + 2 x 8 planes on the stream-ordered RCCL stand-in against one GPU at
   1024 x 1024 x 64: every field bit-identical, the per-slab dumps stitch to the single-GPU dump byte for byte;
+* BASELINE config 4's rank geometry too: two ranks of 512 x 512 x (64 + 16) planes against one GPU at 512 x 512 x 128;
 * the full 1024 x 1024 x 512 grid on ONE rank is refused with the 2 GiB message (include/bimocq_gpu.h, "Limits").
 """
 import json
@@ -89,6 +90,34 @@ def test_two_ranks_of_config5_rows_equal_one_gpu(tmp_path):
         assert parts == [f[:-4] + ".k00000.bqd", f[:-4] + ".k00032.bqd"], parts
         stitched = np.concatenate([read_density_dump(os.path.join(two, p))[1] for p in parts])
         assert hd["nx"] == 1024 and len(rec) > 100000 and stitched.tobytes() == rec.tobytes(), f
+
+
+def test_two_ranks_of_config4_rank_geometry_equal_one_gpu(tmp_path):
+    """BASELINE config 4's RANK geometry -- 512 x 512 x (64 owned + 16 ghost) planes, what each of 8 ranks holds of the 512^3
+    grid: rows of two waves, the plane-range Jacobi launches with the ends-first schedule, ghost exchanges of 2 MB planes -- as
+    two such ranks on the stream-ordered RCCL stand-in against one GPU at 512 x 512 x 128: the rising-smoke scene bench.py
+    runs, 200 Jacobi iterations, every field bit-identical after each of three steps."""
+    from build_fake_rccl import build
+    fake = build("async")
+    ref = str(tmp_path / "ref")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BQ_FAKE_RCCL_DELAY_MB"):
+        env.pop(k, None)
+    worker = os.path.join(HERE, "slab_deviation_worker.py")
+    common = ["--grid", "512", "512", "128", "--steps", "3", "--iters", "200", "--checkpoints", "1", "2", "3"]
+    r = subprocess.run([sys.executable, worker, "--make-reference", ref, *common], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    js = str(tmp_path / "dev.json")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), worker,
+                        "--reference", ref, *common, "--rms-tol", "1e-5", "--json", js], cwd=ROOT,
+                       env=dict(env, BQ_RCCL_LIBRARY=fake, BQ_FAKE_RCCL_SLOT_MB="24"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.load(open(js))
+    assert out["grid"] == [512, 512, 128] and out["ranks"] == 2 and "RCCL branch" in out["transport"]
+    assert out["keep_dmc_border"] == 0
+    assert out["worst_rms"] == 0.0, out["checkpoints"][-1]
 
 
 def test_full_grid_on_one_rank_is_refused():

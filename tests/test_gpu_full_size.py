@@ -1,6 +1,6 @@
 """BASELINE's full sizes on the GPU (configs 2, 3 and the 512^3 grid of config 4): what the toy shapes of the other
 files cannot reach -- the launcher's auto-chunking at 128^3 (one-row fused Jacobi kernel), 256^3 (two-row kernel, 8
-chunks of 32 planes) and 512^3 (WIDE two-row kernel on rows of two waves, 6 chunks of 86 planes), and the gather
+chunks of 32 planes) and 512^3 (three-sweep two-segment kernel, 4 chunks of 128 planes; WIDE two-row kernel for the remainder), and the gather
 kernels on >2^24-element fields.
 
 * 128^3 / 256^3: per-step SHA-256 of rho, u, v, w against the CPU oracle's, committed as
@@ -72,8 +72,8 @@ def test_hip_reproduces_next_row_hashes(case):
 
 
 def test_512_production_kernels_equal_generic_kernels(tmp_path):
-    """512^3 (the grid of BASELINE config 4), 2 steps, 200 Jacobi iterations: default launch configuration (WIDE two-row
-    fused Jacobi, LDS-staged structured map look-ups, marching limiter) against FL_OPT_JACOBI_VARIANT = 1 /
+    """512^3 (the grid of BASELINE config 4), 2 steps, 200 Jacobi iterations: default launch configuration (three-sweep
+    two-segment Jacobi kernel + the WIDE two-row kernel for the remainder, LDS-staged structured map look-ups, marching limiter) against FL_OPT_JACOBI_VARIANT = 1 /
     FL_OPT_JACOBI_FUSE = 0 / FL_OPT_STRUCTURED_MAPS = 0 (one thread per cell, generic map look-up)."""
     import gpufluidsimulation_amd as bq
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
@@ -101,7 +101,7 @@ def test_512_production_kernels_equal_generic_kernels(tmp_path):
         finally:
             lib.fl_set_option(L_.FL_OPT_JACOBI_VARIANT, 0); lib.fl_set_option(L_.FL_OPT_JACOBI_FUSE, 1)
             lib.fl_set_option(L_.FL_OPT_STRUCTURED_MAPS, 1)
-    assert kernel == "jacobi_lean2r_kernel", kernel                       # the two-row fused kernel on rows of two waves did run
+    assert kernel == "jacobi_lds2seg_kernel", kernel                      # the three-sweep kernel for rows of two float4 segments did run
     for k in res["production"]:
         a, b = res["production"][k], res["generic"][k]
         assert np.isfinite(a).all(), k

@@ -328,6 +328,36 @@ def test_fused_three_sweep_lds_kernel(hip, ni, nj, nk, kc, sweeps, shape):
     bq.check()
 
 
+@pytest.mark.parametrize("ni,nj,nk,kc", [(512, 16, 30, 10), (260, 9, 24, 8), (384, 21, 40, 13), (508, 8, 16, 16), (512, 64, 48, 24),
+                                        (264, 8, 12, 12), (512, 11, 13, 8)])
+@pytest.mark.parametrize("sweeps", [3, 7, 8])
+def test_fused_three_sweep_two_segment_kernel(hip, ni, nj, nk, kc, sweeps):
+    """jacobi_lds2seg_kernel (round 3): three sweeps per launch on rows of 260 .. 512 floats -- a lane holds two float4 segments
+    of its wave's row (cells 4l .. 4l+3 and 256 + 4l ..), the x-neighbours across the seam travel by wave rotation, the
+    neighbour rows of all three levels (the input too) come out of LDS.  Against single oracle sweeps: rows that end inside
+    segment B, row counts that leave the last block partly outside the grid, chunks whose warm-up planes reach below plane 0,
+    remainders swept by the two-sweep kernels."""
+    import gpufluidsimulation_amd as bq
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    a, b = p0.copy(), p0.copy()
+    for _ in range(sweeps):
+        oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+        a, b = b, a
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_VARIANT, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, kc)
+    dp, dd, dt = dev(p0, div, p0)
+    where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 3, ALPHA, BETA)      # one triple: names the kernel
+    name = hip.fl_jacobi_kernel_name().decode()
+    where2 = hip.gpu_jacobi_sweeps((dt if where else dp).ptr, dd.ptr, (dp if where else dt).ptr, ni, nj, nk, sweeps - 3, ALPHA, BETA)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+    hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+    assert name == "jacobi_lds2seg_kernel", name
+    newest = (dt if where else dp) if not where2 else (dp if where else dt)
+    assert F.same(a, newest.numpy()), (ni, nj, nk, sweeps)
+    bq.check()
+
+
 @pytest.mark.parametrize("ni,nj,nk,kc", [(64, 48, 40, 10), (256, 32, 30, 8), (128, 37, 19, 8), (32, 12, 12, 12), (36, 25, 50, 9),
                                         (256, 100, 64, 16), (200, 13, 33, 16), (256, 256, 40, 10)])
 @pytest.mark.parametrize("sweeps", [4, 9])
