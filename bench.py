@@ -595,9 +595,11 @@ def main():
                                             "by the fabric/Infinity Cache, not by DRAM; the HBM peak is the yardstick BASELINE names"
                                             if resident else f"p, p', div = {compulsory / 1e6:.0f} MB: HBM-resident")
                                            + (f"; {spl:.2f} sweeps per launch: a fused launch moves ONE sweep's bytes, so `frac` falls as "
-                                              "more sweeps are fused while the time per sweep (us_per_sweep) improves -- the LDS-exchanged "
-                                              "three-sweep kernel keeps VALU, LDS and the L1 path each 25-40 % busy between one barrier per "
-                                              "plane (DESIGN.md section 4), it is not bound by memory" if spl > 2.5 else "")),
+                                              "more sweeps are fused while the time per sweep (us_per_sweep) improves"
+                                              + (" -- the LDS-exchanged three-sweep kernel keeps VALU, LDS and the L1 path each 25-40 % busy "
+                                                 "between one barrier per plane (DESIGN.md section 4), it is not bound by memory" if resident else
+                                                 " -- HBM-resident arrays: the three-sweep launch streams them once, near the rate a plain "
+                                                 "triad reaches at this size") if spl > 2.5 else "")),
                             "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
                                                   "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                   "note": "SURVEY 8(d): 12 B/voxel/SWEEP x sweeps per launch -- the bytes unfused "
