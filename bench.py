@@ -480,6 +480,7 @@ def main():
         alt_sh = 0 if sh == 2 else 2
         legs[f"shallow_exchange_{alt_sh}"] = leg(lambda: s.setOption(6, alt_sh), lambda: s.setOption(6, sh))[0]
         legs["ends_first_" + ("off" if ef else "on")] = leg(lambda: s.setOption(7, 0 if ef else 1), lambda: s.setOption(7, 1 if ef else 0))[0]
+        legs["jacobi_triples_off"] = leg(lambda: s.setOption(10, 0), lambda: s.setOption(10, 1))[0]      # BQ_OPT_JACOBI_TRIPLES: the pair schedule
         for k_ in ([8, 16] if rc == 0 else [0]):
             legs[f"reserve_cus_{k_}"] = leg(lambda: lib.fl_set_option(L_.FL_OPT_RESERVE_CUS, k_), lambda: lib.fl_set_option(L_.FL_OPT_RESERVE_CUS, rc))[0]
     if dist is not None:

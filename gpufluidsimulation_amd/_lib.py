@@ -89,6 +89,7 @@ HIP_SIGS = {
     "gpu_gradient_delta": (None, [VP] * 7 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweep_range": (None, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "gpu_jacobi_sweep_pair_ranges": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "gpu_jacobi_sweep_triple_ranges": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "gpu_residual_norms": (None, [VP, VP, c_i, c_i, c_i, C.POINTER(c_d), C.POINTER(c_f)]),
     "gpu_clamp_extrema_box": (None, [VP, VP, c_i, c_i, c_i]),
     "gpu_clamp_extrema_box_w": (None, [VP, VP, c_i, c_i, c_i]),

@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(256) void jacobi_lean3r_kernel(const float *__restr
 template <int W, int R, int S>
 __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_lds_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                   float *__restrict__ out, int nx, int ny, int nz,
-                                                                  int nby, int nblk, int kchunk, float alpha, float beta, Slab sl)
+                                                                  int nby, int nblk, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
     static_assert((R == 1 || R == 2) && (S == 3 || S == 4), "one or two rows per wave, three or four sweeps per launch");
     constexpr int H = (S - 1 + R - 1) / R, NW = W + 2 * H, NS = NW * R, P = 4, A = P - 2;   // A: the plane loaded in step q is q + A
@@ -1071,7 +1071,9 @@ __global__ __launch_bounds__((W + 2 * ((S - 1 + R - 1) / R)) * 64) void jacobi_l
     const int dn = wv < H ? R * (H - wv) - (R - 1) : (wv >= NW - H ? R * (wv - (NW - H)) + 1 : 0);
     const int smax = S - dn;
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
-    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    // output planes: chunk bz of plane range A or B (whole arrays: A = [0, nz), B empty)
+    const int c0 = bz < rg.nchA ? rg.k0a + bz * kchunk : rg.k0b + (bz - rg.nchA) * kchunk, c1 = bz < rg.nchA ? rg.k1a : rg.k1b;
+    const int kbeg = max(kA, c0), kend = min(min(kB, c1), c0 + kchunk);
     if (kbeg >= kend) return;                                       // (block-uniform: no barrier is skipped by part of a block)
     const int xraw = 4 * lane;
     const bool xok = xraw < nx;
@@ -1234,7 +1236,7 @@ __device__ __forceinline__ R8 jac_r8(R8 ce, R8 fr, R8 bk, R8 dn, R8 up, R8 adv, 
 template <int W>
 __global__ __launch_bounds__((W + 4) * 64) void jacobi_lds2seg_kernel(const float *__restrict__ p, const float *__restrict__ div,
                                                                       float *__restrict__ out, int nx, int ny, int nz,
-                                                                      int nby, int nblk, int kchunk, float alpha, float beta, Slab sl)
+                                                                      int nby, int nblk, int kchunk, float alpha, float beta, Slab sl, PairRanges rg)
 {
     constexpr int S = 3, H = 2, NW = W + 2 * H, P = 4;
     __shared__ v4f lds[S][2][NW][2][64];                            // [level][plane parity][row slot][segment][lane]; level 0: the input
@@ -1251,7 +1253,8 @@ __global__ __launch_bounds__((W + 4) * 64) void jacobi_lds2seg_kernel(const floa
     const int smax = S - dn_rows;                                   // a halo wave dn rows outside owes levels 1 .. S - dn
     const bool low_end = wv == 0;
     const int kA = max(1, 1 - sl.koff), kB = min(nz - 1, sl.nkg - 1 - sl.koff);
-    const int kbeg = max(kA, bz * kchunk), kend = min(kB, bz * kchunk + kchunk);
+    const int r0 = bz < rg.nchA ? rg.k0a + bz * kchunk : rg.k0b + (bz - rg.nchA) * kchunk, r1 = bz < rg.nchA ? rg.k1a : rg.k1b;
+    const int kbeg = max(kA, r0), kend = min(min(kB, r1), r0 + kchunk);
     if (kbeg >= kend) return;                                       // (block-uniform)
     const int xA = 4 * lane, xBraw = 256 + 4 * lane;
     const bool okB = xBraw < nx;
@@ -1685,8 +1688,27 @@ static bool jacobi_sweep_pair(const float *in, const float *div, float *out, int
 
 // Three or four sweeps in one launch through jacobi_lds_kernel (neighbour rows of the intermediate levels via LDS); false = not applicable.
 // FL_OPT_JACOBI_ROWS: 4 forces it wherever it applies, 5 keeps it off (A/B timing); auto: see jacobi_sweep_triple.
-static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta, int S)
+// k0a .. k1b: the OUTPUT planes as up to two ranges (gpu_jacobi_sweep_triple_ranges: the pieces of a z-slab chunk); default: the whole array.
+static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int ni, int nj, int nk, float alpha, float beta, int S,
+                             int k0a = 0, int k1a = 1 << 30, int k0b = 0, int k1b = 0)
 {
+    k0a = std::max(k0a, 0); k1a = std::min(k1a, nk); k0b = std::max(k0b, 0); k1b = std::min(k1b, nk);
+    const int lenA = std::max(k1a - k0a, 0), lenB = std::max(k1b - k0b, 0);
+    if (lenA + lenB == 0) return true;
+    const bool whole = lenB == 0 && lenA == nk;
+    auto chunks_of = [](int len, int kc) { return len > 0 ? (len + kc - 1) / kc : 0; };
+    // chunk length: whole arrays -- as many chunks as fill the CUs once (one block per CU: LDS, registers), refused below 24
+    // planes per chunk (2 (S - 1) warm-up planes: the two-sweep kernel wins there) unless the length is forced; plane ranges
+    // (a slab chunk's ends and interiors) -- whatever fills the CUs once, down to 2 planes per chunk
+    auto chunk_len = [&](int nby, bool &ok) {
+        const int ncus = rt().num_cus;
+        const int nranges = (lenA > 0) + (lenB > 0);
+        const int per_range = std::max(1, ncus / std::max(1, nby * nranges));
+        int kc = std::max(2, (std::max(lenA, lenB) + per_range - 1) / per_range);
+        if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
+        ok = !whole || kc >= (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24);
+        return kc;
+    };
     // block shape: FL_OPT_JACOBI_KCHUNK = 10 R + W selects R rows per wave and W output waves per block for A/B timing
     // (24 / 25 / 26: row pairs, 4 / 5 / 6 of them; 18 / 19: single rows, 8 / 12 of them); default 18 for three sweeps, 24 for four.
     // 256^3, three sweeps, us per sweep (gpurun_out/r03l, r03m): 18 with chunks of 32 planes 10.79, 24 11.06, 25 11.59, 26 with
@@ -1704,13 +1726,13 @@ static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int 
         g_klo == 0 && g_khi >= nk && (double)ni * nj * nk * 4.0 < 2147483648.0) {
         constexpr int LW = 8;
         const int nby = (nj + LW - 1) / LW;
-        int nbz = std::max(1, rt().num_cus / nby);
-        int kc = (nk + nbz - 1) / nbz;
-        if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
-        if (kc < (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24)) return false;
-        nbz = (nk + kc - 1) / kc;
+        bool ok;
+        const int kc = chunk_len(nby, ok);
+        if (!ok) return false;
+        const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kc)};
+        const int nbz = rg.nchA + chunks_of(lenB, kc);
         const int nblk = nby * nbz, grid = 8 * ((nblk + 7) / 8);
-        jacobi_lds2seg_kernel<LW><<<grid, (LW + 4) * 64, 0, rt().compute>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk));
+        jacobi_lds2seg_kernel<LW><<<grid, (LW + 4) * 64, 0, rt().compute>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk), rg);
         BQ_LAUNCH_CHECK("jacobi_lds2seg_kernel");
         g_last_pair_kernel = "jacobi_lds2seg_kernel";
         return true;
@@ -1723,18 +1745,16 @@ static bool jacobi_sweep_lds(const float *in, const float *div, float *out, int 
     if (!((ni % 4 == 0) && ni >= 32 && ni <= 256 && nj >= rows_per_block && nk >= 12 && aligned16(in) && aligned16(div) && aligned16(out))) return false;
     if (g_klo != 0 || g_khi < nk) return false;              // plane ranges: the two-sweep kernels
     const int nby = (nj + rows_per_block - 1) / rows_per_block;
-    // one block per CU (LDS, registers): as many k-chunks as fill the chip once
-    const int ncus = rt().num_cus;
-    int nbz = std::max(1, ncus / nby);
-    int kc = (nk + nbz - 1) / nbz;
-    if (rt().opt_jacobi_kchunk2 > 0) kc = rt().opt_jacobi_kchunk2;
     // 2 (S - 1) warm-up planes per chunk and one block per CU: below ~24 planes per chunk the short-march two-row kernel wins
-    // (128^3: 4.5 us per sweep with chunks of 8 against 3.1); a forced chunk length (tests, tuning) may go down to 8
-    if (kc < (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24)) return false;
-    nbz = (nk + kc - 1) / kc;
+    // on whole arrays (128^3: 4.5 us per sweep with chunks of 8 against 3.1); a forced chunk length (tests, tuning) may go down to 8
+    bool ok;
+    const int kc = chunk_len(nby, ok);
+    if (!ok) return false;
+    const PairRanges rg{k0a, k1a, k0b, k1b, chunks_of(lenA, kc)};
+    const int nbz = rg.nchA + chunks_of(lenB, kc);
     const int nblk = nby * nbz, grid = 8 * ((nblk + 7) / 8);
     hipStream_t st = rt().compute;
-#define BQ_LDS(WV, RV, SV) jacobi_lds_kernel<WV, RV, SV><<<grid, (WV + 2 * ((SV - 1 + RV - 1) / RV)) * 64, 0, st>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk))
+#define BQ_LDS(WV, RV, SV) jacobi_lds_kernel<WV, RV, SV><<<grid, (WV + 2 * ((SV - 1 + RV - 1) / RV)) * 64, 0, st>>>(in, div, out, ni, nj, nk, nby, nblk, kc, alpha, beta, slab_of(nk), rg)
     if (S == 4) {
         if (shape == 24) BQ_LDS(4, 2, 4); else BQ_LDS(6, 1, 4);      // (18 with four sweeps: 6 single rows + 6 halo waves)
     } else {
@@ -1910,6 +1930,20 @@ int gpu_jacobi_sweep_pair_ranges(const float *in, const float *div, float *out, 
     if (!in || !div || !out || in == out) { latch(FL_ERR_BAD_ARGUMENT, "gpu_jacobi_sweep_pair_ranges", "null or aliased buffers"); return 0; }
     if (rt().opt_jacobi_fuse == 0) return 0;
     return jacobi_sweep_pair(in, div, out, ni, nj, nk, alpha, beta, k0a, k1a, k0b, k1b) ? 1 : 0;
+}
+
+// Three sweeps in -> out on the output planes [k0a, k1a) and [k0b, k1b) (either may be empty) through the LDS-exchanged
+// kernels: the triple counterpart of gpu_jacobi_sweep_pair_ranges for the chunks of a z-slab rank.  The input must be
+// valid three planes beyond each range.  Returns 1 when it ran, 0 when it does not apply (nothing launched).
+int gpu_jacobi_sweep_triple_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                                   int k0a, int k1a, int k0b, int k1b, float alpha, float beta)
+{
+    if (!ensure_ready("gpu_jacobi_sweep_triple_ranges") || !dims_ok(ni, nj, nk, "gpu_jacobi_sweep_triple_ranges")) return 0;
+    if (!in || !div || !out || in == out) { latch(FL_ERR_BAD_ARGUMENT, "gpu_jacobi_sweep_triple_ranges", "null or aliased buffers"); return 0; }
+    if (rt().opt_jacobi_fuse == 0 || rt().opt_jacobi_fuse == 4 || rt().opt_jacobi_rows == 5) return 0;
+    if (rt().opt_jacobi_variant != 0 && rt().opt_jacobi_variant != 3) return 0;
+    if (ni < 3 || nj < 4 || nk < 3) return 0;
+    return jacobi_sweep_lds(in, div, out, ni, nj, nk, alpha, beta, 3, k0a, k1a, k0b, k1b) ? 1 : 0;
 }
 
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float halfrdx)

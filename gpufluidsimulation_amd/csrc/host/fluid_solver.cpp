@@ -473,6 +473,7 @@ bool BimocqGPUSolver::projection(bool with_delta)
     int left = jacobi_iters - 1;                                         // iterate iter-1 is applied
     const int own0 = G, own1 = g.nk - G;                                 // local owned planes [own0, own1)
     bool pair_split = G >= 2 && own1 - own0 >= 5;                        // until the operator library says it cannot
+    bool triples_ok = gs.jacobi_triples && G == 8;                       // likewise
     // The exchange a chunk starts with is hidden by the interior part of its first pair only -- one launch (40 us at
     // 512 x 512 x 80) against 8 planes per direction (130 us at 64 GB/s).  So the last two pairs of a chunk that another
     // chunk follows run ENDS FIRST: the G + 2 and then the G owned planes at either end (which need nothing beyond what
@@ -525,6 +526,29 @@ bool BimocqGPUSolver::projection(bool with_delta)
             DeviceField *in = oth, *out = cur;
             int depth = G - done;                                        // correct ghost planes of `in`
             const bool ends_first = ends_first_ok && pair_split && done == 2 && chunk == G && left > chunk;
+            // The six sweeps after the overlapped pair of a full chunk as TWO triples (BQ_OPT_JACOBI_TRIPLES, G = 8): triple A
+            // produces [own0 - 3, own1 + 3) from the pair's result (correct to depth 6), triple B the owned planes.  Ends
+            // first: A and B on the planes next to the slab ends (A: G + 6 planes per end, B: the G planes the neighbours
+            // need), the exchange starts, then the two interiors -- A's interior reads `in` from plane own0 + G on, which is
+            // where B's end stopped writing it.
+            if (triples_ok && pair_split && done == 2 && rest == 6 && depth == 6) {
+                bool ran;
+                if (ends_first) {
+                    ran = gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - 3, own0 + G + 3, own1 - G - 3, own1 + 3, alpha, beta) != 0;
+                    if (ran) {
+                        gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own0 + G, own1 - G, own1, alpha, beta);
+                        { float *ptr = in->get(); size_t pe = in->plane; int ex = 0; fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0); }
+                        in_flight = true;
+                        gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 + G + 3, own1 - G - 3, 0, 0, alpha, beta);
+                        gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0 + G, own1 - G, 0, 0, alpha, beta);
+                    }
+                } else {
+                    ran = gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - 3, own1 + 3, 0, 0, alpha, beta) != 0;
+                    if (ran) gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own1, 0, 0, alpha, beta);
+                }
+                if (ran) { rest = 0; depth = 0; }                        // (two launches per piece: the newest iterate is back in `in`)
+                else triples_ok = false;                                 // the kernels do not apply to this grid: pairs from now on
+            }
             while (pair_split && rest >= 2) {
                 if (ends_first && rest == 4) {
                     // the last two pairs, ends first (depth is 4 here: this pair covers [own0 - 2, own1 + 2), the last [own0, own1))

@@ -236,6 +236,7 @@ public:
     long long wall_bytes_moved = 0;         // floats received through wallFixup so far x 4 (statistics)
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
     bool jacobi_ends_first = true;          // BQ_OPT_JACOBI_ENDS_FIRST
+    bool jacobi_triples = true;             // BQ_OPT_JACOBI_TRIPLES
     int shallow_blocking = 0;               // BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 require(), 2 also withGhosts() move only the planes asked for
     static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes

@@ -119,7 +119,7 @@ class BimocqGPUSolver:
     def setOption(self, option, value):
         """option 1 = BQ_OPT_KEEP_DMC_BORDER, 2 = BQ_OPT_REINIT_POLICY (0 every frame, 1 distortion-driven),
         3 = BQ_OPT_FULL_STATE, 4 = BQ_OPT_FUSED_HOUSEKEEPING, 5 = BQ_OPT_OVERLAP_EXCHANGES, 6 = BQ_OPT_SHALLOW_BLOCKING_EXCHANGE,
-        7 = BQ_OPT_JACOBI_ENDS_FIRST, 8 = BQ_OPT_PROFILE_PHASES, 9 = BQ_OPT_REINIT_MAX_TRAVEL (include/bimocq_solver.h)"""
+        7 = BQ_OPT_JACOBI_ENDS_FIRST, 8 = BQ_OPT_PROFILE_PHASES, 9 = BQ_OPT_REINIT_MAX_TRAVEL, 10 = BQ_OPT_JACOBI_TRIPLES (include/bimocq_solver.h)"""
         self.lib.bq_solver_set_option(self.s, option, value)
         self._check()
 

@@ -376,6 +376,11 @@ void gpu_jacobi_sweep_range(const float *in, const float *div, float *out, int n
  * to this grid -- nothing was launched and the caller falls back to gpu_jacobi_sweep_range. */
 int gpu_jacobi_sweep_pair_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
                                  int k0a, int k1a, int k0b, int k1b, float alpha, float beta);
+/* THREE sweeps in -> out in one launch on the local planes [k0a, k1a) and [k0b, k1b) (either may be empty), through the
+ * LDS-exchanged kernels (rows of 32 .. 512 floats): the pieces of a z-slab rank's pressure chunk.  `in` must be valid three
+ * planes beyond each range; same precondition as above.  Returns 1 when it ran, 0 when it does not apply (nothing launched). */
+int gpu_jacobi_sweep_triple_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                                   int k0a, int k1a, int k0b, int k1b, float alpha, float beta);
 /* exact sum r^2 (double) and max|r| of r = div - (sum6 p - 6p) over interior cells; blocking */
 void gpu_residual_norms(const float *div, const float *p, int ni, int nj, int nk,
                         double *sum_sq, float *max_abs);

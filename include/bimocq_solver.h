@@ -100,7 +100,13 @@ enum {
      * default and maximum T = the ghost depth G (what their ghost planes can serve); single GPU: default 0 (no such rule) --
      * give both the same T and they re-initialise on the same frames and produce the same fields
      * (tests/test_slab_multirank.py).  bq_solver_reinit_counts(s, 2) counts the re-initialisations this rule caused. */
-    BQ_OPT_REINIT_MAX_TRAVEL = 9
+    BQ_OPT_REINIT_MAX_TRAVEL = 9,
+    /* z-slab ranks, G = 8, 1 (default): the six sweeps of a pressure chunk that follow its overlapped first pair run as TWO
+     * fused triples (gpu_jacobi_sweep_triple_ranges: the LDS-exchanged three-sweep kernels on plane ranges) instead of three
+     * pairs -- with BQ_OPT_JACOBI_ENDS_FIRST both triples do the planes next to the slab ends first, the exchange for the next
+     * chunk starts there and the two interiors (and the next chunk's first interior) hide it.  Where the kernels do not apply
+     * (rows wider than 512 floats, ...) and with 0 the pairs run.  Same values either way. */
+    BQ_OPT_JACOBI_TRIPLES = 10
 };
 /* BQ_OPT_PROFILE_PHASES: milliseconds per phase summed over the steps since the last reset -- map update (DMC + RK3,
  * BimocqGPUSolver.cpp:136-139), advection with error compensation (:143-145), sources and forces (:157-177), projection

@@ -399,6 +399,29 @@ int gpu_jacobi_sweep_pair_ranges(const float *in, const float *div, float *out, 
     free(l1);
     return 1;
 }
+/* three sweeps, output on two plane ranges: L1 on the planes two beyond, L2 one beyond, L3 on the ranges themselves */
+int gpu_jacobi_sweep_triple_ranges(const float *in, const float *div, float *out, int ni, int nj, int nk,
+                                   int k0a, int k1a, int k0b, int k1b, float alpha, float beta)
+{
+    size_t n = (size_t)ni * nj * nk;
+    float *l1 = (float *)malloc(n * sizeof(float)), *l2 = (float *)malloc(n * sizeof(float));
+    if (!l1 || !l2) { free(l1); free(l2); return 0; }
+    memcpy(l1, in, n * sizeof(float));
+    memcpy(l2, in, n * sizeof(float));
+    const int r[2][2] = { { k0a, k1a }, { k0b, k1b } };
+    for (int lev = 0; lev < 3; lev++)
+        for (int a = 0; a < 2; a++) {
+            int k0 = r[a][0] < 0 ? 0 : r[a][0], k1 = r[a][1] > nk ? nk : r[a][1];
+            if (k0 >= k1) continue;
+            const int ext = 2 - lev;
+            const int e0 = k0 - ext < 0 ? 0 : k0 - ext, e1 = k1 + ext > nk ? nk : k1 + ext;
+            if (lev == 0) orc_jacobi_sweep_range(in, div, l1, ni, nj, nk, e0, e1, alpha, beta);
+            else if (lev == 1) orc_jacobi_sweep_range(l1, div, l2, ni, nj, nk, e0, e1, alpha, beta);
+            else orc_jacobi_sweep_range(l2, div, out, ni, nj, nk, e0, e1, alpha, beta);
+        }
+    free(l1); free(l2);
+    return 1;
+}
 void gpu_gradient(float *u, float *v, float *w, const float *p, int ni, int nj, int nk, float hr)
 {
     orc_gradient(u, p, ni + 1, nj, nk, 1, 0, 0, hr);

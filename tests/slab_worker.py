@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="BQ_OPT_OVERLAP_EXCHANGES")
     ap.add_argument("--shallow", type=int, default=0, help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE")
     ap.add_argument("--ends-first", type=int, default=1, help="BQ_OPT_JACOBI_ENDS_FIRST")
+    ap.add_argument("--triples", type=int, default=1, help="BQ_OPT_JACOBI_TRIPLES")
     ap.add_argument("--reserve-cus", type=int, default=0, help="FL_OPT_RESERVE_CUS (gpu backend): CU-masked compute stream")
     ap.add_argument("--policy", type=int, default=0, help="BQ_OPT_REINIT_POLICY: 1 = distortion-driven re-initialisation (maps live for several steps)")
     ap.add_argument("--travel-limit", type=int, default=0, help="BQ_OPT_REINIT_MAX_TRAVEL / oracle option 4 (policy 1): 0 = the rank's ghost depth")
@@ -110,6 +111,7 @@ def main():
     s.setOption(5, a.overlap)
     s.setOption(6, a.shallow)
     s.setOption(7, a.ends_first)
+    s.setOption(10, a.triples)
     if a.backend == "cpu":
         # the oracle library inside the CPU stand-in carries the slab context; the reference run below
         # uses the separately loaded liboracle.so, which stays single-domain

@@ -56,7 +56,7 @@ def test_multi_rank_bench_launches_itself():
     d = line["diagnostics"]
     assert len(d["per_rank"]) == 2 and d["comm_exposed_ms_per_step"] > 0
     assert d["phase_ms_per_step_slowest_rank"]["projection"] > 0
-    assert {"shallow_exchange_2", "ends_first_off", "reserve_cus_8", "reserve_cus_16"} <= set(line["extra"])
+    assert {"shallow_exchange_2", "ends_first_off", "jacobi_triples_off", "reserve_cus_8", "reserve_cus_16"} <= set(line["extra"])
 
 
 def test_emulated_rank_line_carries_phases_and_knob_legs():

@@ -391,6 +391,33 @@ def test_fused_four_sweep_lds_kernel(hip, ni, nj, nk, kc, sweeps, shape):
     bq.check()
 
 
+@pytest.mark.parametrize("ni,nj,nk", [(64, 48, 40), (256, 32, 30), (128, 37, 26), (512, 9, 24), (32, 8, 12), (264, 16, 40)])
+def test_fused_triple_on_plane_ranges(hip, ni, nj, nk):
+    """gpu_jacobi_sweep_triple_ranges: three sweeps in one launch, output restricted to two plane ranges (the LDS-exchanged
+    kernels, rows of one wave and rows of two float4 segments per lane): the ends of a slab chunk first, then its interior --
+    together the whole array -- against three oracle sweeps; planes outside the ranges stay untouched, the input is only read."""
+    import gpufluidsimulation_amd as bq
+    p0, div = F.scalar(ni, nj, nk, 0.3), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+    a, b = p0.copy(), p0.copy()
+    for _ in range(3):
+        oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+        a, b = b, a
+    want = a
+    lo, hi = 5, nk - 4
+    dp, dd = dev(p0, div)
+    (dout,) = dev(p0)
+    assert hip.gpu_jacobi_sweep_triple_ranges(dp.ptr, dd.ptr, dout.ptr, ni, nj, nk, 0, lo, hi, nk, ALPHA, BETA) == 1
+    part = dout.numpy().reshape(nk, nj, ni)
+    w3, p3 = want.reshape(nk, nj, ni), p0.reshape(nk, nj, ni)
+    assert F.same(part[:lo], w3[:lo]) and F.same(part[hi:], w3[hi:])
+    assert F.same(part[lo:hi], p3[lo:hi])
+    assert hip.gpu_jacobi_sweep_triple_ranges(dp.ptr, dd.ptr, dout.ptr, ni, nj, nk, lo, hi, 0, 0, ALPHA, BETA) == 1
+    assert F.same(dout.numpy(), want)
+    assert F.same(dp.numpy(), p0)
+    assert hip.fl_jacobi_kernel_name().decode() == ("jacobi_lds2seg_kernel" if ni > 256 else "jacobi_lds3_kernel")
+    bq.check()
+
+
 def test_fused_pair_ranges_reports_when_it_does_not_apply(hip):
     """rows that are not a multiple of 4 floats cannot take the fused kernel: 0 is returned and nothing is written"""
     import gpufluidsimulation_amd as bq

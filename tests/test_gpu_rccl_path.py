@@ -82,6 +82,14 @@ def test_tall_slabs_ends_first_chunks_over_the_rccl_branch(fake):
     rc, out = launch_worker(fake, 3, "--dims", 24, 20, 96, "--ghost", 6, "--steps", 2, "--iters", 40, "--dt-cells", 1.0)
     assert rc == 0, out
     assert out.count("mismatches=0") == 3
+    # G = 8 runs the chunk's last six sweeps as two ends-first triples (default, above); the pair schedule stays tested, and
+    # rows of two float4 segments per lane (jacobi_lds2seg_kernel on plane ranges)
+    rc, out = launch_worker(fake, 2, "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 2, "--iters", 60, "--triples", 0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch_worker(fake, 2, "--dims", 264, 16, 96, "--ghost", 8, "--steps", 2, "--iters", 44, "--dt-cells", 1.0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
 
 
 def test_reserved_cus_change_no_value_over_the_rccl_branch(fake):
@@ -175,7 +183,7 @@ def test_bench_gpus_2_runs_the_rccl_branch(fake, tmp_path):
         assert r["comm_waits_per_step"] > 0 and r["ghost_MB_sent_per_step"] > 0
         assert set(r["phase_ms_per_step"]) == {"maps", "advect_compensate", "forces", "projection", "accumulate_reinit"}
         assert r["phase_ms_per_step"]["projection"] > 0 and sum(r["phase_ms_per_step"].values()) <= 1.05 * r["ms_per_step"]
-    assert {"shallow_exchange_2", "ends_first_off", "reserve_cus_8", "reserve_cus_16"} <= set(b["extra"])
+    assert {"shallow_exchange_2", "ends_first_off", "jacobi_triples_off", "reserve_cus_8", "reserve_cus_16"} <= set(b["extra"])
     assert all(b["extra"][k]["value"] > 0 for k in ("shallow_exchange_2", "ends_first_off", "reserve_cus_8", "reserve_cus_16"))
     assert b["config"]["rccl_version"] is None or b["config"]["rccl_version"] > 0       # (the stand-in exports no ncclGetVersion)
     for f in sorted(os.listdir(one)):

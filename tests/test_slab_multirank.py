@@ -148,6 +148,14 @@ def test_tall_slabs_run_the_ends_first_chunks_cpu():
     rc, out = launch(2, "--backend", "cpu", "--dims", 24, 20, 64, "--ghost", 6, "--steps", 2, "--iters", 40, "--ends-first", 0)
     assert rc == 0, out                                  # BQ_OPT_JACOBI_ENDS_FIRST = 0: the plain chunk order stays tested
     assert out.count("mismatches=0") == 2
+    # G = 8: the six sweeps after a chunk's overlapped pair run as two triples (BQ_OPT_JACOBI_TRIPLES, default) -- ends first
+    # above; here with the ends-first order off, and with the triples off (the pair schedule stays tested)
+    rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 96, "--ghost", 8, "--steps", 2, "--iters", 36, "--dt-cells", 1.0, "--ends-first", 0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
+    rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 96, "--ghost", 8, "--steps", 2, "--iters", 36, "--dt-cells", 1.0, "--triples", 0)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 3
 
 
 def test_shallow_blocking_exchanges_cpu():
@@ -211,6 +219,12 @@ def test_three_ranks_gpu():
 def test_tall_slabs_run_the_ends_first_chunks_gpu():
     rc, out = launch(2, "--backend", "gpu", "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 3, "--iters", 60, threads=4)
     assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(2, "--backend", "gpu", "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 2, "--iters", 60, "--triples", 0, threads=4)
+    assert rc == 0, out                                  # the pair schedule (BQ_OPT_JACOBI_TRIPLES = 0)
+    assert out.count("mismatches=0") == 2
+    rc, out = launch(2, "--backend", "gpu", "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 2, "--iters", 60, "--ends-first", 0, threads=4)
+    assert rc == 0, out                                  # triples without the ends-first order
     assert out.count("mismatches=0") == 2
     rc, out = launch(3, "--backend", "gpu", "--dims", 24, 20, 96, "--ghost", 6, "--steps", 2, "--iters", 40, "--dt-cells", 1.0, threads=4)
     assert rc == 0, out
