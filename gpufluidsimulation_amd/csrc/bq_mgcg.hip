@@ -1465,7 +1465,7 @@ struct VCycleGraph {
     hipGraphExec_t exec = nullptr;
     const double *b = nullptr; double *x = nullptr, *residual = nullptr, *temp0 = nullptr;
     SCoarseLevelInfo levels[LEVEL_COUNT];
-    int levelnum = 0, fuse = 0, rows = 0, kchunk2 = 0, tile = 0;
+    int levelnum = 0, fuse = 0, rows = 0, kchunk = 0, kchunk2 = 0, tile = 0, cus = 0;
 };
 // the two cached graphs ([copy_b]) of the CURRENT context (bq_host.h: Runtime::mgcg_state)
 struct MgcgState { VCycleGraph vcgs[2]; };
@@ -1480,8 +1480,8 @@ static MgcgState &ms()
 static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
 {
     if (!c.exec || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
-    if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk2 != rt().opt_jacobi_kchunk2 ||
-        c.tile != rt().opt_mgcg_tile) return false;
+    if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk != rt().opt_jacobi_kchunk || c.kchunk2 != rt().opt_jacobi_kchunk2 ||
+        c.tile != rt().opt_mgcg_tile || c.cus != rt().num_cus) return false;
     for (int l = 0; l < levelnum; l++) {
         const SCoarseLevelInfo &p = c.levels[l], &q = L[l];
         if (p.ni != q.ni || p.nj != q.nj || p.nk != q.nk || p.number != q.number || p.alpha != q.alpha || p.beta != q.beta ||
@@ -1509,7 +1509,7 @@ static void v_cycle_replayed(const double *b, double *x, double *residual, const
         if (graph) (void)hipGraphDestroy(graph);
         if (!ok) { g_vcg.exec = nullptr; return; }           // the error is latched
         g_vcg.b = b; g_vcg.x = x; g_vcg.residual = residual; g_vcg.temp0 = temp0; g_vcg.levelnum = levelnum;
-        g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2;
+        g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk = rt().opt_jacobi_kchunk; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2; g_vcg.cus = rt().num_cus;
         g_vcg.tile = rt().opt_mgcg_tile;
         for (int l = 0; l < levelnum; l++) g_vcg.levels[l] = L[l];
     }
