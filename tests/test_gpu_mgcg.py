@@ -103,6 +103,34 @@ def test_mgcg_with_fused_smoothing_on_every_level(hip):
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
 
 
+def test_smoothing_lds_triples_on_random_shapes(hip):
+    """seeded sweep over row lengths 130 .. 256 (even), row / plane counts, chunk lengths and sweep counts for mg_lds3_kernel"""
+    import gpufluidsimulation_amd as bq
+    rng = np.random.default_rng(20260306)
+    for case in range(24):
+        ni = int(rng.integers(65, 129)) * 2
+        nj, nk = int(rng.integers(4, 30)), int(rng.integers(12, 40))
+        kc, iters = int(rng.integers(8, 20)), int(rng.choice([6, 10, 12, 14, 18, 32]))
+        n = ni * nj * nk
+        b = rng.standard_normal(n)
+        x0 = rng.standard_normal(n).reshape(nk, nj, ni)
+        t0 = np.zeros_like(x0)
+        t0[0], t0[-1], t0[:, 0], t0[:, -1], t0[:, :, 0], t0[:, :, -1] = x0[0], x0[-1], x0[:, 0], x0[:, -1], x0[:, :, 0], x0[:, :, -1]
+        x0, t0 = x0.ravel().copy(), t0.ravel().copy()
+        xr, tr = x0.copy(), t0.copy()
+        oracle().orc_mg_smooth(dp(xr), dp(b), dp(tr), -8.0, 1.0 / 6.0, ni, nj, nk, iters)
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, kc)
+        dx, db, dt = Dev(hip, x0), Dev(hip, b), Dev(hip, t0)
+        hip.gpu_smoothing_jacobi(dx.ptr, db.ptr, dt.ptr, -8.0, 1.0 / 6.0, ni, nj, nk, iters)
+        name = hip.fl_mg_smooth_kernel_name().decode()
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+        assert name == "mg_lds3_kernel", (case, ni, nj, nk, iters, name)
+        assert F.same(xr, dx.numpy()), (case, ni, nj, nk, kc, iters)
+    bq.check()
+
+
 @pytest.mark.parametrize("ni,nj,nk,levels", [(136, 24, 24, 2), (256, 16, 20, 2), (200, 12, 32, 3)])
 def test_mgcg_with_three_sweep_lds_smoother(hip, ni, nj, nk, levels):
     """the whole operator with level 0 smoothed by mg_lds3_kernel (forced on small grids through the chunk-length option):

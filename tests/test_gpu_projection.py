@@ -418,6 +418,39 @@ def test_fused_triple_on_plane_ranges(hip, ni, nj, nk):
     bq.check()
 
 
+def test_three_sweep_kernels_on_random_shapes_and_ranges(hip):
+    """seeded sweep over grid shapes, chunk lengths and plane ranges for the two three-sweep LDS kernels (rows of one float4
+    segment per lane and of two): whole arrays through gpu_jacobi_sweeps, then the same three sweeps as two range launches
+    (ends, interior) through gpu_jacobi_sweep_triple_ranges -- all against three oracle sweeps"""
+    import gpufluidsimulation_amd as bq
+    rng = np.random.default_rng(20260305)
+    for case in range(36):
+        wide = case % 3 == 2
+        ni = int(rng.integers(65, 129)) * 4 if wide else int(rng.integers(8, 65)) * 4
+        nj, nk = int(rng.integers(8, 40)), int(rng.integers(12, 44))
+        kc = int(rng.integers(8, 20))
+        p0, div = F.scalar(ni, nj, nk, 0.3 + 0.01 * case), F.scalar(ni, nj, nk, 1.1, amp=0.2)
+        a, b = p0.copy(), p0.copy()
+        for _ in range(3):
+            oracle().orc_jacobi_sweep(fp(a), fp(div), fp(b), ni, nj, nk, ALPHA, BETA)
+            a, b = b, a
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, kc)
+        dp, dd, dt = dev(p0, div, p0)
+        where = hip.gpu_jacobi_sweeps(dp.ptr, dd.ptr, dt.ptr, ni, nj, nk, 3, ALPHA, BETA)
+        name = hip.fl_jacobi_kernel_name().decode()
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+        assert name == ("jacobi_lds2seg_kernel" if wide else "jacobi_lds3_kernel"), (case, ni, nj, nk, name)
+        assert F.same(a, (dt if where else dp).numpy()), (case, ni, nj, nk, kc)
+        lo = int(rng.integers(0, nk // 2)); hi = int(rng.integers(max(lo, nk // 2), nk + 1))
+        dp2, dout2 = dev(p0, p0)
+        assert hip.gpu_jacobi_sweep_triple_ranges(dp2.ptr, dd.ptr, dout2.ptr, ni, nj, nk, 0, lo, hi, nk, ALPHA, BETA) == 1
+        assert hip.gpu_jacobi_sweep_triple_ranges(dp2.ptr, dd.ptr, dout2.ptr, ni, nj, nk, lo, hi, 0, 0, ALPHA, BETA) == 1
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+        assert F.same(a, dout2.numpy()), (case, ni, nj, nk, lo, hi)
+    bq.check()
+
+
 def test_fused_pair_ranges_reports_when_it_does_not_apply(hip):
     """rows that are not a multiple of 4 floats cannot take the fused kernel: 0 is returned and nothing is written"""
     import gpufluidsimulation_amd as bq
