@@ -327,3 +327,41 @@ def test_solver_reinit_every_frame_makes_maps_identity():
     assert np.array_equal(s.field("uinit"), s.field("uinit")) and np.isfinite(s.field("u")).all()
     assert abs(s.cfldt - (1.0 / N) / max(np.abs(s.field("v")).max(), 1e-4)) > 0     # cfldt came from the PREVIOUS velocities
     s.close()
+
+
+def test_fma_contraction_moves_the_fields_far_less_than_the_tolerance():
+    """VERDICT's one definitional freedom of the oracle: it is defined WITHOUT FMA contraction, nvcc's default (-fmad=true)
+    contracts the reference's float code wherever it likes.  Nobody can restate that compiler's choices, but the size of the
+    effect can be measured: the same C source built with -ffp-contract=fast (gcc fuses every a * b + c it finds) against the
+    contract build, 32^3 rising smoke, 200 Jacobi iterations, 20 steps -- the fields differ by < 5e-7 RMS (measured: 7e-8 for
+    rho, 4e-8 for v; 1.3e-7 at most over 60 steps), two orders below the north star's 1e-5."""
+    import os
+    import subprocess
+    import oracle_lib as O
+    if "fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("host CPU without FMA")
+    subprocess.check_call(["make", "-s", "-C", O.ORACLE_DIR, "fma"])
+    base = O.lib()
+    fma = C.CDLL(os.path.join(O.ORACLE_DIR, "_build", "liboracle_fma.so"))
+    for name, (res, args) in O._SIGS.items():
+        fn = getattr(fma, name)
+        fn.restype, fn.argtypes = res, args
+
+    def run(l, n=32, steps=20):
+        s = O.OracleSolver.__new__(O.OracleSolver)
+        s.l, s.ni, s.nj, s.nk = l, n, n, n
+        s.s = l.orc_solver_create(n, n, n, 1.0, 0.0, 1.0)
+        s.set_smoke(0.0, 1.0, [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)])
+        s.set_projection(200, 0.5)
+        for f in range(steps):
+            s.advance(f, 2.0 / n)
+        out = {k: s.field(k).astype(np.float64) for k in ("rho", "u", "v", "w")}
+        s.close()
+        return out
+
+    a, b = run(base), run(fma)
+    worst = 0.0
+    for k in a:
+        assert float(np.abs(a[k]).max()) > 0.05, k                   # a developed flow, not zeros
+        worst = max(worst, float(np.sqrt(np.mean((a[k] - b[k]) ** 2))))
+    assert 0.0 < worst < 5e-7, worst                               # it does change bits -- and stays two orders below 1e-5
