@@ -136,6 +136,7 @@ FL_OPT_MAP_QUARTER_FP32 = 13
 FL_OPT_MGCG_TILE = 14
 FL_OPT_PROFILE_COMM = 15
 FL_OPT_RESERVE_CUS = 16
+FL_OPT_MGCG_BOTTOM = 17
 
 
 class BimocqLibraryMissing(RuntimeError):

@@ -1127,6 +1127,94 @@ __global__ __launch_bounds__(256) void mg_prolong_block_kernel(double *__restric
                     x[id3(first[0] + hx, first[1] + hy, first[2] + hz, ni, nj)] += (double)lerp_f(ly[0][hy][hx], ly[1][hy][hx], w[2][hz]);
 }
 
+// ---- the bottom of the V-cycle in ONE launch ----------------------------------------------------------------------------
+// The two coarsest levels of a 256^3 pyramid (15^3 and 7^3) cost ~22 launches per V-cycle -- 8 + 8 + 1 tile-smoother launches,
+// residual, restriction, prolongation, clears -- each of them a few microseconds of latency around almost no work.  Both
+// levels fit one workgroup's LDS, so one block runs the whole sequence V_Cycle issues between "smooth level A 32 times" and
+// "smooth level A 4 times": A's 32 sweeps from a cleared x, its residual, the restriction to B, B's 32 sweeps from a cleared x,
+// the prolongation back and A's 4 sweeps, with __syncthreads where the reference has kernel boundaries.  Every value is the
+// per-cell expression of the kernel it replaces (mg_smooth_kernel, mg_residual_kernel, mg_restrict_kernel's eight samples,
+// mg_prolong_kernel) on the same operands: unclamped flat coarse look-ups that read 0 past the end (M4), float lerps (M2),
+// never-written boundary entries of r taken from memory as they are (M5).  Written back: x of both levels, b of B, r of A
+// (interior).  temp0 is not touched (V_Cycle clears what the next smoothing call uses of it).
+constexpr int kBottomA = 4096, kBottomB = 512;               // LDS capacity in cells of the two levels
+__global__ __launch_bounds__(1024) void mg_vbottom_kernel(const double *__restrict__ rhsA, double *__restrict__ xA_g, double *__restrict__ rA_g,
+                                                          double *__restrict__ bB_g, double *__restrict__ xB_g,
+                                                          int ni, int nj, int nk, int ci, int cj, int ck,
+                                                          double alphaA, double betaA, double alphaB, double betaB)
+{
+    __shared__ double xa[kBottomA], ta[kBottomA], ba[kBottomA], xb[kBottomB], tb[kBottomB], bb[kBottomB];
+    const int nA = ni * nj * nk, nB = ci * cj * ck;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int c = tid; c < nA; c += nth) { ba[c] = rhsA[c]; xa[c] = 0.0; ta[c] = 0.0; }
+    for (int c = tid; c < nB; c += nth) { xb[c] = 0.0; tb[c] = 0.0; }
+    __syncthreads();
+    // `iter` sweeps in -> out -> in ... on the interior of an n0 x n1 x n2 level (smoothing_jacobi: odd counts rounded up)
+    auto smooth = [&](double *x, double *t, const double *b, int n0, int n1, int n2, double alpha, double beta, int iter) {
+        if (iter % 2 == 1) iter += 1;
+        const int sj = n0, sk = n0 * n1, n = n0 * n1 * n2;
+        double *in = x, *out = t;
+        for (int s = 0; s < iter; s++) {
+            for (int c = tid; c < n; c += nth) {
+                const int i = c % n0, j = (c / n0) % n1, k = c / sk;
+                if (i > 0 && i < n0 - 1 && j > 0 && j < n1 - 1 && k > 0 && k < n2 - 1)
+                    out[c] = ((in[c - 1] + in[c + 1] + in[c - sj] + in[c + sj] + in[c - sk] + in[c + sk]) + alpha * b[c]) * beta;
+            }
+            __syncthreads();
+            double *sw = in; in = out; out = sw;
+        }
+    };
+    smooth(xa, ta, ba, ni, nj, nk, alphaA, betaA, 32);
+    // residual of A (interior) into ta, whose boundary entries take what L[A].r holds in memory (never written: M5)
+    {
+        const int sj = ni, sk = ni * nj;
+        for (int c = tid; c < nA; c += nth) {
+            const int i = c % ni, j = (c / ni) % nj, k = c / sk;
+            if (i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1) {
+                const double r = ba[c] - ((xa[c - 1] + xa[c + 1] + xa[c - sj] + xa[c + sj] + xa[c - sk] + xa[c + sk]) - xa[c] * 6);
+                ta[c] = r;
+                rA_g[c] = r;
+            } else ta[c] = rA_g[c];
+        }
+    }
+    __syncthreads();
+    // restriction A -> B: every coarse cell = mean of eight samples (mg_restrict_kernel's order)
+    for (int c = tid; c < nB; c += nth) {
+        const int i = c % ci, j = (c / ci) % cj, k = c / (ci * cj);
+        const float x0 = (float)(2 * i + 0.5), x1 = (float)(2 * i + 1.5);
+        const float y0 = (float)(2 * j + 0.5), y1 = (float)(2 * j + 1.5);
+        const float z0 = (float)(2 * k + 0.5), z1 = (float)(2 * k + 1.5);
+        const double v0 = sample_t<int>(ta, ni, nj, nA, x0, y0, z0), v1 = sample_t<int>(ta, ni, nj, nA, x0, y0, z1);
+        const double v2 = sample_t<int>(ta, ni, nj, nA, x0, y1, z0), v3 = sample_t<int>(ta, ni, nj, nA, x0, y1, z1);
+        const double v4 = sample_t<int>(ta, ni, nj, nA, x1, y0, z0), v5 = sample_t<int>(ta, ni, nj, nA, x1, y0, z1);
+        const double v6 = sample_t<int>(ta, ni, nj, nA, x1, y1, z0), v7 = sample_t<int>(ta, ni, nj, nA, x1, y1, z1);
+        const double v = (v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7) / 8;
+        bb[c] = v;
+        bB_g[c] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < nA; c += nth) ta[c] = 0.0;             // (V_Cycle clears temp0 before every smoothing call)
+    __syncthreads();
+    smooth(xb, tb, bb, ci, cj, ck, alphaB, betaB, 32);
+    for (int c = tid; c < nB; c += nth) xB_g[c] = xb[c];
+    // prolongation B -> A: fine interior += trilinear sample of the coarse correction (mg_prolong_kernel)
+    {
+        const int sk = ni * nj;
+        for (int c = tid; c < nA; c += nth) {
+            const int i = c % ni, j = (c / ni) % nj, k = c / sk;
+            if (i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1) {
+                const float px = (float)((double)((float)i / 2.f) - 0.5);
+                const float py = (float)((double)((float)j / 2.f) - 0.5);
+                const float pz = (float)((double)((float)k / 2.f) - 0.5);
+                xa[c] += sample_t<int>(xb, ci, cj, nB, px, py, pz);
+            }
+        }
+    }
+    __syncthreads();
+    smooth(xa, ta, ba, ni, nj, nk, alphaA, betaA, 4);
+    for (int c = tid; c < nA; c += nth) xA_g[c] = xa[c];
+}
+
 // gradient_kernel, double p (:1009-1023): the three components in one launch
 __global__ __launch_bounds__(256) void mg_gradient_kernel(float *__restrict__ u, float *__restrict__ v, float *__restrict__ w,
                                                           const double *__restrict__ p, int ni, int nj, int nk, double halfrdx)
@@ -1431,15 +1519,24 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
         if (mg_smooth_tiled(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return;
         mg_smooth(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x ? 3 : 1);
     };
-    for (int l = 0; l < levelnum - 1; l++) {
+    // the two coarsest levels in one launch where both fit a workgroup's LDS (FL_OPT_MGCG_BOTTOM)
+    const int lb = levelnum - 2;
+    const bool bottom = rt().opt_mgcg_bottom && rt().opt_mgcg_tile && levelnum >= 2 && L[lb].number <= kBottomA && L[lb + 1].number <= kBottomB &&
+                        L[lb].number > 0 && L[lb + 1].number > 0;
+    for (int l = 0; l < (bottom ? lb : levelnum - 1); l++) {
         smooth_level(l, 32, true);
         mg_residual(L[l].r, rhs(l), L[l].x, L[l].ni, L[l].nj, L[l].nk);
         mg_restrict_kernel<<<grid_of(L[l + 1].ni, L[l + 1].nj, L[l + 1].nk), kBlk, 0, st>>>(
             L[l].r, L[l + 1].b, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
         BQ_LAUNCH_CHECK("mg_restrict_kernel");
     }
-    smooth_level(levelnum - 1, 32, true);
-    for (int l = levelnum - 2; l >= 0; --l) {
+    if (bottom) {
+        mg_vbottom_kernel<<<1, 1024, 0, st>>>(rhs(lb), L[lb].x, L[lb].r, L[lb + 1].b, L[lb + 1].x, L[lb].ni, L[lb].nj, L[lb].nk,
+                                               L[lb + 1].ni, L[lb + 1].nj, L[lb + 1].nk, L[lb].alpha * scale[lb], L[lb].beta,
+                                               L[lb + 1].alpha * scale[lb + 1], L[lb + 1].beta);
+        BQ_LAUNCH_CHECK("mg_vbottom_kernel");
+    } else smooth_level(levelnum - 1, 32, true);
+    for (int l = bottom ? lb - 1 : levelnum - 2; l >= 0; --l) {
         // one thread per 2x2x2 block of fine cells where the coarse array is below 2^31 elements and every fine index is
         // exact in float (always, at these sizes); FL_OPT_MGCG_TILE = 0 keeps the one-cell form
         if (rt().opt_mgcg_tile && (long long)L[l + 1].ni * L[l + 1].nj * L[l + 1].nk < (1ll << 31) && L[l].ni < (1 << 22) &&
@@ -1465,7 +1562,7 @@ struct VCycleGraph {
     hipGraphExec_t exec = nullptr;
     const double *b = nullptr; double *x = nullptr, *residual = nullptr, *temp0 = nullptr;
     SCoarseLevelInfo levels[LEVEL_COUNT];
-    int levelnum = 0, fuse = 0, rows = 0, kchunk = 0, kchunk2 = 0, tile = 0, cus = 0;
+    int levelnum = 0, fuse = 0, rows = 0, kchunk = 0, kchunk2 = 0, tile = 0, cus = 0, bottom = 0;
 };
 // the two cached graphs ([copy_b]) of the CURRENT context (bq_host.h: Runtime::mgcg_state)
 struct MgcgState { VCycleGraph vcgs[2]; };
@@ -1481,7 +1578,7 @@ static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double
 {
     if (!c.exec || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
     if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk != rt().opt_jacobi_kchunk || c.kchunk2 != rt().opt_jacobi_kchunk2 ||
-        c.tile != rt().opt_mgcg_tile || c.cus != rt().num_cus) return false;
+        c.tile != rt().opt_mgcg_tile || c.cus != rt().num_cus || c.bottom != rt().opt_mgcg_bottom) return false;
     for (int l = 0; l < levelnum; l++) {
         const SCoarseLevelInfo &p = c.levels[l], &q = L[l];
         if (p.ni != q.ni || p.nj != q.nj || p.nk != q.nk || p.number != q.number || p.alpha != q.alpha || p.beta != q.beta ||
@@ -1509,7 +1606,7 @@ static void v_cycle_replayed(const double *b, double *x, double *residual, const
         if (graph) (void)hipGraphDestroy(graph);
         if (!ok) { g_vcg.exec = nullptr; return; }           // the error is latched
         g_vcg.b = b; g_vcg.x = x; g_vcg.residual = residual; g_vcg.temp0 = temp0; g_vcg.levelnum = levelnum;
-        g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk = rt().opt_jacobi_kchunk; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2; g_vcg.cus = rt().num_cus;
+        g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk = rt().opt_jacobi_kchunk; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2; g_vcg.cus = rt().num_cus; g_vcg.bottom = rt().opt_mgcg_bottom;
         g_vcg.tile = rt().opt_mgcg_tile;
         for (int l = 0; l < levelnum; l++) g_vcg.levels[l] = L[l];
     }

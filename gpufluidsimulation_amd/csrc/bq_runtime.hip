@@ -349,6 +349,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_MAP_QUARTER_FP32: g_rt.opt_map_quarter_fp32 = value != 0; break;
     case FL_OPT_MGCG_TILE:       g_rt.opt_mgcg_tile = value < 0 ? 0 : value; break;
     case FL_OPT_PROFILE_COMM:    g_rt.opt_profile_comm = value != 0; break;
+    case FL_OPT_MGCG_BOTTOM:     g_rt.opt_mgcg_bottom = value != 0; break;
     case FL_OPT_RESERVE_CUS: {
         const int k = value < 0 ? 0 : value;
         if (k == g_rt.opt_reserve_cus) break;
@@ -385,6 +386,7 @@ int fl_get_option(int option)
     case FL_OPT_MAP_QUARTER_FP32: return g_rt.opt_map_quarter_fp32;
     case FL_OPT_MGCG_TILE:       return g_rt.opt_mgcg_tile;
     case FL_OPT_PROFILE_COMM:    return g_rt.opt_profile_comm;
+    case FL_OPT_MGCG_BOTTOM:     return g_rt.opt_mgcg_bottom;
     case FL_OPT_RESERVE_CUS:     return g_rt.opt_reserve_cus;
     default: return -1;
     }

@@ -103,6 +103,22 @@ def test_mgcg_with_fused_smoothing_on_every_level(hip):
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
 
 
+@pytest.mark.parametrize("ni,nj,nk,levels", [(64, 64, 64, 4), (32, 32, 32, 3), (16, 16, 16, 2), (30, 14, 9, 2), (33, 31, 12, 3)])
+def test_mgcg_bottom_of_the_v_cycle_in_one_launch(hip, ni, nj, nk, levels):
+    """FL_OPT_MGCG_BOTTOM (default on): the two coarsest levels -- when they fit 4096 and 512 cells -- run as ONE launch
+    (mg_vbottom_kernel: 32 sweeps from a cleared x, residual, restriction, 32 sweeps, prolongation, 4 sweeps in LDS) instead of
+    ~22: level pairs (15^3, 7^3) below two finer levels, (15^3, 7^3) with the alpha * 8 of level 1, level 0 itself as the
+    upper one (its right-hand side is then the caller's residual), non-cubic and odd dims; bit-identical to the oracle, twice,
+    and the same with the fusion off."""
+    import gpufluidsimulation_amd as bq
+    test_mgcg_matches_oracle(hip, ni, nj, nk, levels, 2, 0.5)
+    hip.fl_set_option(bq._lib.FL_OPT_MGCG_BOTTOM, 0)
+    try:
+        test_mgcg_matches_oracle(hip, ni, nj, nk, levels, 2, 0.5)
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_BOTTOM, 1)
+
+
 def test_smoothing_lds_triples_on_random_shapes(hip):
     """seeded sweep over row lengths 130 .. 256 (even), row / plane counts, chunk lengths and sweep counts for mg_lds3_kernel"""
     import gpufluidsimulation_amd as bq
