@@ -666,12 +666,13 @@ __device__ __forceinline__ D4 jac_d4(D4 ce, D4 fr, D4 bk, D4 dn, D4 up, D4 adv, 
     return o;
 }
 
-template <int W, bool ZIN>
-__global__ __launch_bounds__((W + 4) * 64) void mg_lds3_kernel(const double *__restrict__ p, const double *__restrict__ div,
+template <int W, int S, bool ZIN>
+__global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const double *__restrict__ p, const double *__restrict__ div,
                                                                double *__restrict__ out, int nx, int ny, int nz,
                                                                int nby, int nblk, int kchunk, double alpha, double beta)
 {
-    constexpr int S = 3, H = 2, NW = W + 2 * H, P = 4;
+    static_assert(S == 2 || S == 3, "two or three sweeps per launch");
+    constexpr int H = S - 1, NW = W + 2 * H, P = 4;
     // [level][plane parity][row slot][segment][lane]; level 0 is the INPUT: a wave loads its own row only and takes the two
     // neighbouring rows of the centre plane out of LDS like those of the later levels (three row loads fewer per plane, 48
     // registers fewer: twelve waves per block fit three to a SIMD).  The outermost halo waves have no neighbour wave on their far
@@ -765,11 +766,19 @@ __global__ __launch_bounds__((W + 4) * 64) void mg_lds3_kernel(const double *__r
             const int ps = q - 1;                                                                                   \
             D4 v = jac_d4(L1[cs], nlo2, nhi2, L1[ds], L1[us], D[cs], beta, xlo, xhi, first, last);                  \
             if (ps < kA || ps >= kB || (EDGE && rowb)) v = L1[cs];                                                  \
-            L2[cs] = v;                                                                                             \
-            if (SM >= 3) { nlo3 = get(lds[2][(q - 2) & 1], rlo); nhi3 = get(lds[2][(q - 2) & 1], rhi); }            \
-            put(lds[2][ps & 1], v);                                                                                 \
+            if constexpr (S == 2) {     /* the last level: store */                                               \
+                if (ps >= kbeg && ps < kend && row_in) {                                                            \
+                    const unsigned pk = pstride * (unsigned)ps;                                                     \
+                    st_d2<2>(v.a, ro, voA, pk);                                                                     \
+                    if (okB) st_d2<2>(v.b, ro, voB, pk);                                                            \
+                }                                                                                                   \
+            } else {                                                                                                \
+                L2[cs] = v;                                                                                         \
+                if (SM >= 3) { nlo3 = get(lds[S - 1][(q - 2) & 1], rlo); nhi3 = get(lds[S - 1][(q - 2) & 1], rhi); } \
+                put(lds[S - 1][ps & 1], v);                                                                         \
+            }                                                                                                       \
         }                                                                                                           \
-        if (SM >= 3) {      /* third sweep on plane q - 2 */                                                        \
+        if (S >= 3 && SM >= 3) {      /* third sweep on plane q - 2 */                                                        \
             constexpr int cs = MG_SL4(T, -2), us = MG_SL4(T, -1), ds = MG_SL4(T, -3);                                \
             const int ps = q - 2;                                                                                   \
             if (ps >= kbeg && ps < kend) {                                                                          \
@@ -1149,22 +1158,47 @@ __global__ __launch_bounds__(1024) void mg_vbottom_kernel(const double *__restri
     for (int c = tid; c < nA; c += nth) { ba[c] = rhsA[c]; xa[c] = 0.0; ta[c] = 0.0; }
     for (int c = tid; c < nB; c += nth) { xb[c] = 0.0; tb[c] = 0.0; }
     __syncthreads();
-    // `iter` sweeps in -> out -> in ... on the interior of an n0 x n1 x n2 level (smoothing_jacobi: odd counts rounded up)
-    auto smooth = [&](double *x, double *t, const double *b, int n0, int n1, int n2, double alpha, double beta, int iter) {
+    // which of this thread's cells (tid, tid + 1024, ...) are interior cells: worked out once, not in each of the 68 sweeps
+    constexpr int MA = kBottomA / 1024;
+    bool innerA[MA];
+#pragma unroll
+    for (int m = 0; m < MA; m++) {
+        const int c = tid + m * 1024;
+        const int i = c % ni, j = (c / ni) % nj, k = c / (ni * nj);
+        innerA[m] = c < nA && i > 0 && i < ni - 1 && j > 0 && j < nj - 1 && k > 0 && k < nk - 1;
+    }
+    bool innerB;
+    {
+        const int i = tid % ci, j = (tid / ci) % cj, k = tid / (ci * cj);
+        innerB = tid < nB && i > 0 && i < ci - 1 && j > 0 && j < cj - 1 && k > 0 && k < ck - 1;
+    }
+    // `iter` sweeps in -> out -> in ... on the interior of a level (smoothing_jacobi: odd counts rounded up)
+    auto smoothA = [&](int iter) {
         if (iter % 2 == 1) iter += 1;
-        const int sj = n0, sk = n0 * n1, n = n0 * n1 * n2;
-        double *in = x, *out = t;
+        const int sj = ni, sk = ni * nj;
+        double *in = xa, *out = ta;
         for (int s = 0; s < iter; s++) {
-            for (int c = tid; c < n; c += nth) {
-                const int i = c % n0, j = (c / n0) % n1, k = c / sk;
-                if (i > 0 && i < n0 - 1 && j > 0 && j < n1 - 1 && k > 0 && k < n2 - 1)
-                    out[c] = ((in[c - 1] + in[c + 1] + in[c - sj] + in[c + sj] + in[c - sk] + in[c + sk]) + alpha * b[c]) * beta;
+#pragma unroll
+            for (int m = 0; m < MA; m++) {
+                const int c = tid + m * 1024;
+                if (innerA[m]) out[c] = ((in[c - 1] + in[c + 1] + in[c - sj] + in[c + sj] + in[c - sk] + in[c + sk]) + alphaA * ba[c]) * betaA;
             }
             __syncthreads();
             double *sw = in; in = out; out = sw;
         }
     };
-    smooth(xa, ta, ba, ni, nj, nk, alphaA, betaA, 32);
+    auto smoothB = [&](int iter) {
+        if (iter % 2 == 1) iter += 1;
+        const int sj = ci, sk = ci * cj;
+        double *in = xb, *out = tb;
+        for (int s = 0; s < iter; s++) {
+            const int c = tid;
+            if (innerB) out[c] = ((in[c - 1] + in[c + 1] + in[c - sj] + in[c + sj] + in[c - sk] + in[c + sk]) + alphaB * bb[c]) * betaB;
+            __syncthreads();
+            double *sw = in; in = out; out = sw;
+        }
+    };
+    smoothA(32);
     // residual of A (interior) into ta, whose boundary entries take what L[A].r holds in memory (never written: M5)
     {
         const int sj = ni, sk = ni * nj;
@@ -1195,7 +1229,7 @@ __global__ __launch_bounds__(1024) void mg_vbottom_kernel(const double *__restri
     __syncthreads();
     for (int c = tid; c < nA; c += nth) ta[c] = 0.0;             // (V_Cycle clears temp0 before every smoothing call)
     __syncthreads();
-    smooth(xb, tb, bb, ci, cj, ck, alphaB, betaB, 32);
+    smoothB(32);
     for (int c = tid; c < nB; c += nth) xB_g[c] = xb[c];
     // prolongation B -> A: fine interior += trilinear sample of the coarse correction (mg_prolong_kernel)
     {
@@ -1211,7 +1245,7 @@ __global__ __launch_bounds__(1024) void mg_vbottom_kernel(const double *__restri
         }
     }
     __syncthreads();
-    smooth(xa, ta, ba, ni, nj, nk, alphaA, betaA, 4);
+    smoothA(4);
     for (int c = tid; c < nA; c += nth) xA_g[c] = xa[c];
 }
 
@@ -1320,9 +1354,12 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
             const int s_begin = s;
             long long launches = 0;
             bool planned = false;
-            // three sweeps per launch through mg_lds3_kernel where it applies (rows of 130 .. 256 doubles, chunks of >= 24 planes
-            // at one block per CU; FL_OPT_JACOBI_ROWS = 5 keeps it off for A/B timing): as many triples as leave an even
-            // number of launches in total, so that the newest iterate still ends in x -- 32 sweeps = 8 triples + 4 pairs
+            // three (and two) sweeps per launch through mg_lds3_kernel where it applies (rows of 130 .. 256 doubles, chunks of >= 24
+            // planes at one block per CU; FL_OPT_JACOBI_ROWS = 5 keeps it off for A/B timing): as many triples as leave an even
+            // number of launches in total, so that the newest iterate still ends in x, the rest as pairs through the same
+            // kernel -- 4 sweeps = 2 pairs.  A call that starts from a cleared x (V_Cycle's way down) is free of the parity rule:
+            // its first launch does not read its input, so with an odd number of launches it writes straight into x --
+            // 32 sweeps = 10 triples + 1 pair.
             if (vec == 2 && ni >= 130 && ni <= 256 && nj >= 4 && nk >= 12 && rt().opt_jacobi_rows != 5 && cleared) {
                 // FL_OPT_JACOBI_KCHUNK = 14: blocks of 4 output rows (8 waves) instead of 8 (12 waves), for A/B timing
                 const int LW = rt().opt_jacobi_kchunk == 14 ? 4 : 8;
@@ -1330,27 +1367,34 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
                 int nbzl = std::max(1, rt().num_cus / nbyl);
                 int kcl = (nk + nbzl - 1) / nbzl;
                 if (rt().opt_jacobi_kchunk2 > 0) kcl = rt().opt_jacobi_kchunk2;
-                // A call that starts from a cleared x (V_Cycle's way down) is free of the parity rule: its first launch does not
-                // read its input, so with an odd number of launches it writes straight into x -- 32 sweeps = 10 triples + 1 pair.
-                int triples = 0;
+                int triples = -1;
                 if (kcl >= (rt().opt_jacobi_kchunk2 > 0 ? 8 : 24))
-                    for (int a = (iter - s) / 3; a > 0 && !triples; a--) {
+                    for (int a = (iter - s) / 3; a >= 0 && triples < 0; a--) {
                         const int rest = iter - s - 3 * a;
                         if (rest % 2 == 0 && (zin || (rest / 2 + a) % 2 == 0)) triples = a;
                     }
-                if (triples && zin && ((iter - s - 3 * triples) / 2 + triples) % 2 == 1) { double *t2 = in; in = out; out = t2; }
-                nbzl = (nk + kcl - 1) / kcl;
-                const int nblk = nbyl * nbzl, gridl = 8 * ((nblk + 7) / 8);
-                for (int t = 0; t < triples; t++) {
-#define MG_L3(WV, Z) mg_lds3_kernel<WV, Z><<<gridl, (WV + 4) * 64, 0, rt().compute>>>(in, b, out, ni, nj, nk, nbyl, nblk, kcl, alpha, beta)
-                    if (LW == 4) { if (zin) MG_L3(4, true); else MG_L3(4, false); }
-                    else         { if (zin) MG_L3(8, true); else MG_L3(8, false); }
+                if (triples >= 0) {
+                    const int pairs = (iter - s - 3 * triples) / 2;
+                    if (zin && (pairs + triples) % 2 == 1) { double *t2 = in; in = out; out = t2; }
+                    nbzl = (nk + kcl - 1) / kcl;
+                    const int nblk = nbyl * nbzl, gridl = 8 * ((nblk + 7) / 8);
+                    for (int t = 0; t < triples + pairs; t++) {
+                        const bool three = t < triples;
+#define MG_L3(WV, SV, Z) mg_lds3_kernel<WV, SV, Z><<<gridl, (WV + 2 * (SV - 1)) * 64, 0, rt().compute>>>(in, b, out, ni, nj, nk, nbyl, nblk, kcl, alpha, beta)
+                        if (three) {
+                            if (LW == 4) { if (zin) MG_L3(4, 3, true); else MG_L3(4, 3, false); }
+                            else         { if (zin) MG_L3(8, 3, true); else MG_L3(8, 3, false); }
+                        } else {
+                            if (LW == 4) { if (zin) MG_L3(4, 2, true); else MG_L3(4, 2, false); }
+                            else         { if (zin) MG_L3(8, 2, true); else MG_L3(8, 2, false); }
+                        }
 #undef MG_L3
-                    zin = false;
-                    double *t2 = in; in = out; out = t2;
-                    s += 3; launches++;
+                        zin = false;
+                        double *t2 = in; in = out; out = t2;
+                        s += three ? 3 : 2; launches++;
+                    }
+                    if (triples + pairs) { BQ_LAUNCH_CHECK("mg_lds3_kernel"); rt().mg_smooth_kernel = "mg_lds3_kernel"; planned = true; }
                 }
-                if (triples) { BQ_LAUNCH_CHECK("mg_lds3_kernel"); rt().mg_smooth_kernel = "mg_lds3_kernel"; planned = true; }
             }
             // (without triples the pairs come in twos, so that the newest iterate ends in x; with them the plan above has
             // settled the parity and the remaining pairs are counted one by one)

@@ -236,7 +236,7 @@ def test_smoothing_fused_pairs(hip, ni, nj, nk, iters):
 def test_smoothing_lds_triples(hip, ni, nj, nk, kc, iters):
     """mg_lds3_kernel (round 3): THREE fp64 smoothing sweeps per launch, a wave owns one row of 130 .. 256 doubles as two
     coalesced segments (the x-neighbours across the seam by wave rotation), the neighbouring rows of the intermediate levels
-    come out of LDS; as many triples as leave an even number of launches, pairs for the rest.  Against the oracle's
+    come out of LDS; as many triples as leave an even number of launches, pairs (the same kernel with two levels) for the rest.  Against the oracle's
     sweep-by-sweep smoothing: rows that end inside segment B, row counts that leave the last block partly outside the grid,
     chunks whose warm-up planes reach below plane 0, a cleared input (the ZIN form)."""
     import gpufluidsimulation_amd as bq
@@ -263,7 +263,7 @@ def test_smoothing_lds_triples(hip, ni, nj, nk, kc, iters):
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
     bq.check()
-    assert name == ("mg_lds3_kernel" if iters >= 6 else "mg_lean2r_kernel"), name
+    assert name == "mg_lds3_kernel", name                # (4 sweeps: two pair launches of the same kernel)
     assert name2 == "mg_lean2r_kernel", name2
     assert F.same(xr, dx.numpy())
     assert F.same(xr, dx2.numpy())
