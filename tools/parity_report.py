@@ -22,12 +22,19 @@ def main():
     ap.add_argument("--n", type=int, nargs="+", default=[32, 48])
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--fl-opt", action="append", default=[], metavar="K=V",
+                    help="fl_set_option(K, V) before the runs, e.g. 9=8: FL_OPT_JACOBI_KCHUNK2 = 8 puts the LDS-exchanged "
+                         "three-sweep Jacobi kernel to work on these small grids")
     a = ap.parse_args()
     import gpufluidsimulation_amd as bq
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     from oracle_lib import OracleSolver
     lib = bq.hip_lib()
-    out = {"scene": "rising smoke (SURVEY 8d): L=1, dt=2h, nu=0, blend=1, one source at step 0, Jacobi %d iterations, halfrdx 0.5" % a.iters,
+    assert lib.fl_init(0) == 0
+    for kv in a.fl_opt:
+        k, v = kv.split("=")
+        lib.fl_set_option(int(k), int(v))
+    out = {"options": a.fl_opt, "scene": "rising smoke (SURVEY 8d): L=1, dt=2h, nu=0, blend=1, one source at step 0, Jacobi %d iterations, halfrdx 0.5" % a.iters,
            "steps": a.steps, "tolerance_rms_abs": 1e-5, "grids": {}}
     for n in a.n:
         em = [(0.5, 0.2, 0.5, 0.1, 1.0, 1.0, 0.0, 1)]
@@ -40,6 +47,7 @@ def main():
                 print(f"[parity_report] {n}^3 step {f + 1}/{a.steps}", file=sys.stderr, flush=True)
         ref = {k: o.field(k).astype(np.float64) for k in ("rho", "u", "v", "w")}
         exact = {k: ex.field(k).astype(np.float64) for k in ref}
+        jacobi_kernel = (lib.fl_jacobi_kernel_name() or b"").decode()
         ex.close()
         lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 1)
         fa = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0); fa.setSmoke(0.0, 1.0, em); fa.setProjection(a.iters, 0.5)
@@ -57,6 +65,7 @@ def main():
                 g[name][k] = {"rms_abs": rms, "rms_rel": rms / base if base else 0.0, "max_abs": float(np.abs(fields[k] - ref[k]).max()),
                               "bit_identical": bool(np.array_equal(fields[k], ref[k], equal_nan=True)),
                               "all_finite": bool(np.isfinite(fields[k]).all() and np.isfinite(ref[k]).all())}
+        g["jacobi_kernel"] = jacobi_kernel
         out["grids"][f"{n}^3"] = g
     bq.check()
     print(json.dumps(out, indent=1))
