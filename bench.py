@@ -81,6 +81,9 @@ def parse():
                     help="BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 = blocking ghost refreshes, 2 = also the overlapped ones move only "
                          "the planes asked for (N > 1)")
     ap.add_argument("--no-ends-first", action="store_true", help="BQ_OPT_JACOBI_ENDS_FIRST = 0 (N > 1)")
+    ap.add_argument("--reinit-policy", type=int, choices=[0, 1], default=0,
+                    help="BQ_OPT_REINIT_POLICY: 0 = both map sets re-initialised every frame (the reference's GPU solver, the headline); "
+                         "1 = distortion-driven re-initialisation with the CPU solver's thresholds (SURVEY 8f N2)")
     ap.add_argument("--reserve-cus", type=int, default=0, metavar="K",
                     help="FL_OPT_RESERVE_CUS: the compute stream leaves K compute units (K / 8 per XCD) to the halo stream's "
                          "RCCL kernels")
@@ -317,6 +320,9 @@ def main():
     # buffer the reference updates is updated, including the *Prev state that nothing reads when blend == 1.  The
     # library's default elides that dead state; its rate is reported next to the headline as "extra".
     s.setOption(3, 1)
+    if args.reinit_policy:
+        s.setOption(2, 1)                       # BQ_OPT_REINIT_POLICY (before the first advance)
+        args.no_extra = True                    # the extra legs belong to the every-frame policy
     if args.shallow_exchange:
         s.setOption(6, args.shallow_exchange)
     if args.no_ends_first:
@@ -509,10 +515,12 @@ def main():
         "config": {"workload": f"bimocq3D {grid_txt} {scene_txt}, " + ("MAC_REFLECTION scheme (two projections per step), " if args.scheme == "reflection" else "")
                                + (f"fp64 multigrid-CG projection ({args.mg_iters} outer iterations, 6 levels), fp32 advection, "
                                   if mg else f"{args.jacobi_iters} Jacobi iters, fp32, ")
-                               + f"halfrdx {args.halfrdx}, reinit every step"
+                               + f"halfrdx {args.halfrdx}, " + ("distortion-driven reinit (BQ_OPT_REINIT_POLICY = 1)" if args.reinit_policy else "reinit every step")
                                + (", density dumped every frame (async, per slab)" if args.dump else ""),
                    "grid_per_gpu": [nx, ny, own_planes], "global_grid": [nx, ny, nz_global], "dt": dt,
                    "nonfinite_velocity_seen": bool(lib.fl_nonfinite_seen(0)),
+                   "map_reinitialisations": ({"velocity": s.reinitCounts()[0], "scalar": s.reinitCounts()[1], "forced_by_travel_limit": s.forcedReinits(),
+                                              "steps_run": frame} if args.reinit_policy else None),
                    "comm_size": comm_size, "rccl_version": (int(lib.fl_comm_rccl_version()) or None) if world > 1 else None,
                    "reserved_cus": args.reserve_cus,
                    "comm_per_step_rank0": None if not multi else {
