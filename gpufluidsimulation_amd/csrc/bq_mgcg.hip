@@ -666,12 +666,32 @@ __device__ __forceinline__ D4 jac_d4(D4 ce, D4 fr, D4 bk, D4 dn, D4 up, D4 adv, 
     return o;
 }
 
-template <int W, int S, bool ZIN>
+// mg_residual_kernel's expression (update_residual_kernel, :1251-1261) on the four cells of a lane
+__device__ __forceinline__ D4 res_d4(D4 ce, D4 fr, D4 bk, D4 dn, D4 up, D4 b, bool first, bool last)
+{
+    const double leftA = lane_up(ce.a.b);
+    const double rightA = lane_rol(first ? ce.b.a : ce.a.a);
+    const double leftB = lane_ror(last ? ce.a.b : ce.b.b);
+    const double rightB = lane_down(ce.b.a);
+    D4 o;
+    o.a.a = b.a.a - ((leftA + ce.a.b + fr.a.a + bk.a.a + dn.a.a + up.a.a) - ce.a.a * 6);
+    o.a.b = b.a.b - ((ce.a.a + rightA + fr.a.b + bk.a.b + dn.a.b + up.a.b) - ce.a.b * 6);
+    o.b.a = b.b.a - ((leftB + ce.b.b + fr.b.a + bk.b.a + dn.b.a + up.b.a) - ce.b.a * 6);
+    o.b.b = b.b.b - ((ce.b.a + rightB + fr.b.b + bk.b.b + dn.b.b + up.b.b) - ce.b.b * 6);
+    return o;
+}
+
+// RES (with S = 3): the third level is not a sweep but the RESIDUAL of the second -- rout = b - A x'' on interior cells
+// (mg_residual_kernel's expression), x'' itself is stored to `out` as the level is made: the last launch of V_Cycle's 32 sweeps
+// and the residual that follows it in one pass over the arrays.
+template <int W, int S, bool ZIN, bool RES = false>
 __global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const double *__restrict__ p, const double *__restrict__ div,
                                                                double *__restrict__ out, int nx, int ny, int nz,
-                                                               int nby, int nblk, int kchunk, double alpha, double beta)
+                                                               int nby, int nblk, int kchunk, double alpha, double beta,
+                                                               double *__restrict__ rout = nullptr)
 {
     static_assert(S == 2 || S == 3, "two or three sweeps per launch");
+    static_assert(!RES || (S == 3 && !ZIN), "the residual is the third level of a two-sweep launch");
     constexpr int H = S - 1, NW = W + 2 * H, P = 4;
     // [level][plane parity][row slot][segment][lane]; level 0 is the INPUT: a wave loads its own row only and takes the two
     // neighbouring rows of the centre plane out of LDS like those of the later levels (three row loads fewer per plane, 48
@@ -701,7 +721,7 @@ __global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const d
     const bool row_in = !halo && j >= 1 && j <= ny - 2;
     const bool rowb = j <= 0 || j >= ny - 1;
     const unsigned bytes = (unsigned)nx * (unsigned)ny * (unsigned)nz * 8u;
-    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes);
+    const v4i rp = make_rsrc4(p, bytes), rd = make_rsrc4(div, bytes), ro = make_rsrc4(out, bytes), rr = make_rsrc4(RES ? rout : out, bytes);
     // byte offsets of this lane's columns in its own row and (outermost halo waves) in the row on the far side
     const unsigned row_own = (unsigned)nx * (unsigned)min(max(j, 0), ny - 1);
     const unsigned row_far = (unsigned)nx * (unsigned)min(max(low_end ? j - 1 : j + 1, 0), ny - 1);
@@ -714,6 +734,7 @@ __global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const d
     auto put = [&](v2d (*buf)[2][64], D4 v) { buf[wv][0][lane] = v2d{v.a.a, v.a.b}; buf[wv][1][lane] = v2d{v.b.a, v.b.b}; };
     auto get = [&](v2d (*buf)[2][64], int r) -> D4 { const v2d u = buf[r][0][lane], w = buf[r][1][lane]; return D4{D2{u.x, u.y}, D2{w.x, w.y}}; };
     const D4 zero = D4{D2{0.0, 0.0}, D2{0.0, 0.0}};
+    auto adv = [&](D4 d) -> D4 { return RES ? D4{D2{alpha * d.a.a, alpha * d.a.b}, D2{alpha * d.b.a, alpha * d.b.b}} : d; };
     auto ld_own = [&](v4i rs, unsigned pp) -> D4 { return D4{ld_d2(rs, voA, pp), ld_d2(rs, voB, pp)}; };
     auto ld_far = [&](unsigned pp) -> D4 { return D4{ld_d2(rp, vfA, pp), ld_d2(rp, vfB, pp)}; };
 
@@ -753,9 +774,11 @@ __global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const d
         if (q < kA || q >= kB) {                                                                                    \
             L1[ic] = L0[ic];                                                                                        \
         } else {                                                                                                    \
-            D[ic].a.a = alpha * D[ic].a.a; D[ic].a.b = alpha * D[ic].a.b;                                           \
-            D[ic].b.a = alpha * D[ic].b.a; D[ic].b.b = alpha * D[ic].b.b;                                           \
-            L1[ic] = jac_d4(L0[ic], fr0, bk0, L0[im], L0[in_], D[ic], beta, xlo, xhi, first, last);                 \
+            if (!RES) {     /* (RES keeps b itself for the residual and multiplies at each use: the same product) */ \
+                D[ic].a.a = alpha * D[ic].a.a; D[ic].a.b = alpha * D[ic].a.b;                                       \
+                D[ic].b.a = alpha * D[ic].b.a; D[ic].b.b = alpha * D[ic].b.b;                                       \
+            }                                                                                                       \
+            L1[ic] = jac_d4(L0[ic], fr0, bk0, L0[im], L0[in_], adv(D[ic]), beta, xlo, xhi, first, last);            \
             if (EDGE && rowb) L1[ic] = L0[ic];                                                                      \
         }                                                                                                           \
         /* (the later levels' neighbour rows are fetched level by level: six rows in flight at once cost 25 registers too many) */ \
@@ -764,15 +787,16 @@ __global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const d
         if (SM >= 2) {      /* second sweep on plane q - 1 */                                                       \
             constexpr int cs = MG_SL4(T, -1), us = MG_SL4(T, 0), ds = MG_SL4(T, -2);                                 \
             const int ps = q - 1;                                                                                   \
-            D4 v = jac_d4(L1[cs], nlo2, nhi2, L1[ds], L1[us], D[cs], beta, xlo, xhi, first, last);                  \
+            D4 v = jac_d4(L1[cs], nlo2, nhi2, L1[ds], L1[us], adv(D[cs]), beta, xlo, xhi, first, last);             \
             if (ps < kA || ps >= kB || (EDGE && rowb)) v = L1[cs];                                                  \
-            if constexpr (S == 2) {     /* the last level: store */                                               \
+            if constexpr (S == 2 || RES) {     /* the last sweep: store (RES: planes one beyond the chunk feed the residual only) */ \
                 if (ps >= kbeg && ps < kend && row_in) {                                                            \
                     const unsigned pk = pstride * (unsigned)ps;                                                     \
                     st_d2<2>(v.a, ro, voA, pk);                                                                     \
                     if (okB) st_d2<2>(v.b, ro, voB, pk);                                                            \
                 }                                                                                                   \
-            } else {                                                                                                \
+            }                                                                                                       \
+            if constexpr (S == 3) {                                                                                 \
                 L2[cs] = v;                                                                                         \
                 if (SM >= 3) { nlo3 = get(lds[S - 1][(q - 2) & 1], rlo); nhi3 = get(lds[S - 1][(q - 2) & 1], rhi); } \
                 put(lds[S - 1][ps & 1], v);                                                                         \
@@ -782,12 +806,23 @@ __global__ __launch_bounds__((W + 2 * (S - 1)) * 64) void mg_lds3_kernel(const d
             constexpr int cs = MG_SL4(T, -2), us = MG_SL4(T, -1), ds = MG_SL4(T, -3);                                \
             const int ps = q - 2;                                                                                   \
             if (ps >= kbeg && ps < kend) {                                                                          \
-                D4 v = jac_d4(L2[cs], nlo3, nhi3, L2[ds], L2[us], D[cs], beta, xlo, xhi, first, last);              \
-                if (EDGE && rowb) v = L2[cs];                                                                       \
-                if (row_in) {                                                                                       \
+                if constexpr (!RES) {                                                                               \
+                    D4 v = jac_d4(L2[cs], nlo3, nhi3, L2[ds], L2[us], D[cs], beta, xlo, xhi, first, last);          \
+                    if (EDGE && rowb) v = L2[cs];                                                                   \
+                    if (row_in) {                                                                                   \
+                        const unsigned pk = pstride * (unsigned)ps;                                                 \
+                        st_d2<2>(v.a, ro, voA, pk);                                                                 \
+                        if (okB) st_d2<2>(v.b, ro, voB, pk);                                                        \
+                    }                                                                                               \
+                } else if (row_in) {    /* r = b - ((l + r + f + b + d + u) - 6 c): interior cells only */          \
+                    const D4 rv = res_d4(L2[cs], nlo3, nhi3, L2[ds], L2[us], D[cs], first, last);                   \
                     const unsigned pk = pstride * (unsigned)ps;                                                     \
-                    st_d2<2>(v.a, ro, voA, pk);                                                                     \
-                    if (okB) st_d2<2>(v.b, ro, voB, pk);                                                            \
+                    if (!xlo) st_d2<2>(rv.a, rr, voA, pk);                                                          \
+                    else bq_buffer_store_x2(__builtin_bit_cast(v2f, rv.a.b), rr, (int)(voA + 8u), (int)pk, 2);      \
+                    if (okB) {                                                                                      \
+                        if (!xhi) st_d2<2>(rv.b, rr, voB, pk);                                                      \
+                        else bq_buffer_store_x2(__builtin_bit_cast(v2f, rv.b.a), rr, (int)voB, (int)pk, 2);         \
+                    }                                                                                               \
                 }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
@@ -1296,8 +1331,11 @@ static void mg_zero_shell(double *p, int ni, int nj, int nk)
 // clear: the clears V_Cycle issues before the call, left to this function -- bit 0: temp counts as cleared, bit 1: x does.
 // Where the lean kernel runs at least two launches they shrink to zeroed faces (every interior cell of both buffers is
 // overwritten before it is read) and the first launch does not read x; otherwise both arrays are cleared in full.
-static void mg_smooth(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter, int clear = 0)
+// resid (optional): where the caller wants r = b - A x of the smoothed x next; *resid_done tells whether the last launch wrote it
+static void mg_smooth(double *x, const double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter, int clear = 0,
+                      double *resid = nullptr, bool *resid_done = nullptr)
 {
+    if (resid_done) *resid_done = false;
     if (iter % 2 == 1) iter += 1;
     const size_t cells = (size_t)ni * nj * nk;
     if (ni < 3 || nj < 3 || nk < 3) {                   // no interior: every sweep is a no-op
@@ -1380,6 +1418,14 @@ static void mg_smooth(double *x, const double *b, double *temp, double alpha, do
                     const int nblk = nbyl * nbzl, gridl = 8 * ((nblk + 7) / 8);
                     for (int t = 0; t < triples + pairs; t++) {
                         const bool three = t < triples;
+                        // the last launch, when it is a pair and the caller wants the residual next: two sweeps + the residual
+                        if (!three && t == triples + pairs - 1 && resid && resid_done && LW == 8 && !zin && out == x) {
+                            mg_lds3_kernel<8, 3, false, true><<<gridl, 12 * 64, 0, rt().compute>>>(in, b, out, ni, nj, nk, nbyl, nblk, kcl, alpha, beta, resid);
+                            *resid_done = true;
+                            double *t2 = in; in = out; out = t2;
+                            s += 2; launches++;
+                            continue;
+                        }
 #define MG_L3(WV, SV, Z) mg_lds3_kernel<WV, SV, Z><<<gridl, (WV + 2 * (SV - 1)) * 64, 0, rt().compute>>>(in, b, out, ni, nj, nk, nbyl, nblk, kcl, alpha, beta)
                         if (three) {
                             if (LW == 4) { if (zin) MG_L3(4, 3, true); else MG_L3(4, 3, false); }
@@ -1559,17 +1605,20 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
     // rest of temp0 is later seen only at boundary indices of the level-0 product dir*A(dir), where dir
     // is 0: no value depends on it.)
     // smoothing call of V_Cycle: clear temp0 (and x on the way down), `iter` sweeps
-    auto smooth_level = [&](int l, int iter, bool clear_x) {
-        if (mg_smooth_tiled(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return;
-        mg_smooth(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x ? 3 : 1);
+    // resid: the residual array the caller computes next (the way down); returns true when the smoothing's last launch wrote it
+    auto smooth_level = [&](int l, int iter, bool clear_x, double *resid = nullptr) -> bool {
+        if (mg_smooth_tiled(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x)) return false;
+        bool done = false;
+        mg_smooth(L[l].x, rhs(l), temp0, L[l].alpha * scale[l], L[l].beta, L[l].ni, L[l].nj, L[l].nk, iter, clear_x ? 3 : 1, resid, &done);
+        return done;
     };
     // the two coarsest levels in one launch where both fit a workgroup's LDS (FL_OPT_MGCG_BOTTOM)
     const int lb = levelnum - 2;
     const bool bottom = rt().opt_mgcg_bottom && rt().opt_mgcg_tile && levelnum >= 2 && L[lb].number <= kBottomA && L[lb + 1].number <= kBottomB &&
                         L[lb].number > 0 && L[lb + 1].number > 0;
     for (int l = 0; l < (bottom ? lb : levelnum - 1); l++) {
-        smooth_level(l, 32, true);
-        mg_residual(L[l].r, rhs(l), L[l].x, L[l].ni, L[l].nj, L[l].nk);
+        if (!smooth_level(l, 32, true, rt().opt_mgcg_bottom ? L[l].r : nullptr))
+            mg_residual(L[l].r, rhs(l), L[l].x, L[l].ni, L[l].nj, L[l].nk);
         mg_restrict_kernel<<<grid_of(L[l + 1].ni, L[l + 1].nj, L[l + 1].nk), kBlk, 0, st>>>(
             L[l].r, L[l + 1].b, L[l].ni, L[l].nj, L[l].nk, L[l + 1].ni, L[l + 1].nj, L[l + 1].nk);
         BQ_LAUNCH_CHECK("mg_restrict_kernel");

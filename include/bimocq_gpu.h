@@ -318,7 +318,8 @@ enum {
     FL_OPT_MGCG_BOTTOM     = 17,/* 1 (default): the two coarsest levels of the multigrid V-cycle -- when both fit one workgroup's
                                  * LDS (4096 and 512 cells: 15^3 and 7^3 of a 256^3 pyramid) -- run as ONE launch
                                  * (mg_vbottom_kernel: 32 sweeps, residual, restriction, 32 sweeps, prolongation, 4 sweeps)
-                                 * instead of ~22.  0: one launch per operator.  Same values either way.            */
+                                 * instead of ~22, and the last launch of level 0's 32 sweeps also writes the residual that
+                                 * follows.  0: one launch per operator.  Same values either way.                   */
     FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
                                  * contract.  1: the caller vouches that every value of the map arrays it passes to the
                                  * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map

@@ -156,8 +156,12 @@ def test_mgcg_with_three_sweep_lds_smoother(hip, ni, nj, nk, levels):
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 2)
     hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 12)
     try:
+        # (default: that last pair launch also writes the residual the restriction reads -- mg_lds3_kernel<8, 3, false, true>)
+        test_mgcg_matches_oracle(hip, ni, nj, nk, levels, 2, 0.5)
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_BOTTOM, 0)     # ... and with the residual as a launch of its own
         test_mgcg_matches_oracle(hip, ni, nj, nk, levels, 2, 0.5)
     finally:
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_BOTTOM, 1)
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
 
