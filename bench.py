@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--mg-iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the two 'extra' legs (dead-state elision, fast lerps)")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="N = 1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure the Jacobi "
+                         "launch's HBM traffic in this run; roofline.traffic then comes from the committed passes (--no-extra implies it)")
     ap.add_argument("--cpu-n", type=int, default=128, help="grid of the bounded CPU sample")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--shallow-exchange", type=int, nargs="?", const=1, default=0,
@@ -202,6 +205,51 @@ def pmc_traffic(dims, kernel):
         if key in table and table[key].get("bytes_per_launch"):
             return table[key]["bytes_per_launch"]
     return None
+
+
+def measure_traffic(n, kernel_hint, timeout_s=120):
+    """HBM bytes per Jacobi launch measured NOW: two child processes under rocprofv3 --pmc (FETCH_SIZE, then WRITE_SIZE --
+    separate passes, as the microarchitecture guide prescribes) run tools/jacobi_tune.py on an n^3 grid with the library's
+    default launch configuration; FETCH_SIZE is doubled (gfx950 counts 128-byte requests at 64 bytes), both are in KB.
+    Returns (bytes_per_launch, {details}) or (None, {reason}).  The parent (this process) is idle meanwhile."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, {"reason": "rocprofv3 not on PATH"}
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, {"reason": "this process already runs under a profiler"}
+    env = dict(os.environ, TMPDIR="/tmp", BQ_COPY_STREAM_CUS="0")       # (a CU-masked copy stream crashed rocprofv3 --pmc at exit)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    means = {}
+    work = tempfile.mkdtemp(prefix="bq_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "jacobi_tune.py"), "--n", str(n), "--variants", "4:0:0", "--sweeps", "21", "--reps", "1"]
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, {"reason": f"rocprofv3 --pmc {counter} pass timed out after {timeout_s} s"}
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, {"reason": f"rocprofv3 --pmc {counter} left no counter file (rc {r.returncode})"}
+            by = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == counter and "jacobi" in row.get("Kernel_Name", ""):
+                    by.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", "").replace("bq::", ""), []).append(float(row["Counter_Value"]))
+            if not by:
+                return None, {"reason": f"no Jacobi kernel in the {counter} pass"}
+            # the fused kernel the default configuration launches: the one with the most launches in the child's loop
+            name = max(by, key=lambda k_: len(by[k_]))
+            means[counter] = (name, sum(by[name]) / len(by[name]), len(by[name]))
+        if means["FETCH_SIZE"][0] != means["WRITE_SIZE"][0]:
+            return None, {"reason": "the two passes saw different kernels"}
+        fetch_b, write_b = means["FETCH_SIZE"][1] * 1024.0 * 2.0, means["WRITE_SIZE"][1] * 1024.0
+        return int(fetch_b + write_b), {"kernel": means["FETCH_SIZE"][0], "fetch_bytes": int(fetch_b), "write_bytes": int(write_b),
+                                        "launches": means["FETCH_SIZE"][2], "hint": kernel_hint}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def main():
@@ -590,13 +638,24 @@ def main():
         kname = (lib.fl_jacobi_kernel_name() or b"").decode() or "jacobi_march2_kernel"
         kname = kname if spl > 1.5 else "jacobi_march_kernel"
         traffic = pmc_traffic((nx, ny, nz_global), kname) if not multi else None
+        traffic_source = ("profiles/jacobi_pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this "
+                          "grid (FETCH_SIZE x 2 as the microarchitecture guide prescribes for gfx950 + WRITE_SIZE, "
+                          "separate passes, tools/jacobi_pmc.sh) -- NOT measured in this run") if traffic else None
+        if rank == 0 and world == 1 and not emul and not args.no_extra and not args.no_measure_traffic and nx == ny == nz_global and spl > 1.5:
+            live, how = measure_traffic(nx, kname)
+            if live:
+                traffic_committed = traffic
+                traffic = live
+                traffic_source = (f"MEASURED IN THIS RUN: two child passes of rocprofv3 --pmc (FETCH_SIZE x 2 for gfx950, WRITE_SIZE) over "
+                                  f"{how['launches']} launches of {how['kernel']} in tools/jacobi_tune.py --n {nx} (same library, same launch "
+                                  f"configuration); the committed passes say {traffic_committed}")
+            else:
+                traffic_source = (traffic_source or "none") + f" [live measurement not available: {how['reason']}]"
         resident = compulsory <= INFINITY_CACHE_BYTES
         line["roofline"] = {"bound": "hbm", "kernel": kname,
                             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                             "traffic": traffic,
-                            "traffic_source": ("profiles/jacobi_pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this "
-                                               "grid (FETCH_SIZE x 2 as the microarchitecture guide prescribes for gfx950 + WRITE_SIZE, "
-                                               "separate passes, tools/jacobi_pmc.sh) -- NOT measured in this run") if traffic else None,
+                            "traffic_source": traffic_source,
                             "frac_traffic": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                             "compulsory_bytes_per_launch": int(compulsory),
                             "working_set": ("infinity-cache" if resident else "hbm"),

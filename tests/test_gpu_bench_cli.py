@@ -36,6 +36,10 @@ def test_single_gpu_line_has_the_contract_fields():
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["frac"] < 1.0 and rf["compulsory_bytes_per_launch"] == 12 * 64 ** 3 and "algorithmic_equiv" in rf
+    # the launch's HBM traffic is measured IN THIS RUN (two rocprofv3 --pmc child passes), not looked up: at least the bytes a
+    # launch has to move, at most a few times that on this tiny grid
+    assert rf["traffic_source"].startswith("MEASURED IN THIS RUN"), rf["traffic_source"]
+    assert 0.9 * rf["compulsory_bytes_per_launch"] < rf["traffic"] < 6 * rf["compulsory_bytes_per_launch"], rf["traffic"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
     # the second kernel family against ITS bounds: phase times of the step and the gather family's object
     ph, rg = line["phase_ms_per_step"], line["roofline_gather"]
