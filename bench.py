@@ -227,9 +227,17 @@ def measure_traffic(n, kernel_hint, timeout_s=120):
             out = os.path.join(work, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "run", "--",
                    sys.executable, os.path.join(ROOT, "tools", "jacobi_tune.py"), "--n", str(n), "--variants", "4:0:0", "--sweeps", "21", "--reps", "1"]
+            # its own process group, so that a pass that overruns is ended together with the program rocprofv3 started
+            r = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+                r.wait(timeout=timeout_s)
             except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(r.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                r.wait()
                 return None, {"reason": f"rocprofv3 --pmc {counter} pass timed out after {timeout_s} s"}
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
