@@ -201,7 +201,10 @@ def pmc_traffic(dims, kernel):
             table = json.load(f)
     except Exception:
         return None
-    for key in (f"{nx}_{kernel}", f"{nx}_fused2r" if kernel == "jacobi_march2r_kernel" else f"{nx}_fused2"):
+    keys = [f"{nx}_{kernel}"]
+    if kernel in ("jacobi_march2r_kernel", "jacobi_march2_kernel"):     # (the round-1 passes were filed under these names)
+        keys.append(f"{nx}_fused2r" if kernel == "jacobi_march2r_kernel" else f"{nx}_fused2")
+    for key in keys:
         if key in table and table[key].get("bytes_per_launch"):
             return table[key]["bytes_per_launch"]
     return None
@@ -621,9 +624,14 @@ def main():
         compulsory = 24.0 * cells
         alg = compulsory * spl
         ach = compulsory / (us * 1e-6) / 1e9
-        line["roofline"] = {"bound": "hbm", "kernel": ("mg_smooth2_kernel" if lib.fl_get_option(bq._lib.FL_OPT_JACOBI_ROWS) in (3, 8) else "mg_lean2r_kernel") + " (level 0)", "achieved": round(ach, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                            "frac_traffic": None, "compulsory_bytes_per_launch": int(compulsory),
+        mgk = (lib.fl_mg_smooth_kernel_name() or b"").decode() or "mg_lean2r_kernel"
+        mg_traffic = pmc_traffic((nx, ny, nz_global), mgk)
+        line["roofline"] = {"bound": "hbm", "kernel": mgk + " (level 0 of the V-cycle: three / two fp64 smoothing sweeps per launch)", "achieved": round(ach, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": mg_traffic,
+                            "traffic_source": ("profiles/jacobi_pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this grid "
+                                               "(FETCH_SIZE x 2 for gfx950 + WRITE_SIZE, separate passes) -- NOT measured in this run") if mg_traffic else None,
+                            "frac_traffic": round(mg_traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if mg_traffic else None,
+                            "compulsory_bytes_per_launch": int(compulsory),
                             "algorithmic_equiv": {"bytes_per_launch": int(alg), "achieved": round(alg / (us * 1e-6) / 1e9, 1),
                                                   "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                   "note": "24 B/cell/sweep x sweeps per launch: what unfused sweeps would move"},
