@@ -210,6 +210,90 @@ def pmc_traffic(dims, kernel):
     return None
 
 
+def pmc_pass(counters, child_args, timeout_s=150):
+    """One child process under `rocprofv3 --pmc <counters> --kernel-trace`: returns ({kernel: {counter: [values], "ns": [durations]}},
+    None) or (None, reason).  The child runs in its own process group and is ended with it on a timeout; the program follows
+    `--` directly."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler"
+    env = dict(os.environ, TMPDIR="/tmp", BQ_COPY_STREAM_CUS="0")       # (a CU-masked copy stream crashed rocprofv3 --pmc at exit)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    work = tempfile.mkdtemp(prefix="bq_pmc_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", work, "-o", "run", "--", sys.executable, *child_args]
+        r = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            r.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(r.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            r.wait()
+            return None, f"rocprofv3 --pmc {' '.join(counters)} timed out after {timeout_s} s"
+        files = glob.glob(os.path.join(work, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, f"rocprofv3 --pmc {' '.join(counters)} left no counter file (rc {r.returncode})"
+        out = {}
+        for row in csv.DictReader(open(files[0])):
+            name = row.get("Kernel_Name", "").split("(")[0].replace("void ", "").replace("bq::exact::", "").replace("bq::", "")
+            d = out.setdefault(name, {})
+            d.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if row["Counter_Name"] == counters[0]:
+                d.setdefault("ns", []).append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        return out, None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+GATHER_BYTES_PER_VOXEL = {"advect_kernel": 20, "compensate_kernel": 24, "cumulate_kernel": 24}     # per sampled field (SURVEY 8d)
+
+
+def measure_gather_counters(n):
+    """The nine-point gather family against ITS bounds, measured now: three child passes over a few full steps at n^3
+    (tools/step_child.py) -- SQ_INSTS_VALU, TA_BUSY_avr, TCP_TCC_READ_REQ_sum, one counter block per pass.
+    valu_issue_busy = instructions x 4 cycles / (1024 SIMDs x duration x 2.4 GHz); ta_busy = TA_BUSY_avr / (duration x 2.4 GHz);
+    L1 -> L2 bytes = requests x 64 B over the kernel's algorithmic bytes.  Single-field and two-field launches apart, the
+    identity-map accumulate (a light kernel of its own kind) left out."""
+    child = [os.path.join(ROOT, "tools", "step_child.py"), "--n", str(n), "--steps", "3", "--warmup", "2", "--jacobi-iters", "6"]
+    res = {}
+    for counter in ("SQ_INSTS_VALU", "TA_BUSY_avr", "TCP_TCC_READ_REQ_sum"):
+        got, why = pmc_pass([counter], child)
+        if got is None:
+            return None, why
+        res[counter] = got
+    GHZ = 2.4
+    fam = {"single_field": {"valu": [], "ta": [], "l2": []}, "two_field": {"valu": [], "ta": [], "l2": []}}
+    for name, d in res["SQ_INSTS_VALU"].items():
+        base = name.split("<")[0]
+        if base not in GATHER_BYTES_PER_VOXEL or "fast::" in name:
+            continue
+        tpl = [t.strip() for t in name[name.index("<") + 1:name.rindex(">")].split(",")]
+        nf = int(tpl[3])
+        if base == "cumulate_kernel" and tpl[4] == "true":      # ID: the identity-map accumulate
+            continue
+        ns = sum(d["ns"]) / len(d["ns"])
+        key = "two_field" if nf == 2 else "single_field"
+        fam[key]["valu"].append(sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"]) * 4.0 / (1024.0 * ns * GHZ))
+        ta = res["TA_BUSY_avr"].get(name)
+        if ta:
+            fam[key]["ta"].append((sum(ta["TA_BUSY_avr"]) / len(ta["TA_BUSY_avr"])) / ((sum(ta["ns"]) / len(ta["ns"])) * GHZ))
+        l2 = res["TCP_TCC_READ_REQ_sum"].get(name)
+        if l2:
+            alg = GATHER_BYTES_PER_VOXEL[base] * nf * float(n) ** 3
+            fam[key]["l2"].append(sum(l2["TCP_TCC_READ_REQ_sum"]) / len(l2["TCP_TCC_READ_REQ_sum"]) * 64.0 / alg)
+    if not fam["single_field"]["valu"]:
+        return None, "no gather kernel in the counter passes"
+    rng = lambda v: [round(min(v), 3), round(max(v), 3)] if v else None
+    return {"valu_issue_busy": {k: rng(v["valu"]) for k, v in fam.items()}, "ta_busy": {k: rng(v["ta"]) for k, v in fam.items()},
+            "l1_to_l2_bytes_over_algorithmic": {k: rng(v["l2"]) for k, v in fam.items()},
+            "kernels_seen": {k: len(v["valu"]) for k, v in fam.items()}, "clock_assumed_ghz": GHZ}, None
+
+
 def measure_traffic(n, kernel_hint, timeout_s=120):
     """HBM bytes per Jacobi launch measured NOW: two child processes under rocprofv3 --pmc (FETCH_SIZE, then WRITE_SIZE --
     separate passes, as the microarchitecture guide prescribes) run tools/jacobi_tune.py on an n^3 grid with the library's
@@ -712,6 +796,17 @@ def main():
                          "ta_busy": [0.74, 0.80], "l1_to_l2_bytes_over_algorithmic": 3.2,
                          "issue_floor_cycles_per_node_wave": 3800},
             "note": "measured in a separate leg of min(steps, 10) steps after the timed region (event pairs per phase)"}
+        # ... and the family's counters measured in THIS run (three rocprofv3 --pmc child passes over a few full steps on this
+        # grid); the committed ones above stay beside them
+        if rank == 0 and not args.no_measure_traffic and nx == ny == nz_global and nx <= 256:
+            live, why = measure_gather_counters(nx)
+            if live:
+                live["source"] = ("MEASURED IN THIS RUN: three child passes of rocprofv3 --pmc (SQ_INSTS_VALU; TA_BUSY_avr; TCP_TCC_READ_REQ_sum) "
+                                  f"over 5 steps of tools/step_child.py --n {nx} (same library; 6 Jacobi iterations per step -- the gather "
+                                  "launches are the same)")
+                line["roofline_gather"]["counters_live"] = live
+            else:
+                line["roofline_gather"]["counters_live"] = {"source": f"not available: {why}"}
     # ---- the one-GPU point of the 512^3 strong-scaling curve (N > 1 runs ONE 512^3 grid in N slabs; this run's headline is
     # config 3's 256^3): a short leg of the same scene at 512^3 on this GPU, so that SCALE's N >= 2 values have their anchor ----
     if rank == 0 and world == 1 and not emul and not args.no_extra and args.scene == "smoke" and args.scheme == "bimocq" and not mg \

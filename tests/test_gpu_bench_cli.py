@@ -45,6 +45,11 @@ def test_single_gpu_line_has_the_contract_fields():
     ph, rg = line["phase_ms_per_step"], line["roofline_gather"]
     assert set(ph) == {"maps", "advect_compensate", "forces", "projection", "accumulate_reinit"} and ph["advect_compensate"] > 0
     assert rg["frac"] < 0.5 and "NOT this run" in rg["counters"]["source"] and rg["ms_per_step"] == ph["advect_compensate"]
+    # ... and its counters measured in THIS run (three rocprofv3 --pmc child passes): VALU issue and texture-addresser busy fractions
+    cl = rg["counters_live"]
+    assert cl["source"].startswith("MEASURED IN THIS RUN"), cl["source"]
+    assert 0.05 < cl["valu_issue_busy"]["single_field"][0] <= cl["valu_issue_busy"]["single_field"][1] < 1.3
+    assert 0.05 < cl["ta_busy"]["single_field"][1] < 1.3 and cl["l1_to_l2_bytes_over_algorithmic"]["single_field"][1] > 0.5
 
 
 def test_multi_rank_bench_launches_itself():
