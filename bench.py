@@ -219,7 +219,7 @@ def pmc_pass(counters, child_args, timeout_s=150):
         return None, "rocprofv3 not on PATH"
     if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process already runs under a profiler"
-    env = dict(os.environ, TMPDIR="/tmp", BQ_COPY_STREAM_CUS="0")       # (a CU-masked copy stream crashed rocprofv3 --pmc at exit)
+    env = dict(os.environ, TMPDIR="/tmp")       # (the children run the product's stream set-up: CU-masked copy stream, released at exit by the library itself)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     work = tempfile.mkdtemp(prefix="bq_pmc_", dir="/tmp")
@@ -304,7 +304,7 @@ def measure_traffic(n, kernel_hint, timeout_s=120):
         return None, {"reason": "rocprofv3 not on PATH"}
     if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, {"reason": "this process already runs under a profiler"}
-    env = dict(os.environ, TMPDIR="/tmp", BQ_COPY_STREAM_CUS="0")       # (a CU-masked copy stream crashed rocprofv3 --pmc at exit)
+    env = dict(os.environ, TMPDIR="/tmp")       # (the children run the product's stream set-up: CU-masked copy stream, released at exit by the library itself)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     means = {}
@@ -851,9 +851,8 @@ def main():
             print("[bench] WARNING: a NaN or an Inf appeared in the velocity field during this run (fl_nonfinite_seen): the "
                   "timings are those of a broken simulation", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
-    # streams, events and cached graphs are released while the HIP runtime is still whole (under rocprofv3 the runtime's own
-    # exit-time teardown of the CU-masked copy stream crashed after the profile had been written)
-    lib.fl_shutdown()
+    # (no explicit fl_shutdown: the library releases its streams, events and cached graphs itself at process exit --
+    # fl_shutdown_all, registered by fl_init and by gpufluidsimulation_amd._lib)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ HIP_SIGS = {
     "fl_context_destroy": (None, [VP]),
     "fl_init": (c_i, [c_i]),
     "fl_shutdown": (None, []),
+    "fl_shutdown_all": (None, []),
     "fl_malloc": (VP, [C.c_size_t]),
     "fl_free": (None, [VP]),
     "fl_memset": (None, [VP, c_i, C.c_size_t]),
@@ -159,6 +160,11 @@ def hip_lib():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _hip = lib
+        # The library registers the same teardown with the C runtime's atexit; interpreter shutdown comes first, while
+        # every Python-side owner of device memory is still alive and the HIP runtime is whole (include/bimocq_gpu.h:
+        # fl_shutdown_all).
+        import atexit
+        atexit.register(lib.fl_shutdown_all)
     return _hip
 
 

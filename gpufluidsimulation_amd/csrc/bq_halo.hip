@@ -106,6 +106,12 @@ void halo_release_state(Runtime &r)
     r.halo_state = nullptr;
 }
 
+void halo_abandon_comm(Runtime &r)
+{
+    HaloState *h = static_cast<HaloState *>(r.halo_state);
+    if (h) h->comm = nullptr;
+}
+
 static void compute_waits_for(hipEvent_t done)
 {
     Runtime &r = rt();

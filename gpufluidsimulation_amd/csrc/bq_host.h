@@ -70,6 +70,7 @@ int  comm_ranks();
 void mgcg_release_graph();              // bq_mgcg.hip: drop the cached V-cycle graphs of the current context (fl_free / fl_shutdown)
 void mgcg_release_state(Runtime &r);    // ... and free the per-context state itself (fl_shutdown)
 void halo_release_state(Runtime &r);    // bq_halo.hip
+void halo_abandon_comm(Runtime &r);     // bq_halo.hip: forget the communicator without destroying it (process exit)
 void project_release_state(Runtime &r); // bq_project.hip
 // bq_project.hip: FL_OPT_PROFILE_JACOBI spans -- an event pair around a loop of sweep launches on the compute
 // stream, summed by fl_jacobi_profile().  profile_begin returns false when profiling is off.

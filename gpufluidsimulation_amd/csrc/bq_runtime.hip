@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace bq {
 
@@ -18,6 +19,24 @@ namespace bq {
 static Runtime g_default_rt;
 static thread_local Runtime *t_current = nullptr;
 static std::mutex g_mu;
+
+// Every context that holds streams (fl_init succeeded, fl_shutdown not yet run).  Process exit releases them through
+// shutdown_all_at_exit below: the HIP runtime's own exit-time teardown of a stream created with
+// hipExtStreamCreateWithCUMask (the copy stream; the compute stream under FL_OPT_RESERVE_CUS) ran after the profiler's
+// finalisation and crashed inside __cxa_finalize in round 3 (two traces, both from processes that left the masked stream
+// alive).  The handler is registered with atexit() at the end of the FIRST successful fl_init, i.e. after the runtime's
+// lazily created singletons that stream creation touches have registered their destructors -- exit handlers run in reverse
+// order of registration, so the library's streams, events, graphs and workspaces are gone while the runtime is still whole.
+static std::vector<Runtime *> g_live;
+static std::once_flag g_exit_once;
+static bool g_exiting = false;          // set by the exit handler: nothing re-creates streams behind it
+static void note_live(Runtime *r, bool live)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t a = 0; a < g_live.size(); a++)
+        if (g_live[a] == r) { if (!live) g_live.erase(g_live.begin() + a); return; }
+    if (live) g_live.push_back(r);
+}
 
 Runtime &rt() { return t_current ? *t_current : g_default_rt; }
 #define g_rt (::bq::rt())
@@ -32,7 +51,14 @@ void latch(int code, const char *what, const char *detail)
 
 bool ensure_ready(const char *op)
 {
-    if (g_rt.ready) return true;
+    if (g_rt.ready) {
+        // the context's device must be the thread's HIP device: a context of another device made on this thread
+        // (fl_context_create) or a foreign hipSetDevice would otherwise silently misplace allocations and launches
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != g_rt.device) (void)hipSetDevice(g_rt.device);
+        return true;
+    }
+    if (g_exiting) { latch(FL_ERR_NO_DEVICE, op, "the process is exiting: the library has released its streams"); return false; }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (fl_init(dev) != FL_OK) { (void)op; return false; }
@@ -129,7 +155,27 @@ int fl_init(int device)
     }
     g_rt.device = device;
     g_rt.ready = true;
+    bq::note_live(&g_rt, true);
+    std::call_once(bq::g_exit_once, [] { (void)atexit([] { bq::g_exiting = true; fl_shutdown_all(); }); });
     return FL_OK;
+}
+
+// Release every live context (the default one and those of fl_context_create): streams, events, cached graphs, workspaces.
+// Registered with atexit() by the first fl_init; a host may call it itself (idempotent).  A communicator still alive at this
+// point is abandoned, not destroyed: its peers may be gone already and ncclCommDestroy could wait for them.
+void fl_shutdown_all(void)
+{
+    std::vector<bq::Runtime *> live;
+    { std::lock_guard<std::mutex> lk(bq::g_mu); live = bq::g_live; }
+    bq::Runtime *prev = bq::t_current;
+    for (bq::Runtime *r : live) {
+        bq::t_current = r == &bq::g_default_rt ? nullptr : r;
+        if (!g_rt.ready) continue;
+        (void)hipSetDevice(g_rt.device);
+        bq::halo_abandon_comm(g_rt);
+        fl_shutdown();
+    }
+    bq::t_current = prev;
 }
 
 void fl_shutdown(void)
@@ -153,15 +199,25 @@ void fl_shutdown(void)
     g_rt.pinned = nullptr; g_rt.pinned_bytes = 0;
     g_rt.compute = nullptr; g_rt.halo = nullptr;
     g_rt.ready = false; g_rt.device = -1;
+    bq::note_live(&g_rt, false);
 }
 
 // ---- contexts -------------------------------------------------------------------------------------------------------
 struct fl_context { bq::Runtime rt; };
 
+// back on the caller's context: the thread's HIP device follows it (fl_init / fl_shutdown of another context moved it)
+static void restore_device_of_current()
+{
+    const bq::Runtime &r = bq::rt();
+    if (r.ready) (void)hipSetDevice(r.device);
+}
+
 fl_context *fl_context_create(int device)
 {
     fl_context *c = new fl_context();
     bq::Runtime *prev = bq::t_current;
+    int dev_before = -1;
+    if (hipGetDevice(&dev_before) != hipSuccess) dev_before = -1;
     bq::t_current = &c->rt;
     const int rc = fl_init(device);
     if (rc != FL_OK) {
@@ -169,11 +225,15 @@ fl_context *fl_context_create(int device)
         char text[256];
         snprintf(text, sizeof text, "%s", c->rt.err_text);
         bq::t_current = prev;
+        if (bq::rt().ready) restore_device_of_current(); else if (dev_before >= 0) (void)hipSetDevice(dev_before);
         bq::latch(rc, "fl_context_create", text);
         delete c;
         return nullptr;
     }
     bq::t_current = prev;
+    // the caller's context stays current, so its device does too (a caller whose context holds no device yet keeps the HIP
+    // device it had)
+    if (bq::rt().ready) restore_device_of_current(); else if (dev_before >= 0) (void)hipSetDevice(dev_before);
     return c;
 }
 
@@ -198,7 +258,7 @@ void fl_context_destroy(fl_context *c)
     fl_comm_destroy();
     fl_shutdown();
     bq::t_current = prev;
-    if (prev && prev->ready) (void)hipSetDevice(prev->device);
+    restore_device_of_current();            // prev == nullptr: the default context's device, when it holds one
     delete c;
 }
 

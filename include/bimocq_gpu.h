@@ -245,6 +245,11 @@ void        fl_context_destroy(fl_context *ctx);       /* synchronises, destroys
  * halo streams.  Returns FL_OK or an error code (the reference exit()s; we report). */
 int   fl_init(int device);
 void  fl_shutdown(void);
+/* fl_shutdown for EVERY live context of the process (the default one and those of fl_context_create).  The first
+ * successful fl_init registers it with atexit(), so a program that simply returns from main -- or a Python process that
+ * ends -- releases the library's streams while the HIP runtime is still whole; callable directly, idempotent.  A
+ * communicator that is still alive is abandoned, not destroyed (fl_comm_destroy is the orderly way). */
+void  fl_shutdown_all(void);
 /* cudaMalloc + cudaMemset(0) (allocGPUBuffer, GPU_Advection.h:322-326).  NULL on failure. */
 void *fl_malloc(size_t bytes);
 void  fl_free(void *p);

@@ -2,8 +2,6 @@
 # tools/jacobi_pmc.sh <variant> <tag> -- HBM traffic of a Jacobi kernel variant (tools/jacobi_tune.py --variants syntax) from two
 # separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
 set -e
-# (a plain copy stream: rocprofv3 --pmc crashed in its finalisation once the library created a CU-masked stream, r03j)
-export BQ_COPY_STREAM_CUS=${BQ_COPY_STREAM_CUS:-0}
 v=${1:-4:2:32}; tag=${2:-x}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do

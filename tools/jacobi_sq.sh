@@ -3,7 +3,6 @@
 # cycles go (parked on s_waitcnt / s_barrier, stalled at issue, issuing), instructions per wave.  One pass, SQ block only (8 counters).
 set -e
 v=${1:-4:0:0}; tag=${2:-x}
-export BQ_COPY_STREAM_CUS=${BQ_COPY_STREAM_CUS:-0}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/sq_$tag -o run -- python3 tools/jacobi_tune.py --n ${N:-256} --variants $v --sweeps 24 --reps 1 > gpurun_out/sq_$tag.log 2>&1
 python3 - "$tag" <<'PY'

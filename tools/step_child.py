@@ -26,8 +26,7 @@ def main():
     for f in range(a.warmup + a.steps):
         s.advance(f, 2.0 / n)
     bq.hip_lib().fl_sync()
-    s.close()
-    bq.hip_lib().fl_shutdown()
+    s.close()           # (no fl_shutdown: the library tears itself down at exit, which is what this child also verifies)
 
 
 if __name__ == "__main__":
