@@ -24,12 +24,14 @@ HOST_OBJS   := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(HOST_SRCS))
 
 all: $(PKG)/libbimocq_hip.so $(PKG)/libbimocq_host.so oracle example
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_buffer.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
+KERNEL_HDRS := $(wildcard $(CSRC)/*.h)
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(KERNEL_HDRS) include/bimocq_gpu.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # the gather kernels a second time with one-fma lerps (bq_device.hip.h: inline namespace bq::fast, entry points *_fast)
-$(OBJDIR)/bq_advect_fast.o: $(CSRC)/bq_advect.hip $(CSRC)/bq_device.hip.h $(CSRC)/bq_host.h include/bimocq_gpu.h
+$(OBJDIR)/bq_advect_fast.o: $(CSRC)/bq_advect.hip $(KERNEL_HDRS) include/bimocq_gpu.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DBQ_FAST_LERP -c $< -o $@
 
@@ -56,7 +58,19 @@ build/bimocq3d_ranks: examples/bimocq3d_ranks.cpp $(PKG)/libbimocq_host.so
 oracle:
 	$(MAKE) -s -C oracle
 
-clean:
-	rm -rf build $(PKG)/*.so oracle/_build tests/_build
+# AddressSanitizer + UndefinedBehaviorSanitizer on the CPU build.  The product's C++ host layer
+# (csrc/host/*.cpp: ghost-plane validity tracking, wall-sheet boxes, plane windows -- index arithmetic throughout), the
+# test-only CPU stand-in of the C-ABI and the oracle are rebuilt with -fsanitize=address,undefined and the CPU tests that
+# drive them run under it: the host state machine, the multi-rank slab logic over gloo, the oracle's known answers and
+# fixtures.  libasan has to be the first library of the interpreter, hence LD_PRELOAD; leak checking is off (CPython and
+# torch never free everything).  GPU code cannot run under ASan on this pool (no xnack).  Summary: profiles/r04_sanitize_summary.txt
+SAN_TESTS ?= tests/test_host_logic_cpu.py tests/test_slab_multirank.py tests/test_oracle_kat.py tests/test_oracle_mgcg.py tests/test_golden.py
+sanitize:
+	BQ_SANITIZE=1 LD_PRELOAD="$$(gcc -print-file-name=libasan.so) $$(gcc -print-file-name=libubsan.so)" \
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+	python -m pytest $(SAN_TESTS) -x -q -m "not gpu" -p no:cacheprovider
 
-.PHONY: all oracle clean example
+clean:
+	rm -rf build $(PKG)/*.so oracle/_build oracle/_build_san tests/_build tests/_build_san
+
+.PHONY: all oracle clean example sanitize

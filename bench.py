@@ -665,6 +665,7 @@ def main():
                    "map_reinitialisations": ({"velocity": s.reinitCounts()[0], "scalar": s.reinitCounts()[1], "forced_by_travel_limit": s.forcedReinits(),
                                               "steps_run": frame} if args.reinit_policy else None),
                    "comm_size": comm_size, "rccl_version": (int(lib.fl_comm_rccl_version()) or None) if world > 1 else None,
+                   "communicators": int(lib.fl_comm_count()) if world > 1 else 0,
                    "reserved_cus": args.reserve_cus,
                    "comm_per_step_rank0": None if not multi else {
                        "ghost_exchanges": round(comm_stats[0] / args.steps, 1), "ghost_MB_sent": round(comm_stats[1] / args.steps / 1e6, 1),

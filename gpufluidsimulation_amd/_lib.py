@@ -110,6 +110,8 @@ HIP_SIGS = {
     "fl_comm_unique_id": (c_i, [VP]),
     "fl_comm_init": (c_i, [VP, c_i, c_i]),
     "fl_comm_destroy": (None, []),
+    "fl_comm_count": (c_i, []),
+    "fl_comm_check": (c_i, [c_i]),
     "fl_comm_rank": (c_i, []),
     "fl_comm_size": (c_i, []),
     "fl_halo_exchange": (None, [c_i, C.POINTER(VP), C.POINTER(C.c_size_t), C.POINTER(c_i), c_i, c_i, c_i, c_i]),
@@ -138,6 +140,8 @@ FL_OPT_MGCG_TILE = 14
 FL_OPT_PROFILE_COMM = 15
 FL_OPT_RESERVE_CUS = 16
 FL_OPT_MGCG_BOTTOM = 17
+FL_OPT_FIELD_WINDOW = 18
+FL_OPT_COMM_CHECK = 19
 
 
 class BimocqLibraryMissing(RuntimeError):

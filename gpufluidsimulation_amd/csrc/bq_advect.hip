@@ -580,6 +580,14 @@ __global__ __launch_bounds__(256) void maps_quarter_safe_kernel(const float *__r
     if (__any(!ok) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
+} // inline namespace BQ_VARIANT
+} // namespace bq
+
+#include "bq_gather_march.hip.h"        // the same three operators as z-marching blocks with the field in an LDS window
+
+namespace bq {
+inline namespace BQ_VARIANT {
+
 // ---- host-side dispatch helpers -----------------------------------------------------------
 // local dims + the library's slab context (fl_set_slab); single GPU: koff = 0, nkg = nk
 static inline Grid mk_grid(int ni, int nj, int nk)
@@ -666,6 +674,36 @@ static bool dispatch_sd(bool p2, bool pt, int sd, Fn &&fn)
 }
 static inline int stag_axis(int dx, int dy, int dz) { return dx ? 1 : dy ? 2 : dz ? 3 : 0; }
 
+// FL_OPT_FIELD_WINDOW: the structured power-of-two path of the three nine-point operators as gather_march_kernel.
+// g carries the plane window (kw0); `planes` = how many planes from there.  Returns false when the option is off or the
+// case is not the structured one (the caller then launches the one-plane kernel).
+template <int KIND, int NF>
+static bool march_launch(const MarchArgs<NF> &a, const float *mx, const float *my, const float *mz,
+                         Spacing sp, Grid g, int planes, int dx, int dy, int dz, bool pt, bool q4, int fused)
+{
+    const int opt = rt().opt_field_window;
+    if (!opt || !sp.pow2 || pt || !rt().opt_structured_maps) return false;
+    const int gx = (g.ni + dx + 63) / 64, gy = (g.nj + dy + 3) / 4;
+    int kchunk = opt;
+    if (opt == 1) {
+        // enough blocks for every CU to hold its three a few times over, chunks long enough that the seven planes a block
+        // stages before its first node stay a small share
+        kchunk = 32;
+        while (kchunk > 8 && (long)gx * gy * ((planes + kchunk - 1) / kchunk) < 3L * 4 * rt().num_cus) kchunk /= 2;
+    }
+    const dim3 grid(gx, gy, (planes + kchunk - 1) / kchunk);
+    hipStream_t st = rt().compute;
+    const int kw1 = g.kw0 + planes;
+    const int sd = stag_axis(dx, dy, dz);
+#define BQ_MARCH(SDV, Q4V) gather_march_kernel<KIND, SDV, NF, Q4V><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, fused, kchunk, kw1)
+#define BQ_MARCH_SD(Q4V) switch (sd) { case 0: BQ_MARCH(0, Q4V); break; case 1: BQ_MARCH(1, Q4V); break; case 2: BQ_MARCH(2, Q4V); break; default: BQ_MARCH(3, Q4V); break; }
+    if (q4) { BQ_MARCH_SD(true) } else { BQ_MARCH_SD(false) }
+#undef BQ_MARCH_SD
+#undef BQ_MARCH
+    BQ_LAUNCH_CHECK("gather_march_kernel");
+    return true;
+}
+
 template <int NF>
 static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, const float *bz,
                          Spacing sp, Grid g, int dx, int dy, int dz, bool pt)
@@ -676,6 +714,11 @@ static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, con
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
     const bool q4 = rt().opt_map_quarter_fp32 != 0;
+    {
+        MarchArgs<NF> ma;
+        for (int f = 0; f < NF; f++) { ma.src[f] = a.init[f]; ma.out[f] = a.field[f]; ma.aux[f] = nullptr; ma.coeff[f] = 1.f; }
+        if (march_launch<kMarchAdvect, NF>(ma, bx, by, bz, sp, g, planes, dx, dy, dz, pt, q4, rt().opt_fused_housekeeping)) return;
+    }
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
         constexpr int sd = decltype(SD)::value;
@@ -697,6 +740,11 @@ static void cumulate_multi(CumulateArgs<NF> a, const float *mx, const float *my,
     if (planes <= 0) return;
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
+    if (!identity) {
+        MarchArgs<NF> ma;
+        for (int f = 0; f < NF; f++) { ma.src[f] = a.src[f]; ma.out[f] = a.dst[f]; ma.aux[f] = nullptr; ma.coeff[f] = a.coeff[f]; }
+        if (march_launch<kMarchCumulate, NF>(ma, mx, my, mz, sp, g, planes, dx, dy, dz, pt, rt().opt_map_quarter_fp32 != 0, 0)) return;
+    }
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
         constexpr int sd = decltype(SD)::value;
@@ -718,6 +766,11 @@ static void compensate_multi(CompensateArgs<NF> a, const float *mx, const float 
     const dim3 grid = grid_for(g.ni + dx, g.nj + dy, planes);
     hipStream_t st = rt().compute;
     const bool q4 = rt().opt_map_quarter_fp32 != 0;
+    {
+        MarchArgs<NF> ma;
+        for (int f = 0; f < NF; f++) { ma.src[f] = a.src[f]; ma.out[f] = a.err[f]; ma.aux[f] = a.init[f]; ma.coeff[f] = 1.f; }
+        if (march_launch<kMarchCompensate, NF>(ma, mx, my, mz, sp, g, planes, dx, dy, dz, pt, q4, rt().opt_fused_housekeeping)) return;
+    }
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
         constexpr int sd = decltype(SD)::value;

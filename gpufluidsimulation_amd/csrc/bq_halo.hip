@@ -40,6 +40,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*GetVersion)(int *) = nullptr;         // optional (reports only)
+    int (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;   // optional: the scalar all-reduces' own communicator
 };
 
 static Rccl g_rccl;                          // the dlopen'ed library: one per process
@@ -49,8 +50,28 @@ static void allreduce_span(hipEvent_t a, hipEvent_t b);
 struct EvPair { hipEvent_t ready = nullptr, done = nullptr; };
 static constexpr int kEvRing = 16;
 struct WaitSpan { hipEvent_t a, b; };
+// FL_OPT_COMM_CHECK: what a rank remembers of the communicator calls it has issued since the last check (fl_comm_check).
+//   p2p    every ncclSend / ncclRecv is a token (src, dst, position in the src -> dst sequence, element count); a send and the
+//          receive that will match it produce the SAME token, so over all ranks the sum of the send tokens' hashes equals the
+//          sum of the receive tokens' hashes exactly when every message has a partner of the same size at the same position
+//   coll   the all-reduces must come in the same order with the same shape on every rank: an order-dependent chain
+struct CommLedger {
+    unsigned long long p2p_sent = 0, p2p_received = 0;      // sums of 40-bit token hashes
+    unsigned long long coll_chain = 0x9e3779b97f4a7c15ull;
+    unsigned seq_to[64] = {0}, seq_from[64] = {0};          // per peer (ranks beyond 64 share counters: still symmetric)
+    long long calls = 0;
+};
+
 struct HaloState {
     ncclComm_t comm = nullptr;
+    // The in-stream scalar all-reduces (CFL maximum, norms, map guard, NaN flag) run on the COMPUTE stream while ghost-plane
+    // exchanges are in flight on the halo stream.  RCCL serialises the operations of ONE communicator in host issue order
+    // whatever stream they are on, so with a single communicator an all-reduce would make the compute stream wait for the
+    // exchange it was meant to overlap -- and correctness would rest on every rank interleaving the two kinds identically.
+    // They therefore get a communicator of their own (ncclCommSplit of the first, same ranks): nullptr = not available, the
+    // one communicator serves both (RCCL without ncclCommSplit, BQ_SINGLE_COMM=1).
+    ncclComm_t comm_red = nullptr;
+    CommLedger ledger;
     int rank = 0, nranks = 1;
     // optional host-side transport (fl_comm_set_custom): used instead of RCCL when set
     fl_exchange_cb custom_exchange = nullptr;
@@ -98,6 +119,7 @@ void halo_release_state(Runtime &r)
 {
     HaloState *h = static_cast<HaloState *>(r.halo_state);
     if (!h) return;
+    if (h->comm_red && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm_red);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (EvPair &e : h->ev) { if (e.ready) (void)hipEventDestroy(e.ready); if (e.done) (void)hipEventDestroy(e.done); }
     for (std::vector<WaitSpan> *v : { &h->wait_spans, &h->allreduce_spans })
@@ -109,7 +131,33 @@ void halo_release_state(Runtime &r)
 void halo_abandon_comm(Runtime &r)
 {
     HaloState *h = static_cast<HaloState *>(r.halo_state);
-    if (h) h->comm = nullptr;
+    if (h) { h->comm = nullptr; h->comm_red = nullptr; }
+}
+
+// ---- FL_OPT_COMM_CHECK ledger ---------------------------------------------------------------------------------------
+static inline unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+static constexpr unsigned long long kMask40 = (1ull << 40) - 1;
+static void ledger_p2p(bool send, int peer, size_t count)
+{
+    if (!rt().opt_comm_check) return;
+    HaloState &h = hs();
+    CommLedger &L = h.ledger;
+    const int src = send ? h.rank : peer, dst = send ? peer : h.rank;
+    const unsigned seq = send ? ++L.seq_to[peer & 63] : ++L.seq_from[peer & 63];
+    const unsigned long long tok = mix64(((unsigned long long)src << 52) ^ ((unsigned long long)dst << 44) ^ ((unsigned long long)seq << 20)) ^ mix64((unsigned long long)count + 0x51ull);
+    (send ? L.p2p_sent : L.p2p_received) += mix64(tok) & kMask40;
+    L.calls++;
+}
+static void ledger_coll(size_t count, bool is_double, bool is_max)
+{
+    if (!rt().opt_comm_check) return;
+    CommLedger &L = hs().ledger;
+    L.coll_chain = mix64(L.coll_chain ^ ((unsigned long long)count * 4 + (is_double ? 2 : 0) + (is_max ? 1 : 0)));
+    L.calls++;
 }
 
 static void compute_waits_for(hipEvent_t done)
@@ -173,6 +221,7 @@ static bool load_rccl()
     BQ_SYM(GetErrorString, "ncclGetErrorString")
 #undef BQ_SYM
     *(void **)(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");
+    *(void **)(&g_rccl.CommSplit) = dlsym(h, "ncclCommSplit");
     return true;
 }
 
@@ -198,10 +247,12 @@ bool comm_allreduce(void *dev, size_t count, bool is_double, bool is_max, hipStr
         return BQ_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st)) && BQ_HIP(hipStreamSynchronize(st));
     }
     if (!g_comm) return true;
+    ledger_coll(count, is_double, is_max);
     // the all-reduce runs IN the stream it is given (the compute stream): its whole duration is exposed; timed separately
     hipEvent_t a = nullptr, b = nullptr;
     const bool timed = rt().opt_profile_comm && BQ_HIP(hipEventCreate(&a)) && BQ_HIP(hipEventCreate(&b)) && BQ_HIP(hipEventRecord(a, st));
-    const bool ok = BQ_NCCL(AllReduce(dev, dev, count, is_double ? ncclDouble : ncclFloat, is_max ? ncclMax : ncclSum, g_comm, st));
+    ncclComm_t comm = hs().comm_red ? hs().comm_red : g_comm;
+    const bool ok = BQ_NCCL(AllReduce(dev, dev, count, is_double ? ncclDouble : ncclFloat, is_max ? ncclMax : ncclSum, comm, st));
     if (timed) { BQ_HIP(hipEventRecord(b, st)); allreduce_span(a, b); }
     return ok;
 }
@@ -257,12 +308,60 @@ int fl_comm_init(const void *id128, int rank, int nranks)
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     if (!BQ_NCCL(CommInitRank(&g_comm, nranks, id, rank))) return FL_ERR_COMM;
+    // the scalar all-reduces' own communicator (HaloState::comm_red): same ranks, split off the first -- a collective call,
+    // every rank makes it here.  BQ_SINGLE_COMM=1 keeps the single communicator of rounds 1-3 (A/B on real links).
+    const char *single = getenv("BQ_SINGLE_COMM");
+    if (g_rccl.CommSplit && !(single && atoi(single) != 0)) {
+        ncclComm_t red = nullptr;
+        if (!BQ_NCCL(CommSplit(g_comm, 0, rank, &red, nullptr))) return FL_ERR_COMM;
+        hs().comm_red = red;
+    }
+    hs().ledger = CommLedger();
     return fl_last_error();
+}
+
+/* 2 when the scalar all-reduces have a communicator of their own, 1 with a single communicator, 0 without any */
+int fl_comm_count(void) { return g_comm ? (hs().comm_red ? 2 : 1) : 0; }
+
+// FL_OPT_COMM_CHECK: compare what the ranks have issued since the last call (CommLedger above).  Two small all-reduces on
+// the compute stream + one read-back: a debugging aid, called by the host solver at the end of every step while the option
+// is on.  Returns FL_OK, or FL_ERR_COMM (latched) when a send has no receive of the same size at the same position of its
+// pair's sequence or the ranks' all-reduce sequences differ.  `perturb` != 0 (tests): this rank's ledger is falsified first.
+int fl_comm_check(int perturb)
+{
+    if (g_nranks <= 1 || g_null_transport || (!g_comm && !g_custom_allreduce)) return FL_OK;
+    Runtime &r = rt();
+    CommLedger &L = hs().ledger;
+    if (perturb) { L.p2p_sent += 12345; L.coll_chain ^= 0x77; }
+    const unsigned long long diff = (L.p2p_sent - L.p2p_received) & kMask40;       // in [0, 2^40): 8 ranks' sum stays below 2^53
+    const unsigned long long chain = L.coll_chain & ((1ull << 48) - 1);
+    L = CommLedger();                               // (before the two all-reduces below, which every rank issues alike)
+    double *dev = (double *)scratch(256);
+    double *host = (double *)pinned(256);
+    if (!dev || !host) return fl_last_error();
+    hipStream_t st = r.compute;
+    const int saved = r.opt_comm_check;
+    r.opt_comm_check = 0;                           // the check's own collectives are not part of the ledger
+    host[0] = (double)diff;
+    host[1] = (double)chain; host[2] = -(double)chain;
+    bool ok = BQ_HIP(hipMemcpyAsync(dev, host, 24, hipMemcpyHostToDevice, st)) && BQ_HIP(hipStreamSynchronize(st));
+    ok = ok && comm_allreduce(dev, 1, true, false, st) && comm_allreduce(dev + 1, 2, true, true, st);
+    ok = ok && BQ_HIP(hipMemcpyAsync(host, dev, 24, hipMemcpyDeviceToHost, st)) && BQ_HIP(hipStreamSynchronize(st));
+    r.opt_comm_check = saved;
+    if (!ok) return fl_last_error();
+    const unsigned long long total = (unsigned long long)host[0];
+    if ((total & kMask40) != 0) { latch(FL_ERR_COMM, "fl_comm_check", "a send has no receive of the same size at the same place of its pair's sequence (or the reverse)"); return FL_ERR_COMM; }
+    if (host[1] != -host[2]) { latch(FL_ERR_COMM, "fl_comm_check", "the ranks issued different sequences of all-reduces"); return FL_ERR_COMM; }
+    return FL_OK;
 }
 
 void fl_comm_destroy(void)
 {
-    if (g_comm) { fl_sync(); g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
+    if (g_comm) {
+        fl_sync();
+        if (hs().comm_red) { g_rccl.CommDestroy(hs().comm_red); hs().comm_red = nullptr; }
+        g_rccl.CommDestroy(g_comm); g_comm = nullptr;
+    }
     g_custom_exchange = nullptr; g_custom_allreduce = nullptr; g_custom_p2p = nullptr;
     g_null_transport = false;
     g_ev_pending = nullptr;
@@ -331,10 +430,12 @@ void fl_halo_exchange(int n, float *const *fields, const size_t *plane_elems, co
         const int ex = extra[f];
         if (lo >= 0) {
             // my bottom owned planes [G, G+depth+ex) become rank-1's high ghost; its top owned planes fill my low ghost
+            ledger_p2p(true, lo, pe * (size_t)(depth + ex)); ledger_p2p(false, lo, pe * (size_t)depth);
             BQ_NCCL(Send(b + pe * (size_t)G, pe * (size_t)(depth + ex), ncclFloat, lo, g_comm, r.halo));
             BQ_NCCL(Recv(b + pe * (size_t)(G - depth), pe * (size_t)depth, ncclFloat, lo, g_comm, r.halo));
         }
         if (hi < g_nranks) {
+            ledger_p2p(true, hi, pe * (size_t)depth); ledger_p2p(false, hi, pe * (size_t)(depth + ex));
             BQ_NCCL(Send(b + pe * (size_t)(G + own - depth), pe * (size_t)depth, ncclFloat, hi, g_comm, r.halo));
             BQ_NCCL(Recv(b + pe * (size_t)(G + own), pe * (size_t)(depth + ex), ncclFloat, hi, g_comm, r.halo));
         }
@@ -462,8 +563,8 @@ static void p2p_exchange(int n, const int *peers, float *const *send, const size
     BQ_HIP(hipStreamWaitEvent(r.halo, ev->ready, 0));
     if (!BQ_NCCL(GroupStart())) return;
     for (int m = 0; m < n; m++) {
-        if (send_count[m]) BQ_NCCL(Send(send[m], send_count[m], ncclFloat, peers[m], g_comm, r.halo));
-        if (recv_count[m]) BQ_NCCL(Recv(recv[m], recv_count[m], ncclFloat, peers[m], g_comm, r.halo));
+        if (send_count[m]) { ledger_p2p(true, peers[m], send_count[m]); BQ_NCCL(Send(send[m], send_count[m], ncclFloat, peers[m], g_comm, r.halo)); }
+        if (recv_count[m]) { ledger_p2p(false, peers[m], recv_count[m]); BQ_NCCL(Recv(recv[m], recv_count[m], ncclFloat, peers[m], g_comm, r.halo)); }
     }
     if (!BQ_NCCL(GroupEnd())) return;
     BQ_HIP(hipEventRecord(ev->done, r.halo));

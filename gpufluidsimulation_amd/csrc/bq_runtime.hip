@@ -153,6 +153,12 @@ int fl_init(int device)
             if (!BQ_HIP(hipStreamCreateWithFlags(&g_rt.copy, hipStreamNonBlocking))) return FL_ERR_HIP;
         }
     }
+    {
+        // BQ_FIELD_WINDOW = k (environment): initial value of FL_OPT_FIELD_WINDOW for every context of the process -- lets a
+        // whole program (the C++ drivers, the multi-process tests) run the z-marching gather kernels without a code change
+        const char *env = getenv("BQ_FIELD_WINDOW");
+        if (env && *env) g_rt.opt_field_window = atoi(env) < 0 ? 0 : atoi(env);
+    }
     g_rt.device = device;
     g_rt.ready = true;
     bq::note_live(&g_rt, true);
@@ -410,6 +416,8 @@ void fl_set_option(int option, int value)
     case FL_OPT_MGCG_TILE:       g_rt.opt_mgcg_tile = value < 0 ? 0 : value; break;
     case FL_OPT_PROFILE_COMM:    g_rt.opt_profile_comm = value != 0; break;
     case FL_OPT_MGCG_BOTTOM:     g_rt.opt_mgcg_bottom = value != 0; break;
+    case FL_OPT_FIELD_WINDOW:    g_rt.opt_field_window = value < 0 ? 0 : value; break;
+    case FL_OPT_COMM_CHECK:      g_rt.opt_comm_check = value != 0; break;
     case FL_OPT_RESERVE_CUS: {
         const int k = value < 0 ? 0 : value;
         if (k == g_rt.opt_reserve_cus) break;
@@ -447,6 +455,8 @@ int fl_get_option(int option)
     case FL_OPT_MGCG_TILE:       return g_rt.opt_mgcg_tile;
     case FL_OPT_PROFILE_COMM:    return g_rt.opt_profile_comm;
     case FL_OPT_MGCG_BOTTOM:     return g_rt.opt_mgcg_bottom;
+    case FL_OPT_FIELD_WINDOW:    return g_rt.opt_field_window;
+    case FL_OPT_COMM_CHECK:      return g_rt.opt_comm_check;
     case FL_OPT_RESERVE_CUS:     return g_rt.opt_reserve_cus;
     default: return -1;
     }

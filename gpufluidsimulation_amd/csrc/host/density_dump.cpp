@@ -7,8 +7,9 @@
 // OpenVDB is not available in this image, so the default container is a dependency-free
 // sparse format ("BQDENS01", little endian) that carries exactly the same information; a z-slab rank
 // writes its own planes with k_offset so that eight ranks' files concatenate to the global grid.
-// Built with -DHAVE_OPENVDB (make HAVE_OPENVDB=1; needs the OpenVDB headers and library, never compiled
-// in this image) the same voxels go into a real .vdb as well (write_density_vdb below).
+// Built with -DHAVE_OPENVDB (make HAVE_OPENVDB=1; needs the OpenVDB headers and library, never built in this image --
+// tests/test_host_logic_cpu.py type-checks the branch against a declaration-only model of the API, tests/vdb_decl) the
+// same voxels go into a real .vdb as well (write_density_vdb below).
 #include "fluid_solver.hpp"
 
 #include <cerrno>
@@ -127,7 +128,9 @@ long write_density_vdb(unsigned frame, const std::string &filepath, float voxel_
         snprintf(name, sizeof name, "%s/density_render_%04u.k%05d.vdb", filepath.c_str(), frame, k_offset);
     try {
         openvdb::io::File out(name);
-        out.write({ grid });
+        openvdb::GridPtrVec grids;              // (io::File::write is a template over the container: a braced list would not deduce)
+        grids.push_back(grid);
+        out.write(grids);
         out.close();
     } catch (const std::exception &) {
         return -1;

@@ -113,6 +113,9 @@ void BimocqGPUSolver::advance(int framenum, float dt)
     case MAC_REFLECTION: advanceReflection(framenum, dt); break;
     default: break;                                      // the reference's GPU solver has no other scheme (:112-122)
     }
+    // FL_OPT_COMM_CHECK (debugging aid for the first runs on real links): every rank has issued this step's communicator
+    // calls; compare the ledgers (include/bimocq_gpu.h: fl_comm_check)
+    if (fl_comm_size() > 1 && fl_get_option(FL_OPT_COMM_CHECK) > 0) (void)fl_comm_check(0);
     last_ms = GpuSolver->endEventRecord();
     if (verbose) printf("[Bimocq GPU Time: %gms ]\n", last_ms);
 }

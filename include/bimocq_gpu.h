@@ -325,6 +325,16 @@ enum {
                                  * (mg_vbottom_kernel: 32 sweeps, residual, restriction, 32 sweeps, prolongation, 4 sweeps)
                                  * instead of ~22, and the last launch of level 0's 32 sweeps also writes the residual that
                                  * follows.  0: one launch per operator.  Same values either way.                   */
+    FL_OPT_FIELD_WINDOW    = 18,/* nine-point operators (gpu_advect_*, gpu_compensate_*, gpu_accumulate_*) on power-of-two
+                                 * spacing: k > 0 runs them as z-marching blocks that read the sampled field out of a rolling
+                                 * LDS window (bq_gather_march.hip.h) instead of gathering every corner from memory; a tap
+                                 * outside the window takes the direct path, so values never change.  k = planes marched per
+                                 * block (1 = auto).  0: the one-plane kernels.                                       */
+    FL_OPT_COMM_CHECK      = 19,/* 1: every RCCL call of the z-slab path (ncclSend / ncclRecv of the exchanges, the scalar
+                                 * all-reduces) is entered into a per-rank ledger that fl_comm_check() compares across the
+                                 * ranks; the host solver calls it at the end of every step while the option is on.  A
+                                 * debugging aid for the first runs on real links: a mismatch latches FL_ERR_COMM instead of
+                                 * hanging or silently pairing the wrong messages.  Default 0.                        */
     FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
                                  * contract.  1: the caller vouches that every value of the map arrays it passes to the
                                  * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map
@@ -488,6 +498,15 @@ void fl_comm_destroy(void);
 /* runs every RCCL call of this library on a temporary one-rank communicator (single-GPU check of the
  * dlopen'ed binding); FL_OK or an error code with fl_last_error_string() set */
 int  fl_comm_selftest(void);
+/* How many RCCL communicators the current context holds: 2 = the ghost-plane exchanges (halo stream) and the in-stream
+ * scalar all-reduces (compute stream) each have their own, so that neither waits for the other inside RCCL's per-communicator
+ * launch order; 1 = one serves both (a RCCL without ncclCommSplit, or BQ_SINGLE_COMM=1 in the environment); 0 = none. */
+int  fl_comm_count(void);
+/* FL_OPT_COMM_CHECK: compare the ranks' ledgers of communicator calls since the last check (collective: every rank calls
+ * it at the same point; two 8-to-24-byte all-reduces + one read-back).  FL_OK, or FL_ERR_COMM (latched) when a send has no
+ * receive of the same size at the same position of its pair's sequence, or the all-reduce sequences differ.  perturb != 0
+ * falsifies this rank's ledger first (tests). */
+int  fl_comm_check(int perturb);
 int  fl_comm_rank(void);
 int  fl_comm_size(void);
 /* refresh `depth` (<= G) ghost planes per side of n fields with the z-neighbours, one RCCL group on

@@ -6,8 +6,12 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "tests", "_build")
+# BQ_SANITIZE=1 (set by `make sanitize`, which also preloads libasan into the interpreter): the same sources built with
+# AddressSanitizer + UndefinedBehaviorSanitizer into a directory of their own (sanitizers on the CPU build)
+SANITIZE = os.environ.get("BQ_SANITIZE", "0") not in ("", "0")
+OUT = os.path.join(ROOT, "tests", "_build_san" if SANITIZE else "_build")
 SO = os.path.join(OUT, "libbimocq_host_cpu.so")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g"]
 
 
 def build():
@@ -21,6 +25,8 @@ def build():
     if os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
         return SO
     cflags = ["-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp"]
+    if SANITIZE:
+        cflags = ["-O1"] + cflags[1:] + SAN_FLAGS
     objs = []
     for src, cc, std in ([(os.path.join(ROOT, "tests", "cpu_abi", "oracle_abi.c"), "gcc", "-std=gnu11"),
                           (os.path.join(ROOT, "oracle", "bimocq_oracle.c"), "gcc", "-std=c11"),
@@ -29,7 +35,7 @@ def build():
         obj = os.path.join(OUT, os.path.basename(src) + ".o")
         subprocess.check_call([cc, std, *cflags, "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
         objs.append(obj)
-    subprocess.check_call(["g++", "-shared", "-fopenmp", "-pthread", "-o", SO, *objs, "-lm"])
+    subprocess.check_call(["g++", "-shared", "-fopenmp", "-pthread", *(SAN_FLAGS if SANITIZE else []), "-o", SO, *objs, "-lm"])
     return SO
 
 

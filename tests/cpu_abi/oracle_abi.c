@@ -172,6 +172,9 @@ void fl_set_slab(int koff, int nk_global, int own0, int own1, int nk_local)
 int fl_comm_unique_id(void *id128) { memset(id128, 0, 128); return FL_OK; }
 int fl_comm_init(const void *id128, int rank, int nranks) { (void)id128; (void)rank; if (nranks > 1) latch(FL_ERR_COMM, "no RCCL in the CPU stand-in"); return g_err; }
 void fl_comm_destroy(void) { c_rank = 0; c_nranks = 1; c_exchange = NULL; c_allreduce = NULL; }
+int fl_comm_count(void) { return 0; }
+int fl_comm_check(int perturb) { (void)perturb; return FL_OK; }
+void fl_shutdown_all(void) {}
 int fl_comm_rank(void) { return c_rank; }
 int fl_comm_size(void) { return c_nranks; }
 void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb ex, fl_allreduce_cb ar)

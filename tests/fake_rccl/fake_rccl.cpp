@@ -53,6 +53,7 @@ struct Comm {
     Segment *seg = nullptr;
     int rank = 0, nranks = 1;
     std::string name;
+    int splits = 0;                                  // ncclCommSplit calls made on this communicator (names the children)
 };
 
 struct Op { bool send; void *buf; size_t bytes; int peer; hipStream_t stream; Comm *comm; size_t done = 0; bool header = false; };
@@ -249,6 +250,21 @@ int ncclCommDestroy(void *comm)
     if (last) shm_unlink(c->name.c_str());
     delete c;
     return kSuccess;
+}
+
+// ncclCommSplit with one colour for everybody (what bq_halo.hip asks for: a second communicator over the same ranks, for the
+// in-stream scalar all-reduces): a child segment named after the parent's and the number of splits made on it so far --
+// every rank splits in the same order, so the names agree.  `key` must be the caller's rank (ranks keep their numbers).
+int ncclCommSplit(void *comm, int color, int key, void **newcomm, void *config)
+{
+    (void)config;
+    Comm *c = (Comm *)comm;
+    if (!c || !newcomm) return fail(kInvalidArgument, "null communicator");
+    if (color != 0 || key != c->rank) return fail(kInvalidArgument, "the stand-in splits with colour 0 and key = rank only");
+    ncclUniqueId id;
+    memset(&id, 0, sizeof id);
+    snprintf(id.internal, sizeof id.internal, "%s_s%d", c->name.c_str(), c->splits++);
+    return ncclCommInitRank(newcomm, c->nranks, id, c->rank);
 }
 
 int ncclGroupStart(void) { g_group_depth++; return kSuccess; }

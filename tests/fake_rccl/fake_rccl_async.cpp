@@ -70,6 +70,7 @@ struct Comm {
     unsigned send_seq[kMaxRanks] = {}, recv_seq[kMaxRanks] = {};
     unsigned red_seq = 0;
     std::string name;
+    int splits = 0;                                  // ncclCommSplit calls made on this communicator (names the children)
 };
 
 thread_local int g_group_depth = 0;
@@ -229,6 +230,21 @@ int ncclCommDestroy(void *comm)
     if (unlink_it) shm_unlink(c->name.c_str());
     delete c;
     return kSuccess;
+}
+
+// ncclCommSplit with one colour for everybody (what bq_halo.hip asks for: a second communicator over the same ranks, for the
+// in-stream scalar all-reduces): a child segment named after the parent's and the number of splits made on it so far --
+// every rank splits in the same order, so the names agree.  `key` must be the caller's rank (ranks keep their numbers).
+int ncclCommSplit(void *comm, int color, int key, void **newcomm, void *config)
+{
+    (void)config;
+    Comm *c = (Comm *)comm;
+    if (!c || !newcomm) return fail(kInvalidArgument, "null communicator");
+    if (color != 0 || key != c->rank) return fail(kInvalidArgument, "the stand-in splits with colour 0 and key = rank only");
+    ncclUniqueId id;
+    memset(&id, 0, sizeof id);
+    snprintf(id.internal, sizeof id.internal, "%s_s%d", c->name.c_str(), c->splits++);
+    return ncclCommInitRank(newcomm, c->nranks, id, c->rank);
 }
 
 int ncclGroupStart(void) { g_group_depth++; return kSuccess; }

@@ -47,12 +47,18 @@ def limit_openmp_threads():
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, usable_cores())))
 
 
+SANITIZE = os.environ.get("BQ_SANITIZE", "0") not in ("", "0")     # see tests/build_cpu_host.py, `make sanitize`
+
+
 def build(march="x86-64", out="_build"):
     """(re)build liboracle.so with gcc; returns its path."""
+    extra = []
+    if SANITIZE:
+        out, extra = out + "_san", ["SANITIZE=1", "OPT=-O1"]
     so = os.path.join(ORACLE_DIR, out, "liboracle.so")
     src = [os.path.join(ORACLE_DIR, f) for f in ("bimocq_oracle.c", "mgcg_oracle.c", "bimocq_oracle.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, f"MARCH={march}", f"OUT={out}"])
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, f"MARCH={march}", f"OUT={out}", *extra])
     return so
 
 

@@ -85,6 +85,11 @@ def main():
         assert abilib.fl_comm_selftest() == 0, abilib.fl_last_error_string()
         transport.init_rccl(abilib, dist)
         assert abilib.fl_comm_size() == world and abilib.fl_comm_rank() == rank
+        # round 4: the in-stream scalar all-reduces have a communicator of their own (ncclCommSplit), and every step's
+        # communicator calls are checked across the ranks (FL_OPT_COMM_CHECK: a mismatch latches FL_ERR_COMM -> s._check())
+        want_comms = 1 if (world == 1 or os.environ.get("BQ_SINGLE_COMM", "0") not in ("", "0")) else 2
+        assert abilib.fl_comm_count() == (0 if world == 1 else want_comms), abilib.fl_comm_count()
+        abilib.fl_set_option(bq._lib.FL_OPT_COMM_CHECK, 1)
 
         class _Stats:                               # the RCCL path keeps no Python-side counters
             exchanges, planes_moved, p2p_messages, p2p_floats, trace = -1, -1, -1, -1, None
@@ -172,6 +177,15 @@ def main():
         abilib.fl_comm_profile(ms2, n2, 1)
         print(f"[rank {rank}] comm profile: {n2[0]} waits {ms2[0]:.3f} ms exposed, {n2[1]} in-stream all-reduces {ms2[1]:.3f} ms", flush=True)
         if world > 1 and not (n2[0] > 0 and ms2[0] >= 0.0):
+            bad += 1
+    if a.transport == "rccl" and world > 1:
+        # the check itself: clean ledgers pass, a falsified one is seen by EVERY rank (the comparison is an all-reduce)
+        rc_clean = abilib.fl_comm_check(0)
+        rc_bad = abilib.fl_comm_check(1 if rank == world - 1 else 0)
+        text = abilib.fl_last_error_string().decode(errors="replace")
+        abilib.fl_clear_error()
+        print(f"[rank {rank}] comm check: communicators={abilib.fl_comm_count()} clean rc={rc_clean} falsified rc={rc_bad} ({text[:60]})", flush=True)
+        if rc_clean != 0 or rc_bad != bq._lib.FL_ERR_COMM:
             bad += 1
     moved = np.abs(o.field("v")).max()
     print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} planes={tr.planes_moved} "

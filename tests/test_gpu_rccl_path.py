@@ -57,6 +57,19 @@ def test_two_ranks_over_the_rccl_branch(fake):
     rc, out = launch_worker(fake, 2, "--steps", 4)
     assert rc == 0, out
     assert out.count("mismatches=0") == 2
+    # round 4: two communicators (exchanges / scalar all-reduces), every step's calls cross-checked, a falsified ledger caught
+    assert out.count("communicators=2 clean rc=0 falsified rc=5") == 2, out
+
+
+def test_single_communicator_fallback(fake):
+    """BQ_SINGLE_COMM=1: the one-communicator set-up of rounds 1-3 (what a RCCL without ncclCommSplit gets) still works"""
+    os.environ["BQ_SINGLE_COMM"] = "1"
+    try:
+        rc, out = launch_worker(fake, 2, "--steps", 2)
+    finally:
+        os.environ.pop("BQ_SINGLE_COMM", None)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2 and out.count("communicators=1 clean rc=0 falsified rc=5") == 2, out
 
 
 def test_three_ranks_over_the_rccl_branch(fake):
