@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 INFINITY_CACHE_BYTES = 256 << 20
 JACOBI_BYTES_PER_VOXEL = 12.0   # read p + read div + write p'  
 
-from gpufluidsimulation_amd.scenes import SMOKE, leapfrog, rising_smoke     # noqa: E402  (pure Python, no GPU touched)
+from gpufluidsimulation_amd.scenes import SMOKE, collision, leapfrog, rising_smoke     # noqa: E402  (pure Python, no GPU touched)
 
 
 def parse():
@@ -56,7 +56,15 @@ def parse():
                     help="N > 1: weak scaling, size^3 (default 256) PER GPU, the grid grows along z; the default for N > 1 is "
                          "strong scaling of one global grid (BASELINE config 4)")
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for round-1 command lines)")
-    ap.add_argument("--scene", choices=["smoke", "leapfrog"], default="smoke",
+    ap.add_argument("--length", type=float, default=1.0, help="domain length along x (h = length / NX); the reference's scene: 0.2")
+    ap.add_argument("--dt", type=float, default=None, help="time step (default 2 h); the reference's scene: 0.08")
+    ap.add_argument("--viscosity", type=float, default=0.0, help="kinematic viscosity (> 0: 20 diffusion sweeps per component and step); "
+                    "the reference's scene: 1e-6")
+    ap.add_argument("--reference-scene", action="store_true",
+                    help="shorthand for the reference binary's own configuration (src/bimocq3D/main.cpp:28-80): --grid 100 200 200 "
+                         "--length 0.2 --dt 0.08 --viscosity 1e-6 --scene collision (spacing 0.002: NOT a power of two; add --scheme "
+                         "reflection --projection mgcg for the scheme and projection it ships)")
+    ap.add_argument("--scene", choices=["smoke", "leapfrog", "collision"], default="smoke",
                     help="smoke: SURVEY 8d rising smoke; leapfrog: two coaxial vortex rings blown along x by the reference's "
                          "emitter formula (src/bimocq3D/main.cpp:52-78), no buoyancy (BASELINE config 5)")
     ap.add_argument("--dump", default=None, metavar="DIR",
@@ -393,6 +401,12 @@ def main():
     multi = world > 1 or emul > 1
     nslabs = world if world > 1 else (emul if emul > 1 else 1)
     weak = args.weak and not args.strong
+    if args.reference_scene:
+        args.grid = args.grid or [100, 200, 200]
+        args.length, args.scene = 0.2, "collision"
+        args.dt = args.dt if args.dt is not None else 0.08
+        args.viscosity = args.viscosity or 1e-6
+        args.no_extra = True
     if args.grid:
         nx, ny, nz_global = args.grid
         weak = False
@@ -402,8 +416,8 @@ def main():
         nz_global = n * nslabs if (multi and weak) else n
     if multi and nz_global % nslabs:
         sys.exit("the global plane count must be divisible by the number of ranks")
-    h = 1.0 / nx
-    dt = 2.0 * h
+    h = args.length / nx
+    dt = args.dt if args.dt is not None else 2.0 * h
 
     keep = None
     side = None                                 # gloo side channel: agreement on the transport, fallback exchange
@@ -435,19 +449,21 @@ def main():
                 args.transport_note = "host-staged over gloo (FALLBACK: RCCL set-up failed)"
         else:
             keep = transport.HostStagedTransport(lib, dist)
-        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost,
+        s = BimocqGPUSolver(nx, ny, nz_global, args.length, args.viscosity, 1.0, device=local_rank, rank=rank, nranks=world, ghost=args.ghost,
                             scheme=3 if args.scheme == "reflection" else 0)
     elif emul > 1:
         erank = args.emulate_rank if args.emulate_rank is not None else emul // 2
         keep = transport.NullTransport(lib, erank, emul)
-        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, rank=erank, nranks=emul, ghost=args.ghost,
+        s = BimocqGPUSolver(nx, ny, nz_global, args.length, args.viscosity, 1.0, device=local_rank, rank=erank, nranks=emul, ghost=args.ghost,
                             scheme=3 if args.scheme == "reflection" else 0)
     else:
-        s = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, scheme=3 if args.scheme == "reflection" else 0)
+        s = BimocqGPUSolver(nx, ny, nz_global, args.length, args.viscosity, 1.0, device=local_rank, scheme=3 if args.scheme == "reflection" else 0)
     comm_size = int(lib.fl_comm_size())
 
     # ---- the scene ------------------------------------------------------------------------------------
-    if args.scene == "leapfrog":
+    if args.scene == "collision":
+        s.setSmoke(0.0, 0.0, collision(h))                  # the reference binary's own scene (gpufluidsimulation_amd/scenes.py)
+    elif args.scene == "leapfrog":
         s.setSmoke(0.0, 0.0, leapfrog(nz_global, h))        # gpufluidsimulation_amd/scenes.py
     elif multi and weak:
         s.setSmoke(0.0, 1.0, [(0.5, 0.2, 0.5 + r, 0.1, 1.0, 1.0, 0.0, 1) for r in range(nslabs)])    # one source per slab
@@ -642,7 +658,8 @@ def main():
     ms_per_step = el / args.steps * 1e3
     value = voxels * args.steps / el / 1e6
     grid_txt = f"{nx}^3" if nx == ny == nz_global else f"{nx}x{ny}x{nz_global}"
-    scene_txt = "rising smoke" if args.scene == "smoke" else "leapfrogging vortex rings"
+    scene_txt = {"smoke": "rising smoke", "leapfrog": "leapfrogging vortex rings",
+                 "collision": f"vortex-ring collision (the reference binary's scene: L {args.length}, dt {dt:g}, viscosity {args.viscosity:g})"}[args.scene]
     border_txt = ""
     if multi:
         kb = s.getOption(1) if hasattr(s, "getOption") else None
@@ -812,8 +829,86 @@ def main():
     # config 3's 256^3): a short leg of the same scene at 512^3 on this GPU, so that SCALE's N >= 2 values have their anchor ----
     if rank == 0 and world == 1 and not emul and not args.no_extra and args.scene == "smoke" and args.scheme == "bimocq" and not mg \
             and (nx, ny, nz_global) == (256, 256, 256) and not args.dump:
+        # ---- SURVEY 8(d)'s own window: "Mvoxels/s per step averaged over steps 20-200" of a FRESH run of the scene.  The
+        # headline above is whatever --steps / --warmup asked for (the driver's command times steps 5-25, each with one DMC
+        # sub-step; later steps take two); this leg is the metric as the survey defines it, whatever the command line was.
         try:
             s.close()
+            sm = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, scheme=0)
+            sm.setSmoke(0.0, 1.0, rising_smoke(nx, 1.0 / nx))
+            sm.setProjection(args.jacobi_iters, args.halfrdx, 0)
+            sm.setOption(3, 1)
+            for f_ in range(20):
+                sm.advance(f_, dt)
+            barrier()
+            tm = time.perf_counter()
+            for f_ in range(20, 200):
+                sm.advance(f_, dt)
+            barrier()
+            elm = time.perf_counter() - tm
+            sm.close()
+            line.setdefault("extra", {})["survey_metric"] = {
+                "value": round(voxels * 180 / elm / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(elm / 180 * 1e3, 3),
+                "steps": "20-200 of a fresh run", "note": "SURVEY 8(d): Mvoxels/s per step averaged over steps 20-200 (full state, exact "
+                "arithmetic, 200 Jacobi iterations); the headline `value` times the steps the command line names"}
+        except Exception as e:                  # extra information only
+            line.setdefault("extra", {})["survey_metric"] = {"value": None, "note": f"failed: {e}"}
+        # ---- the two arithmetic variants side by side ("report separately for the exact and the fast variant"):
+        # the one-fma variant with the z-marching field-window kernels, steps 20-60 of a fresh run, and its deviation from the
+        # exact fields where the north star states its tolerance: 128^3 after 200 steps (both trajectories on this GPU; the
+        # exact one is the trajectory tests/golden pins against the CPU oracle)
+        try:
+            L_ = bq._lib
+            legs_v = {}
+            for tag, fast_, win_ in (("exact", 0, 0), ("fast", 1, 0), ("fast_window", 1, 1)):
+                lib.fl_set_option(L_.FL_OPT_FAST_LERP, fast_)
+                lib.fl_set_option(L_.FL_OPT_FIELD_WINDOW, win_)
+                sv = BimocqGPUSolver(nx, ny, nz_global, 1.0, 0.0, 1.0, device=local_rank, scheme=0)
+                sv.setSmoke(0.0, 1.0, rising_smoke(nx, 1.0 / nx))
+                sv.setProjection(args.jacobi_iters, args.halfrdx, 0)
+                sv.setOption(3, 1)
+                for f_ in range(20):
+                    sv.advance(f_, dt)
+                sv.setOption(8, 1)
+                sv.phaseMs(reset=True)
+                barrier()
+                tv = time.perf_counter()
+                for f_ in range(20, 60):
+                    sv.advance(f_, dt)
+                barrier()
+                elv = time.perf_counter() - tv
+                ph, pst = sv.phaseMs(reset=True)
+                sv.close()
+                legs_v[tag] = {"value": round(voxels * 40 / elv / 1e6, 2), "ms_per_step": round(elv / 40 * 1e3, 3),
+                               "phase_ms_per_step": {k: round(v / max(1, pst), 3) for k, v in ph.items()}}
+            n1 = 128
+            fields_ = {}
+            for tag, fast_, win_ in (("exact", 0, 0), ("fast_window", 1, 1)):
+                lib.fl_set_option(L_.FL_OPT_FAST_LERP, fast_)
+                lib.fl_set_option(L_.FL_OPT_FIELD_WINDOW, win_)
+                sv = BimocqGPUSolver(n1, n1, n1, 1.0, 0.0, 1.0, device=local_rank, scheme=0)
+                sv.setSmoke(0.0, 1.0, rising_smoke(n1, 1.0 / n1))
+                sv.setProjection(200, 0.5, 0)
+                sv.setOption(3, 1)
+                for f_ in range(200):
+                    sv.advance(f_, 2.0 / n1)
+                fields_[tag] = {k: sv.field(k).astype(np.float64) for k in ("rho", "u", "v", "w")}
+                sv.close()
+            rms = {k: float(np.sqrt(np.mean((fields_["exact"][k] - fields_["fast_window"][k]) ** 2))) for k in ("rho", "u", "v", "w")}
+            line.setdefault("extra", {})["arithmetic_variants"] = {
+                "unit": "Mvoxels/s", "grid": [nx, ny, nz_global], "steps": "20-60 of a fresh run each, full state, phases timed",
+                "exact": legs_v["exact"], "fast": legs_v["fast"], "fast_window": legs_v["fast_window"],
+                "rms_fast_vs_exact_128_cubed_after_200_steps": rms, "rms_tolerance": 1e-5,
+                "note": "exact: the reference's double-rounded lerp (the headline's arithmetic); fast: FL_OPT_FAST_LERP = 1, one fp32 fma per "
+                        "lerp, bit-identical to the oracle in ITS fast mode, within the north star's 1e-5 RMS of the exact fields; "
+                        "fast_window: the same arithmetic with FL_OPT_FIELD_WINDOW = 1 (z-marching gather kernels, sampled field in an LDS "
+                        "window: same bits as `fast`)"}
+        except Exception as e:                  # extra information only
+            line.setdefault("extra", {})["arithmetic_variants"] = {"note": f"failed: {e}"}
+        finally:
+            lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
+            lib.fl_set_option(bq._lib.FL_OPT_FIELD_WINDOW, 0)
+        try:
             big = 512
             s5 = BimocqGPUSolver(big, big, big, 1.0, 0.0, 1.0, device=local_rank, scheme=0)
             s5.setSmoke(0.0, 1.0, rising_smoke(big, 1.0 / big))
@@ -823,14 +918,32 @@ def main():
             f5 = 0
             for _ in range(w5):
                 s5.advance(f5, 2.0 / big); f5 += 1
+            lib.fl_jacobi_profile(None, None, None)         # (reset)
+            lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
             barrier()
             t5 = time.perf_counter()
             for _ in range(n5):
                 s5.advance(f5, 2.0 / big); f5 += 1
             barrier()
             el5 = time.perf_counter() - t5
+            lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 0)
+            ms5, l5, sw5 = C.c_double(0.0), C.c_longlong(0), C.c_longlong(0)
+            lib.fl_jacobi_profile(C.byref(ms5), C.byref(l5), C.byref(sw5))
+            k5 = (lib.fl_jacobi_kernel_name() or b"").decode()
             s5.close()
+            roof5 = None
+            if l5.value > 0 and sw5.value > 0:
+                us5 = ms5.value * 1e3 / l5.value
+                comp5 = JACOBI_BYTES_PER_VOXEL * big ** 3
+                roof5 = {"bound": "hbm", "kernel": k5, "achieved": round(comp5 / (us5 * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(comp5 / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "compulsory_bytes_per_launch": int(comp5), "working_set": "hbm (p, p', div = 1.6 GB, six times the Infinity Cache)",
+                         "us_per_launch": round(us5, 3), "launches_timed": int(l5.value), "sweeps_per_launch": round(sw5.value / l5.value, 3),
+                         "us_per_sweep": round(ms5.value * 1e3 / sw5.value, 3),
+                         "note": "the HBM-resident counterpart of the headline's roofline object: compulsory bytes of a fused launch (p and "
+                                 "div read once, p' written once) over its event-timed duration inside these steps"}
             line.setdefault("extra", {})["single_gpu_512_anchor"] = {
+                "roofline": roof5,
                 "value": round(big ** 3 * n5 / el5 / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(el5 / n5 * 1e3, 3), "steps": n5,
                 "warmup": w5, "note": "BASELINE config 4's grid (512^3 rising smoke, 200 Jacobi iterations, full state) on ONE GPU: the N = 1 "
                                       "point of the strong-scaling curve that `bench.py --gpus N` (N > 1) measures on the same grid; early "

@@ -681,8 +681,16 @@ template <int KIND, int NF>
 static bool march_launch(const MarchArgs<NF> &a, const float *mx, const float *my, const float *mz,
                          Spacing sp, Grid g, int planes, int dx, int dy, int dz, bool pt, bool q4, int fused)
 {
-    const int opt = rt().opt_field_window;
+    // -1 (default): on in the one-fma build, whose kernels the window moves from the texture-addresser path onto the VALU
+    // floor (5-12 % per launch at 256^3); off in the exact build, which sits on its VALU floor already and only pays the
+    // window's extra address arithmetic and lower occupancy (+8.6 % per step, profiles/r04_b_*)
+#ifdef BQ_FAST_LERP
+    const int opt = rt().opt_field_window < 0 ? 1 : rt().opt_field_window;
+#else
+    const int opt = rt().opt_field_window < 0 ? 0 : rt().opt_field_window;
+#endif
     if (!opt || !sp.pow2 || pt || !rt().opt_structured_maps) return false;
+    const int sd = stag_axis(dx, dy, dz);
     const int gx = (g.ni + dx + 63) / 64, gy = (g.nj + dy + 3) / 4;
     int kchunk = opt;
     if (opt == 1) {
@@ -694,10 +702,19 @@ static bool march_launch(const MarchArgs<NF> &a, const float *mx, const float *m
     const dim3 grid(gx, gy, (planes + kchunk - 1) / kchunk);
     hipStream_t st = rt().compute;
     const int kw1 = g.kw0 + planes;
-    const int sd = stag_axis(dx, dy, dz);
+    // two fields per launch: the scalar pair (unstaggered) in all three operators, staggered components only in the
+    // accumulation (gpu_accumulate_velocity2) -- nothing else is instantiated
+    if (NF == 2 && KIND != kMarchCumulate && sd != 0) return false;
 #define BQ_MARCH(SDV, Q4V) gather_march_kernel<KIND, SDV, NF, Q4V><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, fused, kchunk, kw1)
-#define BQ_MARCH_SD(Q4V) switch (sd) { case 0: BQ_MARCH(0, Q4V); break; case 1: BQ_MARCH(1, Q4V); break; case 2: BQ_MARCH(2, Q4V); break; default: BQ_MARCH(3, Q4V); break; }
+#define BQ_MARCH_SD(Q4V)                                                                     \
+    if constexpr (NF == 2 && KIND != kMarchCumulate) { BQ_MARCH(0, Q4V); }                    \
+    else switch (sd) { case 0: BQ_MARCH(0, Q4V); break; case 1: BQ_MARCH(1, Q4V); break; case 2: BQ_MARCH(2, Q4V); break; default: BQ_MARCH(3, Q4V); break; }
+#ifdef BQ_FAST_LERP
+    (void)q4;                                       // (the one-fma lerps do not know the quarter-weight distinction)
+    BQ_MARCH_SD(false)
+#else
     if (q4) { BQ_MARCH_SD(true) } else { BQ_MARCH_SD(false) }
+#endif
 #undef BQ_MARCH_SD
 #undef BQ_MARCH
     BQ_LAUNCH_CHECK("gather_march_kernel");

@@ -79,6 +79,7 @@ __device__ __forceinline__ float blend_corners(const float (&v)[8], const CellW 
 struct WindowView {
     int xlo, xspan, ylo, yspan, zlo, zspan;     // cells [lo, lo + span] may be read from the window (corner + 1 included)
     int addr0;                                  // LDS byte address of window element (x = 0, y = 0) of slot 0, field 0
+    int base;                                   // LDS byte address of the window's first element (always valid)
 };
 
 // The eight corners of tap cell c for NF co-located fields: from the window where the lane's cell is inside, else from memory.
@@ -109,9 +110,10 @@ __device__ __forceinline__ void window_corners(const Field (&src)[NF], const Win
     }
 }
 
-// blend9_gather_w of bq_advect.hip with the corners read through the window
+// blend9_gather_w of bq_advect.hip with the corners read through the window, tap by tap: each tap branches on its own
+// predicate (the form the kernels ship with: see the batched form below for what was measured against it)
 template <int NF, bool GE1>
-__device__ __forceinline__ void blend9_window(const Field (&src)[NF], const WindowView &wv, const Spacing &sp, f3 org, const f3 (&mp)[9],
+__device__ __forceinline__ void blend9_window_pertap(const Field (&src)[NF], const WindowView &wv, const Spacing &sp, f3 org, const f3 (&mp)[9],
                                               const float (&w)[NF], float (&sum)[NF], float (&value)[NF])
 {
 #pragma unroll
@@ -129,14 +131,148 @@ __device__ __forceinline__ void blend9_window(const Field (&src)[NF], const Wind
     for (int f = 0; f < NF; f++) value[f] = blend_corners<GE1>(v[f], c);
 }
 
-// map nodes out of the ring: o[z] = float offset of the slot that holds plane kl - 1 + z (uniform)
-struct NodesRing {
-    const float *t; int o0, o1, o2;
-    __device__ __forceinline__ float operator()(int x, int y, int z) const
-    {
-        return t[(z == 0 ? o0 : z == 1 ? o1 : o2) + y * kTileX + x];
+// One tap, located: the LDS byte address of its cell's corner 000 in the window (field 0) when the lane's cell is inside,
+// the window's first byte otherwise (any valid address: the values read there are replaced, see blend9_window).
+struct TapW { unsigned addr; float fx, fy, fz; };
+
+__device__ __forceinline__ bool tap_locate(const Field &f, const WindowView &w, const Spacing &sp, f3 org, f3 pos, TapW &t)
+{
+    const CellW c = locate_ijk(f, sp, org, pos);
+    const bool in = (unsigned)(c.i - w.xlo) <= (unsigned)w.xspan && (unsigned)(c.j - w.ylo) <= (unsigned)w.yspan &&
+                    (unsigned)(c.kl - w.zlo) <= (unsigned)w.zspan;
+    const int slot = c.kl & (kWR - 1);
+    const unsigned a = (unsigned)(w.addr0 + c.i * 4) + (unsigned)__mul24(c.j, kWX * 4) + (unsigned)__mul24(slot, kWPS * 4);
+    t.addr = in ? a : (unsigned)w.base;
+    t.fx = c.fx; t.fy = c.fy; t.fz = c.fz;
+    return in;
+}
+
+template <int NF>
+__device__ __forceinline__ void tap_read(const TapW &t, float (&v)[NF][8])
+{
+    const float *p = (const float *)(__attribute__((address_space(3))) const float *)(size_t)t.addr;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const float *q = p + f * kWField;
+        v[f][0] = q[0];              v[f][1] = q[1];
+        v[f][2] = q[kWX];            v[f][3] = q[kWX + 1];
+        v[f][4] = q[kWPS];           v[f][5] = q[kWPS + 1];
+        v[f][6] = q[kWPS + kWX];     v[f][7] = q[kWPS + kWX + 1];
     }
-};
+}
+
+template <bool FMA>
+__device__ __forceinline__ float blend_tap(const float (&v)[8], const TapW &t)
+{
+    CellW c; c.i = c.j = c.kl = 0; c.fx = t.fx; c.fy = t.fy; c.fz = t.fz;
+    return blend_corners<FMA>(v, c);
+}
+
+// blend9_gather_w of bq_advect.hip with the corners read through the window, in batches of TB taps:
+//   1. locate the batch's taps (cell, weights, in-window predicate, LDS address)
+//   2. read all their corners from LDS -- unconditionally, no branch: TB x NF x 4 two-dword reads in flight together
+//   3. only if some lane of the wave has a tap outside the window (wave-uniform test): those lanes fetch those taps' corners
+//      from memory, exactly as the one-plane kernels do (corners(): descriptor range check, flat-index wrap)
+//   4. the lerps
+// The common case is straight-line code; the direct path costs nothing but one scalar branch per batch when nobody needs it.
+// Measured at 256^3 (profiles/r04_f_*): no faster than the tap-by-tap form where every tap is served by the window (the
+// kernels are bound by VALU issue, not by the latency of the reads: 330 against 332 us), and 5-15 % SLOWER in the accumulations
+// through the backward map, whose zeroed border sends some lane of half of all waves to the direct path: those
+// waves then pay the reads AND a second locate.  Kept selectable (TB > 0) for maps without that border.
+template <int NF, bool GE1, int TB>
+__device__ __forceinline__ void blend9_window(const Field (&src)[NF], const WindowView &wv, const Spacing &sp, f3 org, const f3 (&mp)[9],
+                                              const float (&w)[NF], float (&sum)[NF], float (&value)[NF])
+{
+#pragma unroll
+    for (int b0 = 0; b0 < 9; b0 += TB) {
+        TapW tap[TB];
+        bool in[TB];
+        bool all_in = true;
+#pragma unroll
+        for (int t = 0; t < TB; t++)
+            if (b0 + t < 9) { in[t] = tap_locate(src[0], wv, sp, org, mp[b0 + t], tap[t]); all_in = all_in && in[t]; }
+        float v[TB][NF][8];
+#pragma unroll
+        for (int t = 0; t < TB; t++)
+            if (b0 + t < 9) tap_read<NF>(tap[t], v[t]);
+        if (__any(!all_in)) {
+#pragma unroll
+            for (int t = 0; t < TB; t++)
+                if (b0 + t < 9) {
+                    if (!in[t]) {
+                        const CellW c = locate_ijk(src[0], sp, org, mp[b0 + t]);
+                        Cell g;
+                        const int idx = c.i + __mul24(src[0].nx, c.j) + __mul24(src[0].nx * src[0].ny, c.kl);
+                        g.base = idx < 0 ? 0x80000000u : (unsigned)idx * 4u;
+                        g.fx = c.fx; g.fy = c.fy; g.fz = c.fz;
+#pragma unroll
+                        for (int f = 0; f < NF; f++) corners(src[f], g, v[t][f]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < TB; t++)
+            if (b0 + t < 9) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    const float s = blend_tap<GE1>(v[t][f], tap[t]);
+                    if (b0 + t < 8) sum[f] += w[f] * s; else value[f] = s;
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);          // (keeps the next batch's look-ups from being hoisted over this one: registers)
+    }
+}
+
+// ---- the structured map look-up (bq_device.hip.h: map9_nodes) split along z ---------------------------------------------------
+// map9_nodes interpolates a node's 3 x 3 x 3 block of map nodes along x, then y, then z.  Its first two stages work on ONE
+// plane of nodes at a time and do not depend on the node's own plane: what plane p contributes to node k is what it
+// contributes to k - 1 and k + 1.  A marching thread therefore evaluates them once per plane it enters -- the five (x tap, y tap)
+// combinations the nine taps use: four corners and the centre -- keeps the last NZ planes' results in registers and runs only
+// the z stage per node: 22 lerps per component and node instead of 48, the very same operations on the very same operands.
+// combination index: tx * 2 + ty for the corner taps (tx, ty in {0 '+', 1 '-'}), 4 for the centre
+template <int SX, int SY, bool Q4>
+__device__ __forceinline__ void map_plane_stage(const float *t, int o, float (&ly)[5])
+{
+    constexpr int NX = SX ? 2 : 3, NY = SY ? 2 : 3;
+    float N[NY][NX];
+#pragma unroll
+    for (int y = 0; y < NY; y++)
+#pragma unroll
+        for (int x = 0; x < NX; x++) N[y][x] = t[o + y * kTileX + x];
+    float LX[3][NY];
+#pragma unroll
+    for (int tx = 0; tx < 3; tx++) {
+        const int r = tap_rel(SX, tx);
+        const float c = tap_frac(SX, tx);
+#pragma unroll
+        for (int y = 0; y < NY; y++) LX[tx][y] = lerp_q<Q4>(N[y][r], N[y][r + 1], c);
+    }
+#pragma unroll
+    for (int tx = 0; tx < 2; tx++)
+#pragma unroll
+        for (int ty = 0; ty < 2; ty++) {
+            const int r = tap_rel(SY, ty);
+            ly[tx * 2 + ty] = lerp_q<Q4>(LX[tx][r], LX[tx][r + 1], tap_frac(SY, ty));
+        }
+    {
+        const int r = tap_rel(SY, 2);
+        ly[4] = lerp_q<Q4>(LX[2][r], LX[2][r + 1], tap_frac(SY, 2));
+    }
+}
+
+// the z stage: P[z] = the plane stage of map plane kl - 1 + z (NZ = 3, or 2 when the component is staggered along z)
+template <int SZ, bool Q4, int NZ>
+__device__ __forceinline__ void map_z_stage(const float (&P)[NZ][5], float (&out)[9])
+{
+#pragma unroll
+    for (int ii = 0; ii < 8; ii++) {
+        const int tx = (ii >> 2) & 1, ty = (ii >> 1) & 1, tz = ii & 1;
+        const int r = tap_rel(SZ, tz);
+        out[ii] = lerp_q<Q4>(P[r][tx * 2 + ty], P[r + 1][tx * 2 + ty], tap_frac(SZ, tz));
+    }
+    const int r = tap_rel(SZ, 2);
+    out[8] = lerp_q<Q4>(P[r][4], P[r + 1][4], tap_frac(SZ, 2));
+}
 
 // One thread's share of a plane of the field window / of the map tile, fixed for the whole march.
 struct StageSlots {
@@ -147,7 +283,7 @@ struct StageSlots {
 };
 
 template <int KIND, int SD, int NF, bool Q4>
-__global__ __launch_bounds__(256, 3) void gather_march_kernel(MarchArgs<NF> a, const float *mx, const float *my, const float *mz,
+__global__ __launch_bounds__(256, NF == 1 ? 3 : 2) void gather_march_kernel(MarchArgs<NF> a, const float *mx, const float *my, const float *mz,
                                                               Spacing sp, Grid g, int dx, int dy, int dz, int fused, int kchunk, int kw1)
 {
     __shared__ float fwin[NF * kWField];
@@ -264,11 +400,28 @@ __global__ __launch_bounds__(256, 3) void gather_march_kernel(MarchArgs<NF> a, c
     const f3 lo = KIND == kMarchAdvect ? mk3(h, h, h) : mk3(0.f, 0.f, 0.f);
     const f3 hi = KIND == kMarchAdvect ? mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h)
                                        : mk3(h * (float)g.ni, h * (float)g.nj, h * (float)g.nkg);
+    // plane stages of the map look-up carried from node to node (map_plane_stage): P[c][z] belongs to map plane k - 1 + z
+    constexpr int SXc = SD == 1, SYc = SD == 2, SZc = SD == 3;
+    constexpr int NZ = SZc ? 2 : 3;
+    // ZR: carry them (45 more live registers).  Measured at 256^3 (profiles/r04_e_*): the two-field kernels, which LDS holds at
+    // two waves per SIMD anyway, run 4-10 % faster with it; the single-field kernels need their third wave more than the 12 %
+    // fewer instructions (332 -> 395 us at two waves) and re-evaluate all NZ planes per node instead, as map9_nodes does.
+    constexpr bool ZR = NF == 2 && !(KIND == kMarchCompensate && SD == 0);
+    float P[3][NZ][5];
+    const float *mt = mring + threadIdx.y * kTileX + threadIdx.x;
+    if (ZR && ij_in) {
+#pragma unroll
+        for (int z = 0; z < NZ - 1; z++) {
+            const int o = ((kb - 1 + z) & (kMR - 1)) * kMPS;
+#pragma unroll
+            for (int c = 0; c < 3; c++) map_plane_stage<SXc, SYc, Q4>(mt + c * (kTileX * kTileY), o, P[c][z]);
+        }
+    }
     WindowView wv;
     wv.xlo = max(i0 - kWXoff, 0);           wv.xspan = min(i0 - kWXoff + kWX - 1, nbi - 1) - 1 - wv.xlo;
     wv.ylo = max(j0 - kWYoff, 0);           wv.yspan = min(j0 - kWYoff + kWY - 1, nbj - 1) - 1 - wv.ylo;
-    wv.addr0 = (int)(unsigned)(size_t)fwin - ((i0 - kWXoff) * 4 + (j0 - kWYoff) * (kWX * 4));
-    const float *mt = mring + threadIdx.y * kTileX + threadIdx.x;
+    wv.base = (int)(unsigned)(size_t)fwin;
+    wv.addr0 = wv.base - ((i0 - kWXoff) * 4 + (j0 - kWYoff) * (kWX * 4));
 
     for (int k = kb; k < ke; k++) {
         const int kg = k + g.koff;
@@ -280,17 +433,27 @@ __global__ __launch_bounds__(256, 3) void gather_march_kernel(MarchArgs<NF> a, c
         if (more) { load_field_plane(k + kWD + 2, rf); load_map_plane(k + 2, rm); }
         float init_own[NF];
         housekeeping(k, active, init_own);
+        if (ZR && ij_in) {                                  // the newest map plane this node touches: k + 1 (k when staggered along z)
+            const int o = ((k + NZ - 2) & (kMR - 1)) * kMPS;
+#pragma unroll
+            for (int c = 0; c < 3; c++) map_plane_stage<SXc, SYc, Q4>(mt + c * (kTileX * kTileY), o, P[c][NZ - 1]);
+        }
         if (active) {
+            if (!ZR) {
+#pragma unroll
+                for (int z = 0; z < NZ; z++) {
+                    const int o = ((k - 1 + z) & (kMR - 1)) * kMPS;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) map_plane_stage<SXc, SYc, Q4>(mt + c * (kTileX * kTileY), o, P[c][z]);
+                }
+            }
             wv.zlo = max(k - kWD - 1, 0);   wv.zspan = min(k + kWD + 1, nbk - 1) - 1 - wv.zlo;
             f3 mp[9];
             {
-                const NodesRing nx_{mt, ((k - 1) & (kMR - 1)) * kMPS, (k & (kMR - 1)) * kMPS, ((k + 1) & (kMR - 1)) * kMPS};
-                const NodesRing ny_{mt + kTileX * kTileY, nx_.o0, nx_.o1, nx_.o2};
-                const NodesRing nz_{mt + 2 * kTileX * kTileY, nx_.o0, nx_.o1, nx_.o2};
                 float x9[9], y9[9], z9[9];
-                map9_nodes<SD == 1, SD == 2, SD == 3, NodesRing, Q4>(nx_, x9);
-                map9_nodes<SD == 1, SD == 2, SD == 3, NodesRing, Q4>(ny_, y9);
-                map9_nodes<SD == 1, SD == 2, SD == 3, NodesRing, Q4>(nz_, z9);
+                map_z_stage<SZc, Q4, NZ>(P[0], x9);
+                map_z_stage<SZc, Q4, NZ>(P[1], y9);
+                map_z_stage<SZc, Q4, NZ>(P[2], z9);
 #pragma unroll
                 for (int t = 0; t < 9; t++) mp[t] = mk3(x9[t], y9[t], z9[t]);
             }
@@ -313,9 +476,19 @@ __global__ __launch_bounds__(256, 3) void gather_march_kernel(MarchArgs<NF> a, c
             float sum[NF], value[NF], w[NF];
 #pragma unroll
             for (int f = 0; f < NF; f++) { sum[f] = 0.f; w[f] = KIND == kMarchCumulate ? 0.125f * a.coeff[f] : 0.125f; }
-            if (KIND == kMarchAdvect) blend9_window<NF, true>(src, wv, sp, n.org, mp, w, sum, value);
-            else if (kTestGe && ge1)  blend9_window<NF, true>(src, wv, sp, n.org, mp, w, sum, value);
-            else                      blend9_window<NF, false>(src, wv, sp, n.org, mp, w, sum, value);
+            // 0: tap by tap; 3 / 5: batches (see blend9_window).  The two-field advection (unstaggered, forward-free map
+            // border: every tap in the window) is the one launch the batched form serves better: 487 against 531 / 619 us
+            constexpr int TB = (KIND == kMarchAdvect && NF == 2) ? 3 : 0;
+            if constexpr (TB == 0) {
+                if (KIND == kMarchAdvect) blend9_window_pertap<NF, true>(src, wv, sp, n.org, mp, w, sum, value);
+                else if (kTestGe && ge1)  blend9_window_pertap<NF, true>(src, wv, sp, n.org, mp, w, sum, value);
+                else                      blend9_window_pertap<NF, false>(src, wv, sp, n.org, mp, w, sum, value);
+            } else {
+                constexpr int TBB = TB > 0 ? TB : 3;
+                if (KIND == kMarchAdvect) blend9_window<NF, true, TBB>(src, wv, sp, n.org, mp, w, sum, value);
+                else if (kTestGe && ge1)  blend9_window<NF, true, TBB>(src, wv, sp, n.org, mp, w, sum, value);
+                else                      blend9_window<NF, false, TBB>(src, wv, sp, n.org, mp, w, sum, value);
+            }
             const size_t id = id0 + plane * k;
 #pragma unroll
             for (int f = 0; f < NF; f++) {
@@ -325,6 +498,14 @@ __global__ __launch_bounds__(256, 3) void gather_march_kernel(MarchArgs<NF> a, c
                     a.out[f][id] += (float)(0.5 * (double)sum[f] + 0.5 * (double)v);
                 } else a.out[f][id] = (float)(0.5 * (double)sum[f] + 0.5 * (double)value[f]) - init_own[f];
             }
+        }
+        if (ZR && ij_in) {                                  // the planes move down by one for the next node
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int z = 0; z < NZ - 1; z++)
+#pragma unroll
+                    for (int q = 0; q < 5; q++) P[c][z][q] = P[c][z + 1][q];
         }
         if (more) { store_field_plane(k + kWD + 2, rf); store_map_plane(k + 2, rm); }
         __syncthreads();

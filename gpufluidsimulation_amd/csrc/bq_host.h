@@ -35,7 +35,7 @@ struct Runtime {
     int         opt_profile_comm = 0;       // FL_OPT_PROFILE_COMM: time the compute stream's waits on the halo stream
     int         opt_mgcg_bottom = 1;        // FL_OPT_MGCG_BOTTOM: the two coarsest V-cycle levels in one launch
     int         opt_comm_check = 0;         // FL_OPT_COMM_CHECK: ledger of communicator calls (bq_halo.hip)
-    int         opt_field_window = 0;       // FL_OPT_FIELD_WINDOW: 0 off, 1 auto chunk, k > 1 planes per block
+    int         opt_field_window = -1;      // FL_OPT_FIELD_WINDOW: -1 auto (on with FL_OPT_FAST_LERP), 0 off, 1 on, k > 1 planes per block
     int         opt_reserve_cus = 0;        // FL_OPT_RESERVE_CUS: CUs the compute stream leaves to the halo stream's RCCL kernels
     int         device_cus = 0;             // CUs of the device (hipDeviceProp_t::multiProcessorCount), set by fl_init
     int         num_cus = 256;              // CUs the compute stream may use (device CUs - opt_reserve_cus)

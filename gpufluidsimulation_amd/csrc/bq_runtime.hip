@@ -157,7 +157,7 @@ int fl_init(int device)
         // BQ_FIELD_WINDOW = k (environment): initial value of FL_OPT_FIELD_WINDOW for every context of the process -- lets a
         // whole program (the C++ drivers, the multi-process tests) run the z-marching gather kernels without a code change
         const char *env = getenv("BQ_FIELD_WINDOW");
-        if (env && *env) g_rt.opt_field_window = atoi(env) < 0 ? 0 : atoi(env);
+        if (env && *env) g_rt.opt_field_window = atoi(env) < 0 ? -1 : atoi(env);
     }
     g_rt.device = device;
     g_rt.ready = true;
@@ -416,7 +416,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_MGCG_TILE:       g_rt.opt_mgcg_tile = value < 0 ? 0 : value; break;
     case FL_OPT_PROFILE_COMM:    g_rt.opt_profile_comm = value != 0; break;
     case FL_OPT_MGCG_BOTTOM:     g_rt.opt_mgcg_bottom = value != 0; break;
-    case FL_OPT_FIELD_WINDOW:    g_rt.opt_field_window = value < 0 ? 0 : value; break;
+    case FL_OPT_FIELD_WINDOW:    g_rt.opt_field_window = value < 0 ? -1 : value; break;
     case FL_OPT_COMM_CHECK:      g_rt.opt_comm_check = value != 0; break;
     case FL_OPT_RESERVE_CUS: {
         const int k = value < 0 ? 0 : value;

@@ -23,3 +23,13 @@ def leapfrog(nz_global, h):
     yc = 0.5 + 0.37 * h
     zc = 0.5 * nz_global * h + 0.29 * h
     return [(0.15, yc, zc, 0.08, 1.0, 0.0, 1.0, 10), (0.35, yc, zc, 0.08, 1.0, 0.0, 1.0, 10)]
+
+
+def collision(h):
+    """the reference binary's own scene (src/bimocq3D/main.cpp:28-80 with the constants BimocqGPUSolver::emitSmoke hard-codes,
+    BimocqGPUSolver.cpp:386-389): two spheres of radius 0.015 at x = 0.04 and x = 0.16 of a 0.2 x 0.4 x 0.4 box blowing vortex
+    rings at each other (emiter +1 / -1), density 1, temperature 50, 10 frames, no buoyancy.  The first ring's axis, which the
+    reference puts at y = z = 0.2 -- node (100, 100) of its 0.002 grid, where the emitter's direction normalisation is 0/0 (SURVEY
+    Q14) -- is nudged off the nodes exactly as the reference nudges its second one (y = 0.201)."""
+    return [(0.04, 0.2 + 0.37 * h, 0.2 + 0.29 * h, 0.015, 1.0, 50.0, 1.0, 10),
+            (0.16, 0.201, 0.2, 0.015, 1.0, 50.0, -1.0, 10)]

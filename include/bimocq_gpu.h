@@ -329,7 +329,10 @@ enum {
                                  * spacing: k > 0 runs them as z-marching blocks that read the sampled field out of a rolling
                                  * LDS window (bq_gather_march.hip.h) instead of gathering every corner from memory; a tap
                                  * outside the window takes the direct path, so values never change.  k = planes marched per
-                                 * block (1 = auto).  0: the one-plane kernels.                                       */
+                                 * block (1 = chosen by the launcher).  0: the one-plane kernels.  Negative (default): on
+                                 * with FL_OPT_FAST_LERP, whose kernels it speeds up, off in the exact arithmetic, which is
+                                 * bound by its double-rounded lerps either way.  BQ_FIELD_WINDOW in the environment sets
+                                 * the initial value.                                                                 */
     FL_OPT_COMM_CHECK      = 19,/* 1: every RCCL call of the z-slab path (ncclSend / ncclRecv of the exchanges, the scalar
                                  * all-reduces) is entered into a per-rank ledger that fl_comm_check() compares across the
                                  * ranks; the host solver calls it at the end of every step while the option is on.  A

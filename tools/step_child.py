@@ -14,11 +14,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--jacobi-iters", type=int, default=6)
+    ap.add_argument("--fl-opt", action="append", default=[], metavar="ID=VALUE", help="fl_set_option(ID, VALUE) before the run")
     a = ap.parse_args()
     import gpufluidsimulation_amd as bq
     from gpufluidsimulation_amd.scenes import rising_smoke
     from gpufluidsimulation_amd.solver import BimocqGPUSolver
     n = a.n
+    for kv in a.fl_opt:
+        k, v = kv.split("=")
+        bq.hip_lib().fl_set_option(int(k), int(v))
     s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0)
     s.setSmoke(0.0, 1.0, rising_smoke(n, 1.0 / n))
     s.setProjection(a.jacobi_iters, 0.5)
