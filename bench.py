@@ -858,6 +858,7 @@ def main():
         # exact fields where the north star states its tolerance: 128^3 after 200 steps (both trajectories on this GPU; the
         # exact one is the trajectory tests/golden pins against the CPU oracle)
         try:
+            import numpy as np
             L_ = bq._lib
             legs_v = {}
             for tag, fast_, win_ in (("exact", 0, 0), ("fast", 1, 0), ("fast_window", 1, 1)):

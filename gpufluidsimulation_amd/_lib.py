@@ -87,6 +87,8 @@ HIP_SIGS = {
     "gpu_max_field_owned": (c_f, [VP, c_i, c_i, c_i]),
     "gpu_map_travel_z": (None, [VP, VP, c_f, c_i, c_i, c_i, C.POINTER(c_f)]),
     "gpu_smoothing_jacobi": (None, [VP, VP, VP, c_d, c_d, c_i, c_i, c_i, c_i]),
+    "gpu_mgcg_slab_supported": (c_i, [c_i] * 8),
+    "gpu_multi_grid_conjugate_gradient_slab": (None, [VP, VP, VP, VP] + [c_i] * 7 + [c_d]),
     "gpu_gradient_delta": (None, [VP] * 7 + [c_i, c_i, c_i, c_f]),
     "gpu_jacobi_sweep_range": (None, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "gpu_jacobi_sweep_pair_ranges": (c_i, [VP, VP, VP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <type_traits>
+#include <vector>
 
 namespace bq {
 inline namespace BQ_VARIANT {
@@ -35,7 +36,8 @@ static const dim3 kBlock(64, 4, 1);
     const int kg = k + g.koff;                                                                \
     const bool block_out = !((klo) < kg && kg < (khi)) || i0 + 63 <= (ilo) || i0 >= (ihi) || j0 + 3 <= (jlo) || j0 >= (jhi); \
     const bool active = !block_out && (ilo) < i && i < (ihi) && (jlo) < j && j < (jhi);
-template <bool P2, bool PT, int SD> constexpr bool kStaged = P2 && !PT && SD >= 0;
+// (SD >= 0 with P2: compile-time taps; SD >= 0 without P2: the tabled form for other spacings, bq_device.hip.h: MapTabs)
+template <bool P2, bool PT, int SD> constexpr bool kStaged = !PT && SD >= 0;
 
 // CELL dims of the LOCAL buffers plus the z-slab context: local plane k is global plane k + koff of a
 // grid with nkg cell planes (single GPU: koff = 0, nkg = nk).  Index windows, positions and clamps
@@ -217,7 +219,7 @@ template <int NF> struct CompensateArgs { const float *src[NF]; float *init[NF];
 template <bool P2, bool PT, int SD, int NF, bool Q4 = false>
 __global__ __launch_bounds__(256, NF == 1 ? 7 : 5) void advect_kernel(AdvectArgs<NF> a,
                                                      const float *bx, const float *by, const float *bz,
-                                                     Spacing sp, Grid g, int dx, int dy, int dz, int fused)
+                                                     Spacing sp, Grid g, int dx, int dy, int dz, int fused, MapTabs tabs)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK_WINDOW(2 + dx, nbi - 3, 2 + dy, nbj - 3, 2 + dz, g.nkg + dz - 3)
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(256, NF == 1 ? 7 : 5) void advect_kernel(AdvectArgs
         const Field mf[3] = {back.x, back.y, back.z};
         stage_tiles<3>(mf, i0, j0, k, tile);
         if (!active) return;
-        map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
+        if constexpr (P2) map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
+        else map9_lds_tab<SD == 1, SD == 2, SD == 3>(tile, tabs, i, j, kg, mp);
     } else {
         if (!active) return;
         mapped9<P2, PT, SD>(back, sp, n, c, i, j, k, mp);
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void unit_blend_kernel(float *field, Grid g, i
 template <bool P2, bool PT, int SD, int NF, bool ID, bool Q4 = false>
 __global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void cumulate_kernel(CumulateArgs<NF> a,
                                                        const float *mx, const float *my, const float *mz,
-                                                       Spacing sp, Grid g, int dx, int dy, int dz)
+                                                       Spacing sp, Grid g, int dx, int dy, int dz, MapTabs tabs)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK_WINDOW(1 + dx, nbi - 2, 1 + dy, nbj - 2, 1 + dz, g.nkg + dz - 2)
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void cumulate_kernel(Cumulate
     f3 c = nine_centre(n, i, j, kg);
     const size_t id = (size_t)i + (size_t)nbi * j + (size_t)nbi * nbj * k;
     __shared__ float tile[kStaged<P2, PT, SD> && !ID ? 3 * kTile : 1];
+    (void)tabs;
     if constexpr (ID) {
         // Identity map (node n holds n*h), power-of-two spacing.  A map component then varies along its
         // own axis only; map9's lerps along the other two axes combine equal values (lerp(a, a, c) == a
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void cumulate_kernel(Cumulate
         const Field mf[3] = {m.x, m.y, m.z};
         stage_tiles<3>(mf, i0, j0, k, tile);
         if (!active) return;
-        map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
+        if constexpr (P2) map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
+        else map9_lds_tab<SD == 1, SD == 2, SD == 3>(tile, tabs, i, j, kg, mp);
     } else {
         if (!active) return;
         mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void wall_fixup_kernel(const float *src, int s
 template <bool P2, bool PT, int SD, int NF, bool Q4 = false>
 __global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void compensate_kernel(CompensateArgs<NF> a,
                                                          const float *mx, const float *my, const float *mz,
-                                                         Spacing sp, Grid g, int dx, int dy, int dz, int fused)
+                                                         Spacing sp, Grid g, int dx, int dy, int dz, int fused, MapTabs tabs)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK_WINDOW(1 + dx, nbi - 2, 1 + dy, nbj - 2, 1 + dz, g.nkg + dz - 2)
@@ -448,7 +453,8 @@ __global__ __launch_bounds__(256, NF == 1 ? 7 : 6) void compensate_kernel(Compen
         const Field mf[3] = {m.x, m.y, m.z};
         stage_tiles<3>(mf, i0, j0, k, tile);
         if (!active) return;
-        map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
+        if constexpr (P2) map9_lds<SD == 1, SD == 2, SD == 3, Q4>(tile, mp);
+        else map9_lds_tab<SD == 1, SD == 2, SD == 3>(tile, tabs, i, j, kg, mp);
     } else {
         if (!active) return;
         mapped9<P2, PT, SD>(m, sp, n, c, i, j, k, mp);
@@ -652,13 +658,85 @@ static bool dims_ok(int ni, int nj, int nk, const char *op)
         BQ_LAUNCH_CHECK(#KERNEL);                                                                           \
     } while (0)
 
+// ---- tables of the structured look-up for spacings that are not a power of two (bq_device.hip.h: MapTabs) ----------------
+// For every axis, stagger S and tap t the host evaluates, index by index, exactly what the kernels' generic path evaluates
+// per tap: nine_centre ((float)idx * h + org, org = -S * 0.5f * h), nine_corner (+- 0.25f * h), map_at's locate with the
+// map's origin 0 ((pos - 0.f) / h, floor, q - (float)floor) -- this translation unit is compiled -ffp-contract=off and the
+// division is IEEE on both sides, so the numbers are the device's.  A pair (axis, S) conforms when the '+' / '-' taps land in
+// the cell exact arithmetic predicts for every index >= 2 and the centre tap in that cell or the one below (unstaggered) --
+// anything else (never seen) sends launches that need the pair down the generic path.
+// Built once per (h, dims) and context; z is tabulated over the GLOBAL planes.
+static MapTabs map_tabs(const Spacing &sp, const Grid &g, int *ok_mask)
+{
+    Runtime &r = rt();
+    const int dims[3] = { g.ni, g.nj, g.nkg };
+    if (r.map_tab_dev && r.map_tab_h == sp.h && r.map_tab_dims[0] == dims[0] && r.map_tab_dims[1] == dims[1] && r.map_tab_dims[2] == dims[2]) {
+        *ok_mask = r.map_tab_ok;
+        return MapTabs{ r.map_tab_dev, r.map_tab_dev + 18 * (size_t)r.map_tab_stride, r.map_tab_stride };
+    }
+    *ok_mask = 0;
+    const int stride = std::max(dims[0], std::max(dims[1], dims[2])) + 2;
+    std::vector<float> host((size_t)36 * stride, 0.f);              // 18 frac arrays, then 18 rel arrays
+    const float h = sp.h, q = 0.25f * h, mq = -0.25f * h;
+    int ok = 0;
+    for (int a = 0; a < 3; a++)
+        for (int S = 0; S < 2; S++) {
+            bool conform = true;
+            const float org = -(float)S * 0.5f * h;
+            for (int t = 0; t < 3; t++) {
+                float *frac = host.data() + (size_t)((a * 2 + S) * 3 + t) * stride;
+                float *rel = frac + (size_t)18 * stride;
+                for (int idx = 0; idx < dims[a] + S && idx < stride; idx++) {
+                    const float c = (float)idx * h + org;
+                    const float pos = t == 0 ? c + q : (t == 1 ? c + mq : c);
+                    const float qx = (pos - 0.f) / h;
+                    const float fl = floorf(qx);
+                    const int cell = (int)fl;
+                    frac[idx] = qx - (float)cell;
+                    const int r0 = cell - (idx - 1);                // relative to the node block's first node
+                    rel[idx] = (float)r0;
+                    if (idx < 2) continue;                          // (never inside an operator's index window)
+                    const int expect = S ? 0 : (t == 1 ? 0 : 1);    // tap_rel
+                    if (t < 2 || S) { if (r0 != expect) conform = false; }
+                    else if (r0 != 0 && r0 != 1) conform = false;
+                }
+            }
+            if (conform) ok |= 1 << (a * 2 + S);
+        }
+    if (r.map_tab_dev) { (void)hipStreamSynchronize(r.compute); (void)hipFree(r.map_tab_dev); r.map_tab_dev = nullptr; }
+    if (!BQ_HIP(hipMalloc((void **)&r.map_tab_dev, host.size() * sizeof(float)))) { r.map_tab_dev = nullptr; return MapTabs{ nullptr, nullptr, 0 }; }
+    // (a blocking copy from pageable memory: once per grid)
+    if (!BQ_HIP(hipMemcpy(r.map_tab_dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice))) return MapTabs{ nullptr, nullptr, 0 };
+    r.map_tab_h = sp.h; r.map_tab_dims[0] = dims[0]; r.map_tab_dims[1] = dims[1]; r.map_tab_dims[2] = dims[2];
+    r.map_tab_stride = stride; r.map_tab_ok = ok;
+    *ok_mask = ok;
+    return MapTabs{ r.map_tab_dev, r.map_tab_dev + 18 * (size_t)stride, stride };
+}
+// the (axis, stagger) pairs a launch with staggered axis sd (0 none, 1 x, 2 y, 3 z) needs
+static inline bool tabs_cover(int ok_mask, int sd)
+{
+    const int need = (1 << (0 * 2 + (sd == 1))) | (1 << (1 * 2 + (sd == 2))) | (1 << (2 * 2 + (sd == 3)));
+    return (ok_mask & need) == need;
+}
+
 // Runtime (pow2 spacing, point sampling, staggered axis) -> compile-time <P2, PT, SD>; fn receives three
-// integral_constant tags.  Returns whether the structured power-of-two path was taken.
+// integral_constant tags.  Returns whether a structured path was taken.  tabled: the spacing is not a power of two but the
+// look-up tables cover this launch (map_tabs / tabs_cover) -- the structured kernels with P2 = false.
 template <class Fn>
-static bool dispatch_sd(bool p2, bool pt, int sd, Fn &&fn)
+static bool dispatch_sd(bool p2, bool pt, int sd, Fn &&fn, bool tabled = false)
 {
     using T = std::true_type; using F = std::false_type;
     bool structured = false;
+    if (!p2 && !pt && tabled && rt().opt_structured_maps) {
+        structured = true;
+        switch (sd) {
+        case 0:  fn(F{}, F{}, std::integral_constant<int, 0>{}); break;
+        case 1:  fn(F{}, F{}, std::integral_constant<int, 1>{}); break;
+        case 2:  fn(F{}, F{}, std::integral_constant<int, 2>{}); break;
+        default: fn(F{}, F{}, std::integral_constant<int, 3>{}); break;
+        }
+        return structured;
+    }
     if (p2 && !pt && rt().opt_structured_maps) {
         structured = true;
         switch (sd) {
@@ -736,14 +814,16 @@ static void advect_multi(AdvectArgs<NF> a, const float *bx, const float *by, con
         for (int f = 0; f < NF; f++) { ma.src[f] = a.init[f]; ma.out[f] = a.field[f]; ma.aux[f] = nullptr; ma.coeff[f] = 1.f; }
         if (march_launch<kMarchAdvect, NF>(ma, bx, by, bz, sp, g, planes, dx, dy, dz, pt, q4, rt().opt_fused_housekeeping)) return;
     }
+    int tab_ok = 0;
+    const MapTabs tabs = (!sp.pow2 && !pt && rt().opt_structured_maps) ? map_tabs(sp, g, &tab_ok) : MapTabs{ nullptr, nullptr, 0 };
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
         constexpr int sd = decltype(SD)::value;
-        if constexpr (kStaged<p2, ptc, sd>) {
-            if (q4) { advect_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping); return; }
+        if constexpr (p2 && kStaged<p2, ptc, sd>) {
+            if (q4) { advect_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping, tabs); return; }
         }
-        advect_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
-    });
+        advect_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, bx, by, bz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping, tabs);
+    }, tabs.frac && tabs_cover(tab_ok, stag_axis(dx, dy, dz)));
     BQ_LAUNCH_CHECK("advect_kernel");
 }
 // identity: the caller vouches that mx/my/mz hold the identity map of gpu_init_maps; the shortcut is
@@ -762,15 +842,17 @@ static void cumulate_multi(CumulateArgs<NF> a, const float *mx, const float *my,
         for (int f = 0; f < NF; f++) { ma.src[f] = a.src[f]; ma.out[f] = a.dst[f]; ma.aux[f] = nullptr; ma.coeff[f] = a.coeff[f]; }
         if (march_launch<kMarchCumulate, NF>(ma, mx, my, mz, sp, g, planes, dx, dy, dz, pt, rt().opt_map_quarter_fp32 != 0, 0)) return;
     }
+    int tab_ok = 0;
+    const MapTabs tabs = (!sp.pow2 && !pt && rt().opt_structured_maps) ? map_tabs(sp, g, &tab_ok) : MapTabs{ nullptr, nullptr, 0 };
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
         constexpr int sd = decltype(SD)::value;
         if constexpr (p2 && !ptc && sd >= 0) {
-            if (identity) { cumulate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz); return; }
-            if (rt().opt_map_quarter_fp32) { cumulate_kernel<p2, ptc, sd, NF, false, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz); return; }
+            if (identity) { cumulate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, tabs); return; }
+            if (rt().opt_map_quarter_fp32) { cumulate_kernel<p2, ptc, sd, NF, false, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, tabs); return; }
         }
-        cumulate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz);
-    });
+        cumulate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, tabs);
+    }, tabs.frac && tabs_cover(tab_ok, stag_axis(dx, dy, dz)));
     BQ_LAUNCH_CHECK("cumulate_kernel");
 }
 template <int NF>
@@ -788,14 +870,16 @@ static void compensate_multi(CompensateArgs<NF> a, const float *mx, const float 
         for (int f = 0; f < NF; f++) { ma.src[f] = a.src[f]; ma.out[f] = a.err[f]; ma.aux[f] = a.init[f]; ma.coeff[f] = 1.f; }
         if (march_launch<kMarchCompensate, NF>(ma, mx, my, mz, sp, g, planes, dx, dy, dz, pt, q4, rt().opt_fused_housekeeping)) return;
     }
+    int tab_ok = 0;
+    const MapTabs tabs = (!sp.pow2 && !pt && rt().opt_structured_maps) ? map_tabs(sp, g, &tab_ok) : MapTabs{ nullptr, nullptr, 0 };
     dispatch_sd(sp.pow2, pt, stag_axis(dx, dy, dz), [&](auto P2, auto PT, auto SD) {
         constexpr bool p2 = decltype(P2)::value, ptc = decltype(PT)::value;
         constexpr int sd = decltype(SD)::value;
-        if constexpr (kStaged<p2, ptc, sd>) {
-            if (q4) { compensate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping); return; }
+        if constexpr (p2 && kStaged<p2, ptc, sd>) {
+            if (q4) { compensate_kernel<p2, ptc, sd, NF, true><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping, tabs); return; }
         }
-        compensate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping);
-    });
+        compensate_kernel<p2, ptc, sd, NF, false><<<grid, kBlock, 0, st>>>(a, mx, my, mz, sp, g, dx, dy, dz, rt().opt_fused_housekeeping, tabs);
+    }, tabs.frac && tabs_cover(tab_ok, stag_axis(dx, dy, dz)));
     BQ_LAUNCH_CHECK("compensate_kernel");
 }
 

@@ -425,6 +425,101 @@ __device__ __forceinline__ void map9(const Map3 &m, int i, int j, int kl, f3 out
     for (int a = 0; a < 9; a++) out[a] = mk3(x[a], y[a], z[a]);
 }
 
+// ---- the structured look-up on spacings that are NOT a power of two (round 4) -----------------------------------------------
+// With h = 2^-m the nine sample points of a node hit the map at compile-time cells and weights (above).  For any other h --
+// the reference's own scene has h = 0.002 -- the generic path evaluates (pos - off) / h per tap: 27 IEEE divisions and 72
+// loads per map component and node, which is what made those grids 3x slower per voxel.  But a tap's cell and weight along
+// an axis depend on the node's index along THAT axis, the tap (+, -, centre) and the stagger only, so the host evaluates the
+// very expressions of nine_centre / nine_corner / locate once per index (bq_advect.hip: map_tabs) and the kernels read
+//     frac[axis][S][tap][index]      the weight q - floor(q)
+//     rel [axis][S][centre][index]   0 / 1: the centre tap's cell relative to the node block's first node
+// The '+' / '-' taps land in the cell exact arithmetic predicts for every index of every spacing tried (the table builder
+// verifies it, else the launch takes the generic path); the centre tap of an unstaggered axis, (i h) / h, rounds to just below
+// i for a few indices (63, 125, 126 at h = 0.002f) and then reads cell i - 1 with weight 1 - 2^-24: hence `rel`.  The lerps
+// are the contract's general form (weights are no longer multiples of 1/4), shared between taps exactly as in map9_nodes:
+// same operations on the same operands as locate() + gather(), hence the same bits.
+struct MapTabs { const float *frac; const float *rel; int stride; };
+__device__ __forceinline__ int tab_at(int axis, int S, int tap, int stride) { return ((axis * 2 + S) * 3 + tap) * stride; }
+
+// out[0..7]: corners in the reference's order, out[8]: centre.  f?[t]: weight of tap t along the axis; r?: the centre
+// tap's relative cell (0 or 1 on an unstaggered axis, 0 on the staggered one)
+template <int SX, int SY, int SZ, class Nodes>
+__device__ __forceinline__ void map9_nodes_tab(const Nodes &node, const float (&fx)[3], const float (&fy)[3], const float (&fz)[3],
+                                               int rcx, int rcy, int rcz, float out[9])
+{
+    constexpr int NX = SX ? 2 : 3, NY = SY ? 2 : 3, NZ = SZ ? 2 : 3;
+    float N[NZ][NY][NX];
+#pragma unroll
+    for (int z = 0; z < NZ; z++)
+#pragma unroll
+        for (int y = 0; y < NY; y++)
+#pragma unroll
+            for (int x = 0; x < NX; x++) N[z][y][x] = node(x, y, z);
+    auto lerp = [](float a, float b, float c) { return lerp_w<false>(a, b, c, 1.0 - (double)c); };
+    float LX[3][NZ][NY];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int z = 0; z < NZ; z++)
+#pragma unroll
+            for (int y = 0; y < NY; y++) {
+                float a, b;
+                if (t < 2 || SX) { const int r = tap_rel(SX, t); a = N[z][y][r]; b = N[z][y][r + 1]; }
+                else { a = rcx ? N[z][y][1] : N[z][y][0]; b = rcx ? N[z][y][NX - 1] : N[z][y][1]; }
+                LX[t][z][y] = lerp(a, b, fx[t]);
+            }
+    }
+    float LY[3][3][NZ];
+#pragma unroll
+    for (int tx = 0; tx < 3; tx++)
+#pragma unroll
+        for (int ty = 0; ty < 3; ty++) {
+            if ((tx == 2) != (ty == 2)) continue;
+#pragma unroll
+            for (int z = 0; z < NZ; z++) {
+                float a, b;
+                if (ty < 2 || SY) { const int r = tap_rel(SY, ty); a = LX[tx][z][r]; b = LX[tx][z][r + 1]; }
+                else { a = rcy ? LX[tx][z][1] : LX[tx][z][0]; b = rcy ? LX[tx][z][NY - 1] : LX[tx][z][1]; }
+                LY[tx][ty][z] = lerp(a, b, fy[ty]);
+            }
+        }
+#pragma unroll
+    for (int ii = 0; ii < 8; ii++) {
+        const int tx = (ii >> 2) & 1, ty = (ii >> 1) & 1, tz = ii & 1;
+        const int r = tap_rel(SZ, tz);
+        out[ii] = lerp(LY[tx][ty][r], LY[tx][ty][r + 1], fz[tz]);
+    }
+    {
+        float a, b;
+        if (SZ) { a = LY[2][2][0]; b = LY[2][2][1]; }
+        else { a = rcz ? LY[2][2][1] : LY[2][2][0]; b = rcz ? LY[2][2][NZ - 1] : LY[2][2][1]; }
+        out[8] = lerp(a, b, fz[2]);
+    }
+}
+
+// (i, j, kg): the node's indices in the map's GLOBAL index space (the tables are global along z)
+template <int SX, int SY, int SZ>
+__device__ __forceinline__ void map9_lds_tab(const float *tile, const MapTabs &tb, int i, int j, int kg, f3 out[9])
+{
+    float fx[3], fy[3], fz[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        fx[t] = tb.frac[tab_at(0, SX, t, tb.stride) + i];
+        fy[t] = tb.frac[tab_at(1, SY, t, tb.stride) + j];
+        fz[t] = tb.frac[tab_at(2, SZ, t, tb.stride) + kg];
+    }
+    const int rcx = SX ? 0 : (int)tb.rel[tab_at(0, 0, 2, tb.stride) + i];
+    const int rcy = SY ? 0 : (int)tb.rel[tab_at(1, 0, 2, tb.stride) + j];
+    const int rcz = SZ ? 0 : (int)tb.rel[tab_at(2, 0, 2, tb.stride) + kg];
+    const float *t = tile + threadIdx.y * kTileX + threadIdx.x;
+    float x[9], y[9], z[9];
+    map9_nodes_tab<SX, SY, SZ, NodesLds>(NodesLds{t}, fx, fy, fz, rcx, rcy, rcz, x);
+    map9_nodes_tab<SX, SY, SZ, NodesLds>(NodesLds{t + kTile}, fx, fy, fz, rcx, rcy, rcz, y);
+    map9_nodes_tab<SX, SY, SZ, NodesLds>(NodesLds{t + 2 * kTile}, fx, fy, fz, rcx, rcy, rcz, z);
+#pragma unroll
+    for (int a = 0; a < 9; a++) out[a] = mk3(x[a], y[a], z[a]);
+}
+
 // MAC velocity (GPU_kernel.cu:64-72)
 struct Vel3 { Field u, v, w; };
 

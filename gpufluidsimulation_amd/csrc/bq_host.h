@@ -57,6 +57,11 @@ struct Runtime {
     // the sweep-profile spans and plane range (bq_project.hip), the cached V-cycle graphs (bq_mgcg.hip).  Allocated on first
     // use, released by fl_shutdown through the *_release hooks below.
     void  *halo_state = nullptr, *project_state = nullptr, *mgcg_state = nullptr;
+    // tables of the structured map look-up on spacings that are not a power of two (bq_advect.hip: map_tabs): device
+    // arrays frac / rel, what they were built for, and which (axis, stagger) pairs conform (bit 2 * axis + S)
+    float *map_tab_dev = nullptr;
+    float  map_tab_h = 0.f;
+    int    map_tab_dims[3] = {0, 0, 0}, map_tab_stride = 0, map_tab_ok = 0;
     int    nonfinite_seen = 0;          // sticky: a gpu_max_abs3 met a NaN or an Inf (fl_nonfinite_seen)
     const char *mg_smooth_kernel = ""; // the fused kernel the last fp64 smoothing call launched first (fl_mg_smooth_kernel_name)
 };

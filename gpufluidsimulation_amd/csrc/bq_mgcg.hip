@@ -1563,6 +1563,21 @@ static void mg_residual(double *r, const double *b, const double *x, int ni, int
     BQ_LAUNCH_CHECK("mg_residual_kernel");
 }
 
+// calc_sum over the nb block partials of a dot product -> result[iter_index] (the second half of mg_dot; the z-slab solver
+// runs it on partials gathered from all ranks)
+static void mg_dot_finish(const double *partials, double *result, unsigned nb, int iter_index)
+{
+    const size_t per_thread = (nb + 255) / 256;
+    double *rows = per_thread >= 16 ? (double *)scratch(256 * sizeof(double)) : nullptr;
+    if (rows) {
+        mg_calc_sum_rows_kernel<<<16, 256, 0, rt().compute>>>(partials, rows, nb, per_thread);
+        mg_calc_sum_tree_kernel<<<1, 64, 0, rt().compute>>>(rows, result, iter_index);
+    } else {
+        mg_calc_sum_kernel<<<1, 256, 0, rt().compute>>>(partials, result, nb, per_thread, iter_index);
+    }
+    BQ_LAUNCH_CHECK("mg_dot_finish");
+}
+
 static void mg_dot(const double *v0, const double *v1, double *partials, double *result, size_t count, int iter_index)
 {
     const unsigned nb = blocks1d(count);
@@ -1658,7 +1673,8 @@ struct VCycleGraph {
     int levelnum = 0, fuse = 0, rows = 0, kchunk = 0, kchunk2 = 0, tile = 0, cus = 0, bottom = 0;
 };
 // the two cached graphs ([copy_b]) of the CURRENT context (bq_host.h: Runtime::mgcg_state)
-struct MgcgState { VCycleGraph vcgs[2]; };
+#include "bq_mgcg_slab.hip.inc"
+struct MgcgState { VCycleGraph vcgs[2]; SlabMg slab; };
 static MgcgState &ms()
 {
     Runtime &r = rt();
@@ -1718,6 +1734,7 @@ void mgcg_release_state(Runtime &r)
     if (!st) return;
     for (VCycleGraph &g : st->vcgs)
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    slab_mg_release(st->slab);
     delete st;
     r.mgcg_state = nullptr;
 }
@@ -1790,6 +1807,80 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
     }
     mg_gradient_kernel<<<grid_of(ni + 1, nj + 1, nk + 1), kBlk, 0, st>>>(u, v, w, p, ni, nj, nk, halfrdx);
     BQ_LAUNCH_CHECK("mg_gradient_kernel");
+}
+
+// 1 when gpu_multi_grid_conjugate_gradient_slab can run this decomposition (bq_mgcg_slab.hip.inc: requirements), else 0
+int gpu_mgcg_slab_supported(int ni, int nj, int nkg, int own0, int own1, int ghost, int rank, int nranks)
+{
+    if (nranks < 2 || ni < 8 || nj < 8 || nkg < 8 || rank < 0 || rank >= nranks) return 0;
+    if (((long long)ni * nj) % 256 != 0) return 0;                  // block dot products: slab boundaries must be block boundaries
+    if (nkg % nranks != 0 || own0 != rank * (nkg / nranks) || own1 != own0 + nkg / nranks) return 0;
+    if (own0 % 8 != 0 || own1 - own0 < 17 || ghost < 8) return 0;   // even ranges on three levels, G = 8 on level 0 inside the velocity's ghosts
+    if ((double)ni * nj * (own1 - own0 + 16) * 8.0 >= 2147483648.0) return 0;
+    return 1;
+}
+
+// gpu_multi_grid_conjugate_gradient (GPU_kernel.cu:1764-1815) on a z-slab rank, the grid's levels shared between the ranks.
+//   u, v, w     the rank's LOCAL velocity buffers: global planes [own0 - ghost, own1 + ghost) (w one more), ghost planes correct
+//   tempResult  device, 4096 doubles: the reference's residual history, identical on every rank
+// Everything else the solver needs it allocates itself, once per geometry and context.  Collective: every rank calls it.
+// On return the velocity is projected on the owned planes and on ghost - 1 ghost planes of either side.
+void gpu_multi_grid_conjugate_gradient_slab(float *u, float *v, float *w, double *tempResult,
+                                            int ni, int nj, int nkg, int own0, int own1, int ghost, int iter, double halfrdx)
+{
+    const char *op = "gpu_multi_grid_conjugate_gradient_slab";
+    if (!ensure_ready(op)) return;
+    BQ_REQUIRE(u && v && w && tempResult && iter >= 0, op);
+    BQ_REQUIRE(2 * iter + 2 < 2000 && 2001 + iter <= 4096, op);
+    const int rank = fl_comm_rank(), nranks = fl_comm_size();
+    if (!gpu_mgcg_slab_supported(ni, nj, nkg, own0, own1, ghost, rank, nranks)) { latch(FL_ERR_UNSUPPORTED, op, "geometry not supported (gpu_mgcg_slab_supported)"); return; }
+    SlabMg &m = ms().slab;
+    if (!slab_mg_setup(m, ni, nj, nkg, own0, own1, rank, nranks)) { if (rt().err == FL_OK) latch(FL_ERR_UNSUPPORTED, op, "levels too thin to share"); return; }
+    const SlabLevel &L0 = m.lv[0];
+    const int nkl = L0.nkl(), ulo = own0 - ghost;
+    const size_t pd = L0.plane(), n0 = pd * (size_t)nkl;
+    hipStream_t st = rt().compute;
+    const float *uu = u + (size_t)(ni + 1) * nj * (size_t)(L0.lo - ulo);
+    const float *vv = v + (size_t)ni * (nj + 1) * (size_t)(L0.lo - ulo);
+    const float *ww = w + pd * (size_t)(L0.lo - ulo);
+
+    mg_divergence_kernel<<<grid_of(ni, nj, nkl), kBlk, 0, st>>>(uu, vv, ww, m.div, ni, nj, nkl, halfrdx);
+    BQ_LAUNCH_CHECK("mg_divergence_kernel");
+    mg_zero(m.p, n0);
+    mg_residual(m.residual, m.div, m.p, ni, nj, nkl);
+    slab_exchange(L0, m.residual, L0.G);
+    mg_mul_kernel<<<blocks1d(n0), 256, 0, st>>>(m.dir, m.residual, 1, n0);
+    BQ_LAUNCH_CHECK("mg_mul_kernel");
+    slab_max(m, m.residual, tempResult, 2000);
+    slab_dot(m, m.residual, m.residual, tempResult, 0);                                      // r.r
+
+    for (int it = 0; it < iter; it++) {
+        const int off = it * 2;
+        // dir and residual are correct on every stored plane here (exchanged below / above)
+        if (!mg_stencil_lean(m.temp0, nullptr, m.dir, ni, nj, nkl, true)) {
+            mg_poisson_kernel<<<grid_of(ni, nj, nkl), kBlk, 0, st>>>(m.dir, m.temp0, ni, nj, nkl);
+            BQ_LAUNCH_CHECK("mg_poisson_kernel");
+        }
+        slab_dot(m, m.dir, m.temp0, tempResult, off + 1);
+        mg_update_x_kernel<<<blocks1d(n0), 256, 0, st>>>(m.p, m.dir, tempResult, n0, off, off + 1);
+        BQ_LAUNCH_CHECK("mg_update_x_kernel");
+        mg_residual(m.residual, m.div, m.p, ni, nj, nkl);
+        slab_exchange(L0, m.residual, L0.G);                // level 0's right-hand side, ghost planes included
+
+        slab_v_cycle(m, it == iter - 1);
+        slab_exchange(L0, m.residual, L0.G);
+        slab_max(m, m.residual, tempResult, 2001 + it);
+
+        slab_dot(m, m.residual, m.residual, tempResult, off + 2);
+        mg_update_dir_kernel<<<blocks1d(n0), 256, 0, st>>>(m.dir, m.residual, tempResult, n0, off, off + 2);
+        BQ_LAUNCH_CHECK("mg_update_dir_kernel");
+    }
+    // p is correct on every stored plane (the cycle's last exchange + elementwise updates); the gradient needs p(k - 1)
+    const int k_first = std::max(L0.lo + 1, 2), k_end = std::min(L0.hi, nkg);
+    if (k_end > k_first) {
+        mg_gradient_slab_kernel<<<grid_of(ni + 1, nj + 1, k_end - k_first), kBlk, 0, st>>>(u, v, w, m.p, ni, nj, nkg, L0.lo, k_end, ulo, k_first, halfrdx);
+        BQ_LAUNCH_CHECK("mg_gradient_slab_kernel");
+    }
 }
 
 } // extern "C"

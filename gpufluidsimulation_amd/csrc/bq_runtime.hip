@@ -196,6 +196,8 @@ void fl_shutdown(void)
     if (g_rt.scratch) (void)hipFree(g_rt.scratch);
     if (g_rt.pinned) (void)hipHostFree(g_rt.pinned);
     if (g_rt.map_guard) (void)hipFree(g_rt.map_guard);
+    if (g_rt.map_tab_dev) (void)hipFree(g_rt.map_tab_dev);
+    g_rt.map_tab_dev = nullptr; g_rt.map_tab_h = 0.f; g_rt.map_tab_ok = 0;
     g_rt.map_guard = nullptr; g_rt.map_guard_on = false;
     (void)hipStreamDestroy(g_rt.compute);
     (void)hipStreamDestroy(g_rt.halo);

@@ -415,10 +415,32 @@ bool BimocqGPUSolver::projectionMgcgSlabs()
     return fl_last_error() == FL_OK;
 }
 
+// The multigrid-CG projection on z-slab ranks with the fine levels SHARED (round 4: include/bimocq_gpu.h,
+// gpu_multi_grid_conjugate_gradient_slab; csrc/bq_mgcg_slab.hip.inc): nothing global is allocated here -- the operator owns its
+// per-level slab arrays -- and the velocity needs its ghost planes only as deep as level 0's (8).  false when the decomposition
+// is not covered (planes that are not a multiple of 256 cells, thin or unaligned slabs, the CPU stand-in): the caller falls
+// back to the replicated solve, which is bit-identical.
+bool BimocqGPUSolver::projectionMgcgShared()
+{
+    gpuMapper &gs = *GpuSolver;
+    const SlabCtx &sl = gs.slab;
+    mgcg_shared_ran = false;
+    if (!mgcg_shared || !gpu_mgcg_slab_supported(g.ni, g.nj, sl.nkg, sl.own0, sl.own1, sl.G, sl.rank, sl.nranks)) return false;
+    if (mg.result.bytes() < 4096 * sizeof(double) && !mg.result.alloc(4096 * sizeof(double))) return false;
+    gs.require({ &VelocityU, &VelocityV, &VelocityW }, sl.G);
+    gpu_multi_grid_conjugate_gradient_slab(VelocityU, VelocityV, VelocityW, mg.result.f64(), g.ni, g.nj, sl.nkg, sl.own0, sl.own1, sl.G,
+                                           mg_iters, (double)halfrdx);
+    // projected on the owned planes and on the 7 ghost planes next to them (the gradient needs p one plane below)
+    const int depth = std::min(sl.G, 8) - 1;
+    gs.produced(VelocityU, depth); gs.produced(VelocityV, depth); gs.produced(VelocityW, depth);
+    mgcg_shared_ran = true;
+    return true;
+}
+
 std::vector<double> BimocqGPUSolver::mgHistory() const
 {
     std::vector<double> h(4096, 0.0);
-    if (mg.ready) fl_memcpy_d2h(h.data(), mg.result.f64(), h.size() * sizeof(double));
+    if (mg.result.bytes() >= h.size() * sizeof(double)) fl_memcpy_d2h(h.data(), mg.result.f64(), h.size() * sizeof(double));
     return h;
 }
 
@@ -430,8 +452,13 @@ bool BimocqGPUSolver::projection(bool with_delta)
     gpuMapper &gs = *GpuSolver;
     const float alpha = -1.f, beta = (float)(1.0 / 6.0);
     if (projection_kind == BQ_PROJECTION_MGCG) {            // :443-446
+        if (gs.slab.on && gs.slab.nranks > 1) {
+            if (projectionMgcgShared()) return false;
+            if (!allocMgcg()) return false;
+            projectionMgcgSlabs();
+            return false;
+        }
         if (!allocMgcg()) return false;
-        if (gs.slab.on && gs.slab.nranks > 1) { projectionMgcgSlabs(); return false; }
         gpu_multi_grid_conjugate_gradient(VelocityU, VelocityV, VelocityW, mg.div.f64(), mg.p.f64(), mg.dir.f64(),
                                           mg.residual.f64(), mg.temp0.f64(), mg.temp1.f64(), mg.result.f64(),
                                           mg.levels.data(), (int)mg.levels.size(), mg_iters, (double)halfrdx);

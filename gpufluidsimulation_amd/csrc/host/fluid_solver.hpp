@@ -111,6 +111,9 @@ public:
     } mg;
     bool allocMgcg();
     bool projectionMgcgSlabs();
+    bool projectionMgcgShared();                    // the levels shared between the slab ranks; false: not applicable here
+    bool mgcg_shared = true;                        // BQ_OPT_MGCG_SHARED
+    bool mgcg_shared_ran = false;                   // the last MGCG projection on slabs took the shared path
     std::vector<double> mgHistory() const;          // tempResult (4096 doubles), downloaded
 
     std::vector<float> host_density, host_u, host_v, host_w;    // outputResult staging (:538-541)

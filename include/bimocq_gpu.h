@@ -461,6 +461,20 @@ int gpu_diffuse_sweeps(const float *field, float *in, float *out, int ni, int nj
 /* smoothing_jacobi<double> (GPU_kernel.cu:1464-1483) on its own: `iter` (rounded up to even) sweeps of
  * x' = ((sum6 x) + alpha*b) * beta on interior cells, ping-ponging x <-> temp; the newest iterate ends in x.
  * x and temp must carry the same boundary layer (V_Cycle clears both): sweeps are fused pairwise. */
+/* gpu_multi_grid_conjugate_gradient on a z-slab rank with the grid's fine levels SHARED between the ranks (round 4;
+ * csrc/bq_mgcg_slab.hip.inc): every level the ranks share is stored as owned planes + ghost planes, the single-GPU launchers run
+ * on those plane ranges with the ghost planes computed redundantly and refreshed by the neighbour exchange (fl_halo_exchange),
+ * the float-narrowed block dot products are computed per rank and all-gathered for the reference's final sum, thin levels are
+ * gathered and solved replicated.  Bit-identical to the single-domain solver.
+ *   u, v, w      the rank's LOCAL velocity buffers, planes [own0 - ghost, own1 + ghost) (w one more), ghost planes correct
+ *   tempResult   device, 4096 doubles: the reference's residual history (identical on every rank)
+ * Collective (every rank of the communicator calls it with its own planes).  gpu_mgcg_slab_supported says whether a
+ * decomposition can run this way: planes of a multiple of 256 cells, equal slabs that start at a multiple of 8 and hold at least
+ * 17 planes, ghost >= 8; the host solver keeps the replicated solve otherwise.  On return the velocity is projected on the owned
+ * planes and on 7 ghost planes of either side. */
+int  gpu_mgcg_slab_supported(int ni, int nj, int nkg, int own0, int own1, int ghost, int rank, int nranks);
+void gpu_multi_grid_conjugate_gradient_slab(float *u, float *v, float *w, double *tempResult,
+                                            int ni, int nj, int nkg, int own0, int own1, int ghost, int iter, double halfrdx);
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta,
                           int ni, int nj, int nk, int iter);
 /* max(0, max of field[0..count)) with NaNs skipped -- the host scan of MapperBaseGPU::estimateDistortion

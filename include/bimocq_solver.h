@@ -106,7 +106,14 @@ enum {
      * pairs -- with BQ_OPT_JACOBI_ENDS_FIRST both triples do the planes next to the slab ends first, the exchange for the next
      * chunk starts there and the two interiors (and the next chunk's first interior) hide it.  Where the kernels do not apply
      * (rows wider than 512 floats, ...) and with 0 the pairs run.  Same values either way. */
-    BQ_OPT_JACOBI_TRIPLES = 10
+    BQ_OPT_JACOBI_TRIPLES = 10,
+    /* z-slab ranks with the multigrid-CG projection, 1 (default): the grid's fine levels are SHARED between the ranks
+     * (gpu_multi_grid_conjugate_gradient_slab: owned + ghost planes per level, neighbour exchanges, all-gathered block dot
+     * products; thin levels gathered and solved replicated) wherever gpu_mgcg_slab_supported says the decomposition allows it
+     * -- no global fp64 array on any rank, the solve scales with the rank count.  0, and any decomposition it does not cover:
+     * the replicated solve of round 3 (every rank assembles the whole velocity and solves the whole grid).  Same bits.
+     * bq_solver_get_option returns 2 once a projection has taken the shared path. */
+    BQ_OPT_MGCG_SHARED = 11
 };
 /* BQ_OPT_PROFILE_PHASES: milliseconds per phase summed over the steps since the last reset -- map update (DMC + RK3,
  * BimocqGPUSolver.cpp:136-139), advection with error compensation (:143-145), sources and forces (:157-177), projection

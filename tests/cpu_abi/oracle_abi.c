@@ -310,6 +310,13 @@ void gpu_accumulate_component(float *c1, float k1, float *c2, float k2, float *d
 void gpu_accumulate_velocity_identity(float *uc, float *vc, float *wc, float *du, float *dv, float *dw,
                                       float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt, float coeff)
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }
+/* the slab-decomposed multigrid solver is HIP-only: the CPU stand-in answers "not supported" and the host solver keeps the replicated solve */
+int gpu_mgcg_slab_supported(int ni, int nj, int nkg, int own0, int own1, int ghost, int rank, int nranks)
+{ (void)ni; (void)nj; (void)nkg; (void)own0; (void)own1; (void)ghost; (void)rank; (void)nranks; return 0; }
+void gpu_multi_grid_conjugate_gradient_slab(float *u, float *v, float *w, double *tempResult, int ni, int nj, int nkg, int own0, int own1,
+                                            int ghost, int iter, double halfrdx)
+{ (void)u; (void)v; (void)w; (void)tempResult; (void)ni; (void)nj; (void)nkg; (void)own0; (void)own1; (void)ghost; (void)iter; (void)halfrdx;
+  latch(FL_ERR_UNSUPPORTED, "gpu_multi_grid_conjugate_gradient_slab: not in the CPU stand-in"); }
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta, int ni, int nj, int nk, int iter)
 { orc_mg_smooth(x, b, temp, alpha, beta, ni, nj, nk, iter); }
 int gpu_diffuse_sweeps(const float *field, float *in, float *out, int ni, int nj, int nk, int sweeps, float coef)

@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--projection-kind", type=int, default=0, help="0 Jacobi (--iters sweeps), 1 fp64 multigrid-CG (--iters outer iterations; "
                     "replicated solve on slab ranks)")
     ap.add_argument("--scheme", type=int, default=0, help="0: BiMocq, 3: MAC_REFLECTION (BQ_SCHEME_*)")
+    ap.add_argument("--mgcg-shared", type=int, default=1, help="BQ_OPT_MGCG_SHARED: 1 = the multigrid levels shared between the ranks "
+                    "where the decomposition allows it, 0 = the replicated solve")
+    ap.add_argument("--expect-shared", type=int, default=-1, help="1 / 0: fail unless the multigrid projection did / did not take the shared path")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
                          "ranks on one GPU that needs BQ_RCCL_LIBRARY = the tests' stand-in (tests/fake_rccl)")
@@ -117,6 +120,7 @@ def main():
     s.setOption(6, a.shallow)
     s.setOption(7, a.ends_first)
     s.setOption(10, a.triples)
+    s.setOption(11, a.mgcg_shared)
     if a.backend == "cpu":
         # the oracle library inside the CPU stand-in carries the slab context; the reference run below
         # uses the separately loaded liboracle.so, which stays single-domain
@@ -186,6 +190,11 @@ def main():
         abilib.fl_clear_error()
         print(f"[rank {rank}] comm check: communicators={abilib.fl_comm_count()} clean rc={rc_clean} falsified rc={rc_bad} ({text[:60]})", flush=True)
         if rc_clean != 0 or rc_bad != bq._lib.FL_ERR_COMM:
+            bad += 1
+    if a.projection_kind and a.backend == "gpu":
+        took = s.getOption(11) == 2
+        print(f"[rank {rank}] multigrid projection on slabs: {'levels SHARED between the ranks' if took else 'replicated solve'}", flush=True)
+        if a.expect_shared >= 0 and took != bool(a.expect_shared):
             bad += 1
     moved = np.abs(o.field("v")).max()
     print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} planes={tr.planes_moved} "

@@ -46,6 +46,65 @@ def test_hip_reproduces_full_size_hashes(case):
     s.close()
 
 
+_LONG_FINAL = {}          # final fields of the 128^3 x 200 runs, exact and one-fma: what the RMS test below compares
+
+
+@pytest.mark.parametrize("case", ["128_200", "128_200_fast", "256_12", "256_rise8_12"])
+def test_hip_reproduces_long_run_hashes(case):
+    """Round 4: the north star's own LENGTH.  tests/golden/long_run_hashes.json (tests/golden/make_long_hashes.py, CPU oracle):
+    128^3 for 200 steps (two DMC sub-steps per step from step ~41 on) in the exact arithmetic and in the oracle's one-fma mode
+    (which pins the library's FL_OPT_FAST_LERP variant with its z-marching window kernels), 256^3 for 12 steps, and 256^3 with
+    eight times the buoyancy so that 2^24-element fields reach the two-sub-step regime within 12 steps.  cfldt every step,
+    SHA-256 of rho, u, v, w where the fixture holds them (every 10th step of the long runs).  No oracle in the loop here."""
+    import gpufluidsimulation_amd as bq
+    from make_hashes import FIELDS, digest_hex
+    from gpufluidsimulation_amd.solver import BimocqGPUSolver
+    path = os.path.join(HERE, "golden", "long_run_hashes.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/long_run_hashes.json not generated")
+    spec = json.load(open(path))["cases"].get(case)
+    if spec is None:
+        pytest.skip(f"case {case} not in the fixture")
+    n = spec["grid"]
+    hip = bq.hip_lib()
+    hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, spec["fast_lerp"])
+    try:
+        s = BimocqGPUSolver(n, n, n, 1.0, 0.0, 1.0)
+        s.setSmoke(0.0, spec["rise"], [tuple(spec["emitter"])])
+        s.setProjection(spec["jacobi_iters"], spec["halfrdx"])
+        s.setOption(3, 1)
+        checked = 0
+        for row in spec["rows"]:
+            s.advance(row["step"] - 1, 2.0 / n)
+            assert float(np.float32(s.cfldt)) == row["cfldt"], (case, row["step"])
+            if "rho" in row:
+                for k in FIELDS:
+                    assert digest_hex(s.field(k)) == row[k], (case, row["step"], k)
+                checked += 1
+        assert checked >= 2
+        if case.startswith("128_200"):
+            _LONG_FINAL[case] = {k: s.field(k).astype(np.float64) for k in FIELDS}
+        s._check()
+        s.close()
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
+
+
+def test_fast_variant_is_within_the_tolerance_after_200_steps_at_128():
+    """SURVEY 8(d)'s parity figure for the fast variant at BASELINE config 2's size: RMS of rho, u, v, w against the exact
+    fields after 200 steps <= 1e-5 (the north star's tolerance).  Both trajectories were just checked against the oracle's
+    hashes (exact mode / one-fma mode), so this IS the deviation of the oracle's two arithmetic modes."""
+    if set(_LONG_FINAL) != {"128_200", "128_200_fast"}:
+        pytest.skip("needs both 128^3 x 200 cases of test_hip_reproduces_long_run_hashes in this session")
+    worst = {}
+    for k in ("rho", "u", "v", "w"):
+        a, b = _LONG_FINAL["128_200"][k], _LONG_FINAL["128_200_fast"][k]
+        assert not np.array_equal(a, b), k                                 # it really is another arithmetic
+        worst[k] = float(np.sqrt(np.mean((a - b) ** 2)))
+    assert max(worst.values()) <= 1e-5, worst
+    print("RMS fast vs exact, 128^3 after 200 steps:", worst)
+
+
 @pytest.mark.parametrize("case", ["mgcg_128", "reflection_128", "reflection_mgcg_64", "mgcg_256", "reflection_256"])
 def test_hip_reproduces_next_row_hashes(case):
     """SURVEY 8(f) rows N1 / N3 at sizes the toy shapes do not reach: the fp64 multigrid-CG projection at 128^3 and 256^3

@@ -774,3 +774,27 @@ def test_nonfinite_velocity_is_flagged(gm):
         assert lib.fl_nonfinite_seen(0) == 1 and lib.fl_nonfinite_seen(1) == 1 and lib.fl_nonfinite_seen(0) == 0
         assert got == (np.float32(ref) if np.isnan(bad) else np.float32(np.inf))
     bq.check()
+
+
+@pytest.mark.parametrize("ni,nj,nk,h", [(24, 20, 16, 1.0 / 24), (72, 68, 66, 0.002), (130, 24, 20, 0.002), (40, 36, 30, 0.01)])
+@pytest.mark.parametrize("fast", [0, 1])
+def test_tabled_lookup_on_other_spacings(gm, ni, nj, nk, h, fast):
+    """Round 4: on spacings that are not a power of two the structured map look-up runs from per-axis tables of cell and
+    weight (csrc/bq_device.hip.h: MapTabs) instead of 27 IEEE divisions per component and node.  h = 0.002f is the reference
+    binary's own spacing: there (i h) / h rounds to just below i at i = 63, 125, 126, so the centre tap reads cell i - 1 with
+    weight 1 - 2^-24 -- the grids here put index 63 on every axis.  Operators with warped and with wild maps, one and two
+    fields, in both arithmetic variants: the oracle's bits, and the generic path's (FL_OPT_STRUCTURED_MAPS = 0)."""
+    import gpufluidsimulation_amd as bq
+    hip = bq.hip_lib()
+    hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, fast)
+    oracle().orc_set_fast_lerp(fast)
+    try:
+        test_advect_velocity_and_field(gm, ni, nj, nk, h, False)
+        test_compensate_velocity_and_field(gm, ni, nj, nk, h)
+        test_accumulate(gm, ni, nj, nk, h, -0.5)
+        test_batched_scalar_ops(gm, ni, nj, nk, h, False)
+        test_gather_ops_on_wild_maps(gm, ni, nj, nk, h)
+        test_fused_housekeeping_bits(gm, ni, nj, nk, h)
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
+        oracle().orc_set_fast_lerp(0)

@@ -72,6 +72,13 @@ def test_single_communicator_fallback(fake):
     assert out.count("mismatches=0") == 2 and out.count("communicators=1 clean rc=0 falsified rc=5") == 2, out
 
 
+def test_two_ranks_on_a_spacing_that_is_not_a_power_of_two(fake):
+    """L = 1 on 24 cells: h = 1/24 -- the tabled structured look-up (round 4) with its z tables indexed by GLOBAL plane"""
+    rc, out = launch_worker(fake, 2, "--L", 1.0, "--steps", 3)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == 2
+
+
 def test_three_ranks_over_the_rccl_branch(fake):
     """a middle rank with two neighbours; wall sheets between non-neighbours (rank 2 needs planes of rank 0)"""
     rc, out = launch_worker(fake, 3, "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0)
@@ -128,6 +135,27 @@ def test_multigrid_projection_on_slabs_over_the_rccl_branch(fake):
                             "--projection-kind", 1, "--scheme", 3)
     assert rc == 0, out
     assert out.count("mismatches=0") == 3
+
+
+@pytest.mark.parametrize("nranks,dims", [(2, (32, 32, 96)), (3, (32, 32, 96)), (4, (32, 16, 128))])
+def test_multigrid_levels_shared_between_the_ranks(fake, nranks, dims):
+    """Round 4: the fp64 multigrid-CG projection with the grid's fine levels SHARED between the slab ranks
+    (gpu_multi_grid_conjugate_gradient_slab, csrc/bq_mgcg_slab.hip.inc): owned + ghost planes per level, the single-GPU
+    launchers on plane ranges, ghost planes refreshed every 8 sweeps, block dot products all-gathered, thin levels gathered
+    and solved replicated.  Planes of 1024 / 512 cells (multiples of the 256-cell dot blocks), 48 / 32 planes per rank, three
+    shared levels.  Every field equals the single-domain oracle's bit for bit, BiMocq and the reference binary's default
+    (MAC_REFLECTION + multigrid-CG); with the option off the replicated solve runs and gives the same."""
+    common = ["--dims", *dims, "--L", 1.0, "--ghost", 8, "--steps", 2, "--iters", 3, "--dt-cells", 1.0, "--projection-kind", 1]
+    rc, out = launch_worker(fake, nranks, *common, "--expect-shared", 1)
+    assert rc == 0, out
+    assert out.count("mismatches=0") == nranks and out.count("levels SHARED between the ranks") == nranks, out
+    if nranks == 2:
+        rc, out = launch_worker(fake, nranks, *common, "--scheme", 3, "--expect-shared", 1)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == nranks
+        rc, out = launch_worker(fake, nranks, *common, "--mgcg-shared", 0, "--expect-shared", 0)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == nranks and out.count("replicated solve") == nranks, out
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
