@@ -550,6 +550,17 @@ def main():
         extra = (extra_steps, el_extra, el_fast)
     # ---- one GPU: where the step's time goes, and the second kernel family against its own bounds (outside the timed region) ----
     phase_ms, quad_leg = None, None
+    if world == 1 and args.scheme == "bimocq" and mg and not args.no_extra:
+        # multigrid-CG mode (one GPU, or an emulated slab rank): where the step's time goes, nothing else
+        n_ph = max(1, min(3, args.steps))
+        s.setOption(8, 1)
+        s.phaseMs(reset=True)
+        barrier()
+        run(n_ph)
+        barrier()
+        phases, psteps = s.phaseMs(reset=True)
+        s.setOption(8, 0)
+        phase_ms = {k: round(v / max(1, psteps), 3) for k, v in phases.items()}
     if world == 1 and not emul and args.scheme == "bimocq" and not mg and not args.no_extra:
         n_ph = max(1, min(10, args.steps))
         s.setOption(3, 1)                                   # the headline's full sequence
@@ -792,7 +803,10 @@ def main():
                                                           "sweeps would move; above 1 only because a fused launch moves one sweep's bytes"},
                             "us_per_launch": round(us, 3), "launches_timed": int(launches.value),
                             "sweeps_per_launch": round(spl, 3), "us_per_sweep": round(ms.value * 1e3 / sweeps.value, 3)}
-    if phase_ms:
+    if phase_ms and (mg or emul):
+        line["phase_ms_per_step"] = phase_ms
+        line["config"]["mgcg_levels_shared"] = bool(emul > 1 and s.getOption(11) == 2) if mg else None
+    elif phase_ms:
         # The nine-point gather family (advect / compensate / cumulate + the limiter: the advection phase) is NOT bound by
         # HBM: algorithmic bytes per SURVEY 8(d) -- 20 B/voxel per advected component + ~60 B per compensate chain, 5
         # components -- over the phase time give a small fraction of the HBM peak; what binds it is VALU instruction issue

@@ -101,6 +101,10 @@ inline Spacing make_spacing(float h)
     return sp;
 }
 
+// (Round 4 measured, and did not keep, division by the constant h as fma(x, zh, x * zl) with (zh, zl) = 1 / h as a float pair:
+// correctly rounded for every mantissa of x for h = 0.002f, 1/24, 0.01f, 1/300 ... -- checked exhaustively -- but only while
+// no product leaves the normal range, and the per-wave guard for that (three votes and a second code path per locate) made the
+// reference grid's step 8.6 -> 20.5 ms: EXPERIMENTS.md section 9.)
 template <bool P2>
 __device__ __forceinline__ float div_h(float s, const Spacing &sp)
 {
