@@ -312,9 +312,13 @@ int fl_comm_init(const void *id128, int rank, int nranks)
     // every rank makes it here.  BQ_SINGLE_COMM=1 keeps the single communicator of rounds 1-3 (A/B on real links).
     const char *single = getenv("BQ_SINGLE_COMM");
     if (g_rccl.CommSplit && !(single && atoi(single) != 0)) {
+        // (a failure here is not fatal: the first communicator serves both, as in rounds 1-3 -- the run must not lose its RCCL
+        // transport over an optimisation)
         ncclComm_t red = nullptr;
-        if (!BQ_NCCL(CommSplit(g_comm, 0, rank, &red, nullptr))) return FL_ERR_COMM;
-        hs().comm_red = red;
+        const int rc = g_rccl.CommSplit(g_comm, 0, rank, &red, nullptr);
+        if (rc == ncclSuccess && red) hs().comm_red = red;
+        else fprintf(stderr, "[bimocq] ncclCommSplit failed (%s): one communicator serves exchanges and all-reduces\n",
+                     g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
     }
     hs().ledger = CommLedger();
     return fl_last_error();
