@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--halfrdx", type=float, default=0.5)
     ap.add_argument("--fl-opt", action="append", default=[], metavar="ID=VALUE",
                     help="fl_set_option(ID, VALUE) before the run (A/B timing of library options; repeatable)")
+    ap.add_argument("--bq-opt", action="append", default=[], metavar="ID=VALUE",
+                    help="bq_solver_set_option(ID, VALUE) on the solver before the run (A/B timing of host-solver options; repeatable)")
     ap.add_argument("--scheme", choices=["bimocq", "reflection"], default="bimocq",
                     help="bimocq: BASELINE's headline solver; reflection: the MacCormack + reflection scheme the reference's binary "
                          "ships as its default (main.cpp:51); z-slab ranks with the Jacobi projection")
@@ -488,6 +490,9 @@ def main():
         s.setOption(7, 0)
     if args.keep_dmc_border is not None:
         s.setOption(1, args.keep_dmc_border)
+    for kv in args.bq_opt:
+        k_, v_ = kv.split("=")
+        s.setOption(int(k_), int(v_))
     if args.dump:
         os.makedirs(args.dump, exist_ok=True)
 

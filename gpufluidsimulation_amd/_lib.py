@@ -54,6 +54,9 @@ HIP_SIGS = {
     "fl_memcpy_d2h": (None, [VP, VP, C.c_size_t]),
     "fl_memcpy_d2d": (None, [VP, VP, C.c_size_t]),
     "fl_sync": (None, []),
+    "fl_aux_begin": (None, []),
+    "fl_aux_end": (None, []),
+    "fl_aux_join": (None, []),
     "fl_malloc_host": (VP, [C.c_size_t]),
     "fl_free_host": (None, [VP]),
     "fl_download_begin": (VP, [VP, VP, C.c_size_t]),

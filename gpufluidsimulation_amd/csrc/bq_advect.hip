@@ -705,8 +705,9 @@ static MapTabs map_tabs(const Spacing &sp, const Grid &g, int *ok_mask)
         }
     if (r.map_tab_dev) { (void)hipStreamSynchronize(r.compute); (void)hipFree(r.map_tab_dev); r.map_tab_dev = nullptr; }
     if (!BQ_HIP(hipMalloc((void **)&r.map_tab_dev, host.size() * sizeof(float)))) { r.map_tab_dev = nullptr; return MapTabs{ nullptr, nullptr, 0 }; }
-    // (a blocking copy from pageable memory: once per grid)
-    if (!BQ_HIP(hipMemcpy(r.map_tab_dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice))) return MapTabs{ nullptr, nullptr, 0 };
+    // (once per grid: on the compute stream, in front of the launches that read it, and waited for because `host` dies here)
+    if (!BQ_HIP(hipMemcpyAsync(r.map_tab_dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, r.compute)) ||
+        !BQ_HIP(hipStreamSynchronize(r.compute))) return MapTabs{ nullptr, nullptr, 0 };
     r.map_tab_h = sp.h; r.map_tab_dims[0] = dims[0]; r.map_tab_dims[1] = dims[1]; r.map_tab_dims[2] = dims[2];
     r.map_tab_stride = stride; r.map_tab_ok = ok;
     *ok_mask = ok;

@@ -619,7 +619,10 @@ int fl_comm_selftest(void)
         ok = ok && BQ_NCCL(GroupEnd());
         ok = ok && BQ_HIP(hipStreamSynchronize(r.halo));
         float back[2 * n]; double bd[2];
-        ok = ok && BQ_HIP(hipMemcpy(back, buf, sizeof back, hipMemcpyDeviceToHost)) && BQ_HIP(hipMemcpy(bd, dd, sizeof bd, hipMemcpyDeviceToHost));
+        // (on the halo stream too, then one sync: no null-stream call anywhere -- a CU-masked stream is a BLOCKING stream with
+        // respect to the legacy null stream, so a null-stream copy next to a dump or an exchange would serialise with it)
+        ok = ok && BQ_HIP(hipMemcpyAsync(back, buf, sizeof back, hipMemcpyDeviceToHost, r.halo)) &&
+             BQ_HIP(hipMemcpyAsync(bd, dd, sizeof bd, hipMemcpyDeviceToHost, r.halo)) && BQ_HIP(hipStreamSynchronize(r.halo));
         if (ok) {
             for (int i = 0; i < n && ok; i++) ok = back[i] == host[i] && back[n + i] == host[i];
             ok = ok && bd[0] == hd[0] && bd[1] == hd[1];

@@ -13,6 +13,11 @@ struct Runtime {
     hipStream_t compute = nullptr;      // every operator launches here
     hipStream_t halo = nullptr;         // ghost-plane exchange (multi-GPU), overlapped with interior work
     hipStream_t copy = nullptr;         // device -> host downloads of the dump path, overlapped with the next step
+    // fl_aux_*: a second compute stream for an operator that is independent of the ones that follow it (the forward-map
+    // update beside the backward one): while a section is open `compute` IS the auxiliary stream
+    hipStream_t aux = nullptr, compute_main = nullptr;
+    hipEvent_t  aux_fork = nullptr, aux_done = nullptr;
+    bool        aux_pending = false;
     int         err = FL_OK;
     char        err_text[256] = {0};
     int         opt_residual_stride = 0;

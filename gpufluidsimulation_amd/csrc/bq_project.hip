@@ -663,16 +663,19 @@ __device__ __forceinline__ void st_r4(R4 v, v4i rs, unsigned voff, unsigned soff
 // where a DPP move, a move to pair the operands and a packed add stood.  A lane without a source lane (0 / 63) reads 0
 // (bound_ctrl): those are x-boundary or out-of-range columns, whose result is replaced or never stored.  The s_nop covers the
 // two wait states a DPP read needs after a VALU write of its source, which the compiler cannot see inside the asm.
+// `volatile` (round 4, ADVICE): the result depends on EXEC and on the neighbouring lanes, which the compiler cannot see either --
+// a pure two-operand asm could be sunk into a divergent region or merged across EXEC changes; volatile statements stay where
+// the source puts them (every use is in wave-uniform code of the plane loop).  Same ISA at today's -O3, same timings.
 __device__ __forceinline__ float add_from_left_lane(float from, float own)
 {
     float r;
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(from), "v"(own));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(from), "v"(own));
     return r;
 }
 __device__ __forceinline__ float add_from_right_lane(float from, float own)
 {
     float r;
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(from), "v"(own));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(from), "v"(own));
     return r;
 }
 
@@ -1204,13 +1207,13 @@ struct R8 { R4 a, b; };
 __device__ __forceinline__ float add_rol(float from, float own)      // own + `from` of lane + 1 (lane 63: of lane 0)
 {
     float r;
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_rol:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from), "v"(own));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_rol:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from), "v"(own));
     return r;
 }
 __device__ __forceinline__ float add_ror(float from, float own)      // own + `from` of lane - 1 (lane 0: of lane 63)
 {
     float r;
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from), "v"(own));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from), "v"(own));
     return r;
 }
 // jacobi_kernel's expression on the eight cells of a lane; adv = alpha * div

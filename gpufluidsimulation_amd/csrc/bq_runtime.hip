@@ -199,6 +199,11 @@ void fl_shutdown(void)
     if (g_rt.map_tab_dev) (void)hipFree(g_rt.map_tab_dev);
     g_rt.map_tab_dev = nullptr; g_rt.map_tab_h = 0.f; g_rt.map_tab_ok = 0;
     g_rt.map_guard = nullptr; g_rt.map_guard_on = false;
+    if (g_rt.compute_main) { g_rt.compute = g_rt.compute_main; g_rt.compute_main = nullptr; }
+    if (g_rt.aux) { (void)hipStreamSynchronize(g_rt.aux); (void)hipStreamDestroy(g_rt.aux); g_rt.aux = nullptr; }
+    if (g_rt.aux_fork) { (void)hipEventDestroy(g_rt.aux_fork); g_rt.aux_fork = nullptr; }
+    if (g_rt.aux_done) { (void)hipEventDestroy(g_rt.aux_done); g_rt.aux_done = nullptr; }
+    g_rt.aux_pending = false;
     (void)hipStreamDestroy(g_rt.compute);
     (void)hipStreamDestroy(g_rt.halo);
     (void)hipStreamDestroy(g_rt.copy);
@@ -323,7 +328,45 @@ void fl_sync(void)
 {
     if (!g_rt.ready) return;
     BQ_HIP(hipStreamSynchronize(g_rt.compute));
+    if (g_rt.compute_main) BQ_HIP(hipStreamSynchronize(g_rt.compute_main));
+    if (g_rt.aux && g_rt.aux_pending) BQ_HIP(hipStreamSynchronize(g_rt.aux));
     BQ_HIP(hipStreamSynchronize(g_rt.halo));
+}
+
+// ---- an auxiliary compute stream for ONE independent operator (round 4) -----------------------------------------------------
+// fl_aux_begin(): operators launched from here on go to a second stream, which first waits for everything queued on the
+// compute stream; fl_aux_end(): launches go to the compute stream again while the auxiliary one keeps running;
+// fl_aux_join(): the compute stream waits for what the section launched.  The caller vouches that the section's operators
+// neither read nor write anything the operators between end and join write (the host solver: the forward-map update, which
+// reads the velocity and updates its own three arrays, beside the backward one's sub-steps).  No blocking call inside a section.
+void fl_aux_begin(void)
+{
+    if (!bq::ensure_ready("fl_aux_begin") || g_rt.compute_main) return;
+    if (!g_rt.aux && !BQ_HIP(hipStreamCreateWithFlags(&g_rt.aux, hipStreamNonBlocking))) { g_rt.aux = nullptr; return; }
+    if (!g_rt.aux_fork && !BQ_HIP(hipEventCreateWithFlags(&g_rt.aux_fork, hipEventDisableTiming))) return;
+    if (!g_rt.aux_done && !BQ_HIP(hipEventCreateWithFlags(&g_rt.aux_done, hipEventDisableTiming))) return;
+    if (g_rt.aux_pending) fl_aux_join();
+    BQ_HIP(hipEventRecord(g_rt.aux_fork, g_rt.compute));
+    BQ_HIP(hipStreamWaitEvent(g_rt.aux, g_rt.aux_fork, 0));
+    g_rt.compute_main = g_rt.compute;
+    g_rt.compute = g_rt.aux;
+}
+
+void fl_aux_end(void)
+{
+    if (!g_rt.compute_main) return;
+    g_rt.compute = g_rt.compute_main;
+    g_rt.compute_main = nullptr;
+    g_rt.aux_pending = true;
+}
+
+void fl_aux_join(void)
+{
+    if (g_rt.compute_main) fl_aux_end();
+    if (!g_rt.aux_pending) return;
+    BQ_HIP(hipEventRecord(g_rt.aux_done, g_rt.aux));
+    BQ_HIP(hipStreamWaitEvent(g_rt.compute, g_rt.aux_done, 0));
+    g_rt.aux_pending = false;
 }
 
 // ---- asynchronous downloads (the dump path) ---------------------------------------

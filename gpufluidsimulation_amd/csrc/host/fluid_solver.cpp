@@ -565,16 +565,21 @@ bool BimocqGPUSolver::projection(bool with_delta)
                 bool ran;
                 if (ends_first) {
                     ran = gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - 3, own0 + G + 3, own1 - G - 3, own1 + 3, alpha, beta) != 0;
+                    // (all four launches must apply or none: the same kernel on the same rows either takes every one of these
+                    // ranges or refused the first; a later refusal would leave `in` half-updated, so it is an error, not a fall-back)
+                    int later = 1;
                     if (ran) {
-                        gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own0 + G, own1 - G, own1, alpha, beta);
+                        later &= gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own0 + G, own1 - G, own1, alpha, beta) != 0;
                         { float *ptr = in->get(); size_t pe = in->plane; int ex = 0; fl_halo_exchange(1, &ptr, &pe, &ex, g.nk, G, G, /*wait=*/0); }
                         in_flight = true;
-                        gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 + G + 3, own1 - G - 3, 0, 0, alpha, beta);
-                        gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0 + G, own1 - G, 0, 0, alpha, beta);
+                        later &= gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 + G + 3, own1 - G - 3, 0, 0, alpha, beta) != 0;
+                        later &= gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0 + G, own1 - G, 0, 0, alpha, beta) != 0;
                     }
+                    if (!later) fl_report_error(FL_ERR_UNSUPPORTED, "projection on slabs: a follow-up three-sweep launch was refused after the first one ran");
                 } else {
                     ran = gpu_jacobi_sweep_triple_ranges(*in, div, *out, g.ni, g.nj, g.nk, own0 - 3, own1 + 3, 0, 0, alpha, beta) != 0;
-                    if (ran) gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own1, 0, 0, alpha, beta);
+                    if (ran && !gpu_jacobi_sweep_triple_ranges(*out, div, *in, g.ni, g.nj, g.nk, own0, own1, 0, 0, alpha, beta))
+                        fl_report_error(FL_ERR_UNSUPPORTED, "projection on slabs: the second three-sweep launch was refused after the first one ran");
                 }
                 if (ran) { rest = 0; depth = 0; }                        // (two launches per piece: the newest iterate is back in `in`)
                 else triples_ok = false;                                 // the kernels do not apply to this grid: pairs from now on

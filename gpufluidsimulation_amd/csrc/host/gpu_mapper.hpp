@@ -237,6 +237,7 @@ public:
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
     bool jacobi_ends_first = true;          // BQ_OPT_JACOBI_ENDS_FIRST
     bool jacobi_triples = true;             // BQ_OPT_JACOBI_TRIPLES
+    bool concurrent_maps = false;           // BQ_OPT_CONCURRENT_MAPS (measured: no gain, EXPERIMENTS.md section 9)
     int shallow_blocking = 0;               // BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: 1 require(), 2 also withGhosts() move only the planes asked for
     static bool trace_require() { static const bool on = getenv("BQ_TRACE_REQUIRE") && atoi(getenv("BQ_TRACE_REQUIRE")) != 0; return on; }
     // record that an operator just rewrote `f` from inputs whose reach left `valid` correct ghost planes

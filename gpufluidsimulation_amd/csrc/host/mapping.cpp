@@ -58,8 +58,21 @@ void MapperBaseGPU::updateMapping(DeviceField &U, DeviceField &V, DeviceField &W
     // read-back afterwards tells whether the 9-point operators may run their weight-1/4 map lerps in fp32
     fl_map_guard_reset(0);
     fl_map_guard_reset(1);
-    updateBackward(U, V, W, cfldt, dt, dcells);
-    updateForward(U, V, W, cfldt, dt, dcells);
+    // One GPU, BQ_OPT_CONCURRENT_MAPS (off by default): the forward update (RK3 particle trace, Mapping.cpp:370-373) and the
+    // backward one's DMC sub-steps (:354-368) both read the velocity and touch disjoint map arrays, so the forward kernel can run
+    // on the library's auxiliary stream BESIDE the sub-steps (fl_aux_*).  Measured in round 4: no gain -- each kernel fills the
+    // chip on its own.  Slab ranks keep the order in any case: their exchanges are ordered against one compute stream.
+    const bool beside = gpuSolver->concurrent_maps && !gpuSolver->slab.on;
+    if (beside) {
+        fl_aux_begin();
+        updateForward(U, V, W, cfldt, dt, dcells);
+        fl_aux_end();
+        updateBackward(U, V, W, cfldt, dt, dcells);
+        fl_aux_join();
+    } else {
+        updateBackward(U, V, W, cfldt, dt, dcells);
+        updateForward(U, V, W, cfldt, dt, dcells);
+    }
     int ok[2] = { 0, 0 };
     fl_map_guard_read(ok);
     fl_map_guard_reset(-1);

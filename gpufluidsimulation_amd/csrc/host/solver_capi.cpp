@@ -111,6 +111,8 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         s->solver->GpuSolver->jacobi_triples = value != 0;
     } else if (option == BQ_OPT_MGCG_SHARED) {
         s->solver->mgcg_shared = value != 0;
+    } else if (option == BQ_OPT_CONCURRENT_MAPS) {
+        s->solver->GpuSolver->concurrent_maps = value != 0;
     } else if (option == BQ_OPT_SHALLOW_BLOCKING_EXCHANGE) {
         s->solver->GpuSolver->shallow_blocking = value < 0 ? 0 : value;
     } else if (option == BQ_OPT_REINIT_MAX_TRAVEL) {
@@ -134,6 +136,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
     case BQ_OPT_OVERLAP_EXCHANGES:   return s->solver->GpuSolver->overlap_exchanges ? 1 : 0;
     case BQ_OPT_JACOBI_ENDS_FIRST:   return s->solver->GpuSolver->jacobi_ends_first ? 1 : 0;
     case BQ_OPT_JACOBI_TRIPLES:      return s->solver->GpuSolver->jacobi_triples ? 1 : 0;
+    case BQ_OPT_CONCURRENT_MAPS:     return s->solver->GpuSolver->concurrent_maps ? 1 : 0;
     case BQ_OPT_MGCG_SHARED:         return s->solver->mgcg_shared ? (s->solver->mgcg_shared_ran ? 2 : 1) : 0;    // 2: the last projection took it
     case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking;
     case BQ_OPT_PROFILE_PHASES:      return s->solver->profile_phases ? 1 : 0;

@@ -258,6 +258,15 @@ void  fl_memcpy_h2d(void *dst, const void *src, size_t bytes);          /* block
 void  fl_memcpy_d2h(void *dst, const void *src, size_t bytes);          /* blocking, after queued work */
 void  fl_memcpy_d2d(void *dst, const void *src, size_t bytes);          /* async on the compute stream */
 void  fl_sync(void);
+/* An auxiliary compute stream for ONE operator that is independent of the ones that follow it (round 4): between
+ * fl_aux_begin() and fl_aux_end() operators are launched on a second stream that first waits for everything queued on the
+ * compute stream; after fl_aux_end() launches go to the compute stream again while the auxiliary work keeps running;
+ * fl_aux_join() makes the compute stream wait for it.  The caller vouches for the independence.  The host solver runs the
+ * forward-map update (gpu_solve_forward: reads the velocity, updates its own three arrays) beside the backward map's DMC
+ * sub-steps this way on one GPU (BQ_OPT_CONCURRENT_MAPS). */
+void  fl_aux_begin(void);
+void  fl_aux_end(void);
+void  fl_aux_join(void);
 /* Asynchronous download for the dump path (replaces the blocking cudaMemcpy of copyDeviceToHost,
  * GPU_Advection.h:276-299): pinned host memory, a copy on the library's third stream ordered after the
  * compute work queued so far, and a ticket any host thread can wait on while the next step runs. */

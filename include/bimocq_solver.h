@@ -113,7 +113,11 @@ enum {
      * -- no global fp64 array on any rank, the solve scales with the rank count.  0, and any decomposition it does not cover:
      * the replicated solve of round 3 (every rank assembles the whole velocity and solves the whole grid).  Same bits.
      * bq_solver_get_option returns 2 once a projection has taken the shared path. */
-    BQ_OPT_MGCG_SHARED = 11
+    BQ_OPT_MGCG_SHARED = 11,
+    /* one GPU, 1: updateMapping launches the forward-map update on the library's auxiliary stream beside the backward map's DMC
+     * sub-steps (fl_aux_*: disjoint arrays) instead of after them.  Same values.  Default 0: measured at 256^3 and 128^3, the
+     * two kernels each fill the chip and gain nothing from running side by side (11.14-11.19 against 11.10-11.15 ms per step). */
+    BQ_OPT_CONCURRENT_MAPS = 12
 };
 /* BQ_OPT_PROFILE_PHASES: milliseconds per phase summed over the steps since the last reset -- map update (DMC + RK3,
  * BimocqGPUSolver.cpp:136-139), advection with error compensation (:143-145), sources and forces (:157-177), projection

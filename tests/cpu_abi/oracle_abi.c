@@ -175,6 +175,9 @@ void fl_comm_destroy(void) { c_rank = 0; c_nranks = 1; c_exchange = NULL; c_allr
 int fl_comm_count(void) { return 0; }
 int fl_comm_check(int perturb) { (void)perturb; return FL_OK; }
 void fl_shutdown_all(void) {}
+void fl_aux_begin(void) {}
+void fl_aux_end(void) {}
+void fl_aux_join(void) {}
 int fl_comm_rank(void) { return c_rank; }
 int fl_comm_size(void) { return c_nranks; }
 void fl_comm_set_custom(int rank, int nranks, fl_exchange_cb ex, fl_allreduce_cb ar)
