@@ -37,7 +37,7 @@ def window(request):
     hip = bq.hip_lib()
     hip.fl_set_option(bq._lib.FL_OPT_FIELD_WINDOW, request.param)
     yield request.param
-    hip.fl_set_option(bq._lib.FL_OPT_FIELD_WINDOW, 0)
+    hip.fl_set_option(bq._lib.FL_OPT_FIELD_WINDOW, -1)      # (the default: the library's choice)
 
 
 @pytest.mark.parametrize("ni,nj,nk,h", P2_GRIDS)

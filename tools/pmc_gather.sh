@@ -21,7 +21,7 @@ dur = collections.defaultdict(list)
 for f in glob.glob(f"gpurun_out/pg_{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if not any(k in n for k in ("advect_kernel", "compensate_kernel", "cumulate_kernel", "gather_march")): continue
+        if not any(k in n for k in ("advect_kernel", "compensate_kernel", "cumulate_kernel", "gather_march", "dmc_kernel", "forward_kernel", "clamp_box")): continue
         key = n.split("(")[0].replace("void bq::exact::", "").replace("void bq::fast::", "f:")
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if "Start_Timestamp" in r and r["Counter_Name"] in ("SQ_WAVES", "TA_BUSY_avr"):
