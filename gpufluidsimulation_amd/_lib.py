@@ -74,6 +74,7 @@ HIP_SIGS = {
     "fl_jacobi_profile": (None, [C.POINTER(c_d), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "fl_jacobi_kernel_name": (C.c_char_p, []),
     "fl_mg_smooth_kernel_name": (C.c_char_p, []),
+    "fl_mg_fused_launches": (C.c_longlong, []),
     # 3. additive
     "gpu_init_maps": (None, [VP, VP, VP] + _G),
     "gpu_maps_quarter_safe": (c_i, [VP, VP, VP] + _G),
@@ -145,6 +146,7 @@ FL_OPT_MGCG_TILE = 14
 FL_OPT_PROFILE_COMM = 15
 FL_OPT_RESERVE_CUS = 16
 FL_OPT_MGCG_BOTTOM = 17
+FL_OPT_MGCG_FUSE = 20
 FL_OPT_FIELD_WINDOW = 18
 FL_OPT_COMM_CHECK = 19
 

@@ -1603,11 +1603,16 @@ static void mg_max(const double *v, double *result, size_t count, int iter_index
     BQ_LAUNCH_CHECK("mg_max");
 }
 
+#include "bq_mgcg_fused.hip.inc"
+
 // V_Cycle, multi-level form (:1636-1707), `else` branch
 // copy_b: whether level 0's right-hand side is copied into L[0].b first (the reference does, :1640).  The copy only
 // matters for what L[0].b holds afterwards, i.e. in the last outer iteration; before that level 0 reads `residual` itself
 // (nothing writes it until this function's last launch) and 134 MB of traffic per cycle stay away.
-static void v_cycle(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum, bool copy_b = true)
+// xin (FL_OPT_MGCG_FUSE): the iterate comes in `xin` (update_x's result) and goes out in `x`; the last two launches -- x += L[0].x,
+// residual = b - A x -- and the max / dot of that residual that the caller takes next are one (partials in temp0, the max parts behind)
+static void v_cycle(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum, bool copy_b = true,
+                    const double *xin = nullptr, double *maxpart = nullptr)
 {
     double scale[LEVEL_COUNT] = { 1.0, 1.0, 1.0, 1.0, 1.0, 1.0 };
     scale[1] = 8.0;                                                                          // M3
@@ -1657,6 +1662,13 @@ static void v_cycle(const double *b, double *x, double *residual, const SCoarseL
         BQ_LAUNCH_CHECK("mg_prolong_kernel");
         smooth_level(l, 4, false);
     }
+    if (xin) {
+        FuseArgs A{};
+        A.base = xin; A.d = L[0].x; A.rhs = b; A.xout = x; A.out = residual; A.mul = 1.0;
+        A.partials = temp0; A.maxpart = maxpart;                     // (temp0's other rim cells must stay as the sweeps left them)
+        mg_fused<kFuseAddRes>(A, L[0].ni, L[0].nj, L[0].nk);
+        return;
+    }
     mg_add_kernel<<<blocks1d(n0), 256, 0, st>>>(x, L[0].x, 1.0, n0);
     BQ_LAUNCH_CHECK("mg_add_kernel");
     mg_residual(residual, b, x, L[0].ni, L[0].nj, L[0].nk);
@@ -1671,6 +1683,7 @@ struct VCycleGraph {
     const double *b = nullptr; double *x = nullptr, *residual = nullptr, *temp0 = nullptr;
     SCoarseLevelInfo levels[LEVEL_COUNT];
     int levelnum = 0, fuse = 0, rows = 0, kchunk = 0, kchunk2 = 0, tile = 0, cus = 0, bottom = 0;
+    const double *xin = nullptr; double *maxpart = nullptr;
 };
 // the two cached graphs ([copy_b]) of the CURRENT context (bq_host.h: Runtime::mgcg_state)
 #include "bq_mgcg_slab.hip.inc"
@@ -1683,9 +1696,10 @@ static MgcgState &ms()
 }
 #define g_vcgs (ms().vcgs)
 
-static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum)
+static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum,
+                        const double *xin, double *maxpart)
 {
-    if (!c.exec || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
+    if (!c.exec || c.xin != xin || c.maxpart != maxpart || c.b != b || c.x != x || c.residual != residual || c.temp0 != temp0 || c.levelnum != levelnum) return false;
     if (c.fuse != rt().opt_jacobi_fuse || c.rows != rt().opt_jacobi_rows || c.kchunk != rt().opt_jacobi_kchunk || c.kchunk2 != rt().opt_jacobi_kchunk2 ||
         c.tile != rt().opt_mgcg_tile || c.cus != rt().num_cus || c.bottom != rt().opt_mgcg_bottom) return false;
     for (int l = 0; l < levelnum; l++) {
@@ -1696,25 +1710,26 @@ static bool vcg_matches(const VCycleGraph &c, const double *b, double *x, double
     return true;
 }
 
-static void v_cycle_replayed(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum, bool copy_b)
+static void v_cycle_replayed(const double *b, double *x, double *residual, const SCoarseLevelInfo *L, double *temp0, int levelnum, bool copy_b,
+                             const double *xin = nullptr, double *maxpart = nullptr)
 {
     if (!rt().opt_mgcg_tile) copy_b = true;
-    if (!rt().opt_mgcg_graph || rt().opt_profile_jacobi) { v_cycle(b, x, residual, L, temp0, levelnum, copy_b); return; }
+    if (!rt().opt_mgcg_graph || rt().opt_profile_jacobi) { v_cycle(b, x, residual, L, temp0, levelnum, copy_b, xin, maxpart); return; }
     VCycleGraph &g_vcg = g_vcgs[copy_b ? 1 : 0];
     hipStream_t st = rt().compute;
-    if (!vcg_matches(g_vcg, b, x, residual, L, temp0, levelnum)) {
+    if (!vcg_matches(g_vcg, b, x, residual, L, temp0, levelnum, xin, maxpart)) {
         if (g_vcg.exec) { (void)hipGraphExecDestroy(g_vcg.exec); g_vcg.exec = nullptr; }
         (void)scratch(64);                                   // no allocation may happen while capturing
         hipGraph_t graph = nullptr;
         bool ok = BQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         if (ok) {
-            v_cycle(b, x, residual, L, temp0, levelnum, copy_b);
+            v_cycle(b, x, residual, L, temp0, levelnum, copy_b, xin, maxpart);
             ok = BQ_HIP(hipStreamEndCapture(st, &graph)) && rt().err == FL_OK;
         }
         if (ok) ok = BQ_HIP(hipGraphInstantiate(&g_vcg.exec, graph, nullptr, nullptr, 0));
         if (graph) (void)hipGraphDestroy(graph);
         if (!ok) { g_vcg.exec = nullptr; return; }           // the error is latched
-        g_vcg.b = b; g_vcg.x = x; g_vcg.residual = residual; g_vcg.temp0 = temp0; g_vcg.levelnum = levelnum;
+        g_vcg.b = b; g_vcg.x = x; g_vcg.residual = residual; g_vcg.temp0 = temp0; g_vcg.levelnum = levelnum; g_vcg.xin = xin; g_vcg.maxpart = maxpart;
         g_vcg.fuse = rt().opt_jacobi_fuse; g_vcg.rows = rt().opt_jacobi_rows; g_vcg.kchunk = rt().opt_jacobi_kchunk; g_vcg.kchunk2 = rt().opt_jacobi_kchunk2; g_vcg.cus = rt().num_cus; g_vcg.bottom = rt().opt_mgcg_bottom;
         g_vcg.tile = rt().opt_mgcg_tile;
         for (int l = 0; l < levelnum; l++) g_vcg.levels[l] = L[l];
@@ -1746,6 +1761,7 @@ using namespace bq;
 extern "C" {
 
 const char *fl_mg_smooth_kernel_name(void) { return rt().mg_smooth_kernel; }
+long long fl_mg_fused_launches(void) { const long long n = rt().mg_fused_launches; rt().mg_fused_launches = 0; return n; }
 
 void gpu_smoothing_jacobi(double *x, double *b, double *temp, double alpha, double beta,
                           int ni, int nj, int nk, int iter)
@@ -1785,25 +1801,66 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
     mg_max(residual, tempResult, number, 2000);
     mg_dot(residual, residual, temp0, tempResult, number, 0);                               // r.r
 
+    // FL_OPT_MGCG_FUSE (bq_mgcg_fused.hip.inc): the nine level-0 vector passes of an iteration as three launches.  The fused
+    // updates are out of place: p -> temp1 (update_x) -> p (the V-cycle's add), dir <-> levels[0].b (free while the V-cycle
+    // reads `residual` itself as its right-hand side, i.e. in every iteration but the last)
+    const bool fused = levelNum >= 1 && mg_fuse_ok(ni, nj, nk, { div, p, dir, residual, temp0, temp1, levels[0].b, levels[0].x });
+    const FuseGeom fg = fused ? fuse_geom(ni, nj, nk) : FuseGeom{};
+    // the max parts of the fused residual: in the runtime's scratch, behind the 4 KB that mg_dot_finish uses
+    double *maxpart = fused ? (double *)scratch(4096 + (size_t)(fg.nblk + fg.nrim) * sizeof(double)) : nullptr;
+    if (fused && !maxpart) return;
+    if (maxpart) maxpart += 512;
+    double *dcur = dir;                                                                     // where the search direction lives
     for (int it = 0; it < iter; it++) {
         const int off = it * 2;
+        const bool last = it == iter - 1;
         // smoothing_conjugate_gradient (:1485-1495): aMulDir = temp0, dotDir = temp1
-        if (!mg_stencil_lean(temp0, nullptr, dir, ni, nj, nk, true)) {
-            mg_poisson_kernel<<<grid_of(ni, nj, nk), kBlk, 0, st>>>(dir, temp0, ni, nj, nk);
-            BQ_LAUNCH_CHECK("mg_poisson_kernel");
+        if (!fused || it == 0) {
+            if (!mg_stencil_lean(temp0, nullptr, dcur, ni, nj, nk, true)) {
+                mg_poisson_kernel<<<grid_of(ni, nj, nk), kBlk, 0, st>>>(dcur, temp0, ni, nj, nk);
+                BQ_LAUNCH_CHECK("mg_poisson_kernel");
+            }
+            mg_dot(dcur, temp0, temp1, tempResult, number, off + 1);
         }
-        mg_dot(dir, temp0, temp1, tempResult, number, off + 1);
-        mg_update_x_kernel<<<blocks1d(number), 256, 0, st>>>(p, dir, tempResult, number, off, off + 1);
-        BQ_LAUNCH_CHECK("mg_update_x_kernel");
-        mg_residual(residual, div, p, ni, nj, nk);
+        if (!fused) {
+            mg_update_x_kernel<<<blocks1d(number), 256, 0, st>>>(p, dir, tempResult, number, off, off + 1);
+            BQ_LAUNCH_CHECK("mg_update_x_kernel");
+            mg_residual(residual, div, p, ni, nj, nk);
 
-        v_cycle_replayed(div, p, residual, levels, temp0, levelNum, it == iter - 1);
-        mg_max(residual, tempResult, number, 2001 + it);
+            v_cycle_replayed(div, p, residual, levels, temp0, levelNum, last);
+            mg_max(residual, tempResult, number, 2001 + it);
 
-        // updateDir (:1497-1503)
-        mg_dot(residual, residual, temp0, tempResult, number, off + 2);
-        mg_update_dir_kernel<<<blocks1d(number), 256, 0, st>>>(dir, residual, tempResult, number, off, off + 2);
-        BQ_LAUNCH_CHECK("mg_update_dir_kernel");
+            // updateDir (:1497-1503)
+            mg_dot(residual, residual, temp0, tempResult, number, off + 2);
+            mg_update_dir_kernel<<<blocks1d(number), 256, 0, st>>>(dir, residual, tempResult, number, off, off + 2);
+            BQ_LAUNCH_CHECK("mg_update_dir_kernel");
+            continue;
+        }
+        {   // temp1 = p + dcur a0/a1, residual = div - A temp1
+            FuseArgs A{};
+            A.base = p; A.d = dcur; A.rhs = div; A.xout = temp1; A.out = residual; A.coef = tempResult; A.num_idx = off; A.den_idx = off + 1;
+            mg_fused<kFuseXRes>(A, ni, nj, nk);
+        }
+        if (last && dcur != dir) {          // the last V-cycle copies its right-hand side into levels[0].b: move the direction out of it
+            BQ_HIP(hipMemcpyAsync(dir, dcur, number * sizeof(double), hipMemcpyDeviceToDevice, st));
+            dcur = dir;
+        }
+        v_cycle_replayed(div, p, residual, levels, temp0, levelNum, last, temp1, maxpart);  // ... p = temp1 + L0.x, residual, its max and r.r
+        mg_max_final_kernel<<<1, 256, 0, st>>>(maxpart, (int)(fg.nblk + fg.nrim), tempResult, 2001 + it);
+        BQ_LAUNCH_CHECK("mg_max_final_kernel");
+        mg_dot_finish(temp0, tempResult, fg.npart, off + 2);
+        if (last) {
+            mg_update_dir_kernel<<<blocks1d(number), 256, 0, st>>>(dir, residual, tempResult, number, off, off + 2);
+            BQ_LAUNCH_CHECK("mg_update_dir_kernel");
+        } else {                            // updateDir and the next iteration's A dir, dir . A dir
+            double *dnext = dcur == dir ? levels[0].b : dir;
+            FuseArgs A{};
+            A.base = residual; A.d = dcur; A.xout = dnext; A.out = temp0; A.coef = tempResult; A.num_idx = off + 2; A.den_idx = off;
+            A.partials = temp1;
+            mg_fused<kFuseDirPoi>(A, ni, nj, nk);
+            mg_dot_finish(temp1, tempResult, fg.npart, off + 3);
+            dcur = dnext;
+        }
     }
     mg_gradient_kernel<<<grid_of(ni + 1, nj + 1, nk + 1), kBlk, 0, st>>>(u, v, w, p, ni, nj, nk, halfrdx);
     BQ_LAUNCH_CHECK("mg_gradient_kernel");

@@ -347,6 +347,14 @@ enum {
                                  * ranks; the host solver calls it at the end of every step while the option is on.  A
                                  * debugging aid for the first runs on real links: a mismatch latches FL_ERR_COMM instead of
                                  * hanging or silently pairing the wrong messages.  Default 0.                        */
+    FL_OPT_MGCG_FUSE       = 20,/* gpu_multi_grid_conjugate_gradient on rows of 256 or 512 cells: 1 (default) runs the level-0
+                                 * vector updates of an outer iteration inside the stencil pass that follows each of them
+                                 * (update_x + residual; add + residual + max + dot; update_dir + A dir + dot -- three
+                                 * launches for nine passes over the arrays, bq_mgcg_fused.hip.inc) on grids of 2^20 cells
+                                 * and more, 2 on any grid of that row length, 0 never.  Same values; the fused form keeps
+                                 * its intermediate vectors in temp1 and levels[0].b, which the reference's caller
+                                 * allocates at full size (BimocqGPUSolver.cpp:65-66), and what temp0 / temp1 hold after
+                                 * the call differs (both are scratch).                                               */
     FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
                                  * contract.  1: the caller vouches that every value of the map arrays it passes to the
                                  * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map
@@ -364,6 +372,8 @@ const char *fl_jacobi_kernel_name(void);
 /* name of the fused kernel the last fp64 smoothing call (gpu_smoothing_jacobi, V_Cycle) launched first ("" if none; for
  * reports and tests) */
 const char *fl_mg_smooth_kernel_name(void);
+/* launches of the fused level-0 kernels (FL_OPT_MGCG_FUSE) since the previous call (resets the count; for reports and tests) */
+long long fl_mg_fused_launches(void);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Additive entry points (no reference counterpart)

@@ -62,11 +62,15 @@ def device_case(lib, c, levels):
     (16, 16, 16, 1, 2, 0.5),          # one level: V-cycle = smoothing only
     (24, 20, 16, 2, 0, 0.5),          # no outer iteration: divergence, initial sums, gradient of p = 0
 ])
-def test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, hr):
+def test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, hr, stale=None):
     import gpufluidsimulation_amd as bq
     h = 1.0 / ni
     u, v, w = velocity(ni, nj, nk, h)
     c = HostCase(ni, nj, nk, levels)
+    if stale is not None:             # the work arrays arrive with arbitrary content (rim cells are never written by the stencils)
+        rng = np.random.default_rng(stale)
+        for a in (c.p, c.dir, c.residual, c.temp0, c.temp1, c.lb[0], c.lx[0], c.lr[0]):
+            a[:] = rng.uniform(-2.0, 2.0, a.size)
     d, lv, table = device_case(hip, c, levels)
     du, dv, dw = Dev(hip, u), Dev(hip, v), Dev(hip, w)
     ou, ov, ow = u.copy(), v.copy(), w.copy()
@@ -87,7 +91,7 @@ def test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, hr):
             assert F.same(c.lb[l], lv[0][l].numpy()), (call, "b", l)
         for a, b in ((ou, du), (ov, dv), (ow, dw)):
             assert F.same(a, b.numpy()), call
-    if iters:
+    if iters and stale is None:       # (stale rim cells take part in the reference's max)
         assert c.result[2000 + iters] < c.result[2000]      # the positive residual peak went down
 
 
@@ -101,6 +105,31 @@ def test_mgcg_with_fused_smoothing_on_every_level(hip):
         test_mgcg_matches_oracle(hip, 40, 36, 32, 3, 2, 1.0)
     finally:
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_FUSE, 1)
+
+
+@pytest.mark.parametrize("ni,nj,nk,levels,iters,stale", [
+    (256, 16, 12, 2, 3, None),        # rows of two waves; odd iteration count: the direction ends in its own array
+    (256, 16, 12, 2, 4, 7),           # even: moved out of levels[0].b before the last V-cycle; stale rim cells everywhere
+    (256, 9, 7, 1, 2, 11),            # odd row count, one z-chunk, one level
+    (512, 8, 10, 2, 3, 3),            # rows of four waves: two partials per row
+    (256, 64, 64, 3, 2, None),        # 2^20 cells: fused by default
+])
+def test_mgcg_vector_updates_inside_the_stencil_passes(hip, ni, nj, nk, levels, iters, stale):
+    """FL_OPT_MGCG_FUSE: update_x + residual, add + residual + max + dot, update_dir + A dir + dot as three launches
+    (bq_mgcg_fused.hip.inc) -- bit-identical to the oracle's nine passes, the dot products' summation trees included, with
+    stale values in every rim cell, twice in a row; and the same with the fusion off"""
+    import gpufluidsimulation_amd as bq
+    default_on = ni * nj * nk >= 1 << 20
+    hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1 if default_on else 2)
+    try:
+        hip.fl_mg_fused_launches()
+        test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, stale)
+        assert hip.fl_mg_fused_launches() > 0
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 0)
+        test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, stale)
+        assert hip.fl_mg_fused_launches() == 0
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1)
 
 
 @pytest.mark.parametrize("ni,nj,nk,levels", [(64, 64, 64, 4), (32, 32, 32, 3), (16, 16, 16, 2), (30, 14, 9, 2), (33, 31, 12, 3)])
