@@ -23,6 +23,8 @@ HIP_SIGS = {
     "gpu_advect_vel_double": (None, [VP] * 12 + _G + [c_b, c_f]),
     "gpu_advect_field": (None, [VP] * 5 + _G + [c_b]),
     "gpu_advect_field_double": (None, [VP] * 8 + _G + [c_b, c_f]),
+    "gpu_advect_vel_double_global": (None, [VP] * 12 + _G + [c_b, c_f]),
+    "gpu_advect_field_double_global": (None, [VP] * 8 + _G + [c_b, c_f]),
     "gpu_accumulate_velocity": (None, [VP] * 9 + _G + [c_b, c_f]),
     "gpu_accumulate_field": (None, [VP] * 5 + _G + [c_b, c_f]),
     "gpu_estimate_distortion": (None, [VP] * 7 + _G),

@@ -265,7 +265,7 @@ template <bool P2, bool PT, int SD>
 __global__ __launch_bounds__(256) void double_advect_kernel(float *field, const float *prev,
                                                             const float *bx, const float *by, const float *bz,
                                                             const float *px, const float *py, const float *pz,
-                                                            Spacing sp, Grid g, int dx, int dy, int dz, float blend)
+                                                            Spacing sp, Grid g, int dx, int dy, int dz, float blend, int prev_global)
 {
     const int nbi = g.ni + dx, nbj = g.nj + dy, nbk = g.nk + dz;
     BQ_IJK(nbi, nbj, nbk)
@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256) void double_advect_kernel(float *field, const 
     const float h = sp.h;
     Map3 back{make_field(bx, g.ni, g.nj, g.nk, g.koff), make_field(by, g.ni, g.nj, g.nk, g.koff), make_field(bz, g.ni, g.nj, g.nk, g.koff)};
     Map3 bprev{make_field(px, g.ni, g.nj, g.nk, g.koff), make_field(py, g.ni, g.nj, g.nk, g.koff), make_field(pz, g.ni, g.nj, g.nk, g.koff)};
-    Field src = make_field(prev, nbi, nbj, nbk, g.koff);
+    // prev_global (gpu_advect_*_double_global): `prev` holds every plane of the grid, not this rank's -- the second look-up
+    // lands anywhere between the origin and the node when it meets the zeroed border cells of the previous map
+    Field src = prev_global ? make_field(prev, nbi, nbj, g.nkg + dz, 0) : make_field(prev, nbi, nbj, nbk, g.koff);
     Nine n = nine_setup(h, dx, dy, dz);
     f3 lo = mk3(h, h, h), hi = mk3(h * (float)g.ni - h, h * (float)g.nj - h, h * (float)g.nkg - h);
     f3 c = nine_centre(n, i, j, kg);
@@ -901,7 +903,7 @@ static void compensate_comp(const float *src, float *init, float *err, const flo
 }
 static void double_comp(float *f, const float *prev, const float *bx, const float *by, const float *bz,
                         const float *px, const float *py, const float *pz,
-                        Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float blend)
+                        Spacing sp, Grid g, int dx, int dy, int dz, bool pt, float blend, int prev_global = 0)
 {
     // blend == 1: field*1 + 0*prev.  For finite prev that is field + (+-0): the value of every node is unchanged
     // (only a -0 would turn into +0, which no consumer can tell apart).  FL_OPT_SKIP_UNIT_BLEND = 1 (default): nothing
@@ -912,7 +914,7 @@ static void double_comp(float *f, const float *prev, const float *bx, const floa
         BQ_LAUNCH_CHECK("unit_blend_kernel");
         return;
     }
-    BQ_DISPATCH2(double_advect_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, prev, bx, by, bz, px, py, pz, sp, g, dx, dy, dz, blend);
+    BQ_DISPATCH2(double_advect_kernel, sp.pow2, pt, (dx ? 1 : dy ? 2 : dz ? 3 : 0), grid_for(g.ni + dx, g.nj + dy, g.nk + dz), f, prev, bx, by, bz, px, py, pz, sp, g, dx, dy, dz, blend, prev_global);
 }
 // The same limiter, separable and k-marching: a thread owns one float4 column of row j, reduces min/max over the
 // 3x3 (x, y) neighbourhood of each plane once (rows j-1, j, j+1 as float4 loads, x-neighbours from the neighbouring
@@ -1111,6 +1113,32 @@ BQ_ENTRY(gpu_advect_field_double, (float *field, float *field_prev, float *backw
              backward_xprev, backward_yprev, backward_zprev)
     Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
     double_comp(field, field_prev, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 0, is_point, blend_coeff);
+}
+
+// the two-level advection on a z-slab rank with the *_prev fields of the WHOLE grid (include/bimocq_gpu.h)
+BQ_ENTRY(gpu_advect_vel_double_global, (float *u, float *v, float *w, float *uprev_g, float *vprev_g, float *wprev_g,
+                           float *backward_x, float *backward_y, float *backward_z,
+                           float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                           float h, int ni, int nj, int nk, bool is_point, float blend_coeff), (u, v, w, uprev_g, vprev_g, wprev_g, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, h, ni, nj, nk, is_point, blend_coeff))
+{
+    BQ_ENTER("gpu_advect_vel_double_global", u, v, w, uprev_g, vprev_g, wprev_g, backward_x, backward_y, backward_z,
+             backward_xprev, backward_yprev, backward_zprev)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    BQ_REQUIRE((double)(ni + 1) * (nj + 1) * (g.nkg + 1) * 4.0 < 2147483648.0, "gpu_advect_vel_double_global");
+    double_comp(u, uprev_g, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 1, 0, 0, is_point, blend_coeff, 1);
+    double_comp(v, vprev_g, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 1, 0, is_point, blend_coeff, 1);
+    double_comp(w, wprev_g, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 1, is_point, blend_coeff, 1);
+}
+
+BQ_ENTRY(gpu_advect_field_double_global, (float *field, float *field_prev_g, float *backward_x, float *backward_y, float *backward_z,
+                             float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                             float h, int ni, int nj, int nk, bool is_point, float blend_coeff), (field, field_prev_g, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, h, ni, nj, nk, is_point, blend_coeff))
+{
+    BQ_ENTER("gpu_advect_field_double_global", field, field_prev_g, backward_x, backward_y, backward_z,
+             backward_xprev, backward_yprev, backward_zprev)
+    Spacing sp = make_spacing(h); Grid g = mk_grid(ni, nj, nk);
+    BQ_REQUIRE((double)ni * nj * g.nkg * 4.0 < 2147483648.0, "gpu_advect_field_double_global");
+    double_comp(field, field_prev_g, backward_x, backward_y, backward_z, backward_xprev, backward_yprev, backward_zprev, sp, g, 0, 0, 0, is_point, blend_coeff, 1);
 }
 
 BQ_ENTRY(gpu_accumulate_velocity, (float *u_change, float *v_change, float *w_change,

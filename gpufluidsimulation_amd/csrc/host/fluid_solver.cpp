@@ -627,11 +627,26 @@ bool BimocqGPUSolver::projection(bool with_delta)
     return with_delta;
 }
 
+// The two-level advection of blend != 1 (Mapping.cpp:383-390) samples the *Prev fields through the previous backward map.  With
+// the reference's zeroed map border a look-up that meets border cells returns s * q, s in [0, 1]: anywhere between
+// the origin and the node -- on a z-slab rank, on any other rank's planes.  The *Prev fields change at a re-initialisation and
+// nowhere else, so that is when every rank assembles whole-grid copies of them (gpuMapper::assembleGlobal: one message per peer
+// and field); the advectors find the copies through gpuMapper::globalTwin.  BQ_OPT_KEEP_DMC_BORDER = 1 has no zeroed cells and
+// needs none of this.
+bool BimocqGPUSolver::wholeGridPrev() const
+{
+    const gpuMapper &gs = *GpuSolver;
+    return whole_grid_prev && gs.slab.on && gs.slab.nranks > 1 && VelocityAdvector.BlendCoeff != 1.f && !VelocityAdvector.keepDmcBorder;
+}
+
 // :503-516.  UPrev <- UInit by swap (UInit is refilled right after), UInit <- U by copy.
 void BimocqGPUSolver::velocityReinitialize()
 {
     VelocityUPrev.swap(VelocityUInit); VelocityVPrev.swap(VelocityVInit); VelocityWPrev.swap(VelocityWInit);
     VelocityUInit.copy_from(VelocityU); VelocityVInit.copy_from(VelocityV); VelocityWInit.copy_from(VelocityW);
+    if (wholeGridPrev())
+        GpuSolver->assembleGlobal({ { &VelocityUPrev, &VelocityUPrevAll }, { &VelocityVPrev, &VelocityVPrevAll }, { &VelocityWPrev, &VelocityWPrevAll } });
+    else GpuSolver->dropGlobalTwins();
 }
 
 // :518-527
@@ -639,6 +654,9 @@ void BimocqGPUSolver::scalarReinitialize()
 {
     DensityPrev.swap(DensityInit); TemperaturePrev.swap(TemperatureInit);
     DensityInit.copy_from(Density); TemperatureInit.copy_from(Temperature);
+    if (wholeGridPrev())
+        GpuSolver->assembleGlobal({ { &DensityPrev, &DensityPrevAll }, { &TemperaturePrev, &TemperaturePrevAll } });
+    else GpuSolver->dropGlobalTwins();
 }
 
 static BimocqGPUSolver *g_trace_solver = nullptr;

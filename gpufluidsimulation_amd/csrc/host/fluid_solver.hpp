@@ -43,6 +43,8 @@ public:
     bool projection(bool with_delta = false);
     void velocityReinitialize();
     void scalarReinitialize();
+    bool whole_grid_prev = true;            // BQ_OPT_WHOLE_GRID_PREV
+    bool wholeGridPrev() const;             // blend != 1 on z-slab ranks with the zeroed map border: *Prev fields need whole-grid copies
     void setSmoke(float drop, float raise, const std::vector<Emitter> &emitters);
     long outputResult(unsigned frame, const std::string &filepath);
     // The same dump without stalling the simulation: the density is downloaded into pinned
@@ -93,6 +95,7 @@ public:
     DeviceField VelocityU, VelocityV, VelocityW;
     DeviceField VelocityUInit, VelocityVInit, VelocityWInit;
     DeviceField VelocityUPrev, VelocityVPrev, VelocityWPrev;
+    DeviceField VelocityUPrevAll, VelocityVPrevAll, VelocityWPrevAll, DensityPrevAll, TemperaturePrevAll;   // wholeGridPrev()
     DeviceField VelocityUTemp, VelocityVTemp, VelocityWTemp;
     DeviceField duProj, dvProj, dwProj, duExtern, dvExtern, dwExtern;
     DeviceField TempSrcU, TempSrcV, TempSrcW;

@@ -211,6 +211,42 @@ void gpuMapper::wallFixupEnd(DeviceField &bx, DeviceField &by, DeviceField &bz, 
     }
 }
 
+// Whole-grid copies of slab fields: my owned planes by a device copy, every peer's by one point-to-point message per field, all
+// in one group (xGMI is a full mesh).  Equal slabs (nkg / nranks planes each; a w-type field's top face goes with the last rank),
+// as everywhere in the slab path.
+bool gpuMapper::assembleGlobal(std::initializer_list<GlobalPair> fields)
+{
+    if (!slab.on || slab.nranks <= 1) return false;
+    const int R = slab.nranks, nkg = slab.nkg, G = slab.G;
+    const auto own0_of = [&](int r) { return r * (nkg / R); };
+    const auto planes_of = [&](int r, int extra) { return nkg / R + ((extra && r == R - 1) ? 1 : 0); };
+    std::vector<int> peers; std::vector<float *> send, recv; std::vector<size_t> send_count, recv_count;
+    for (const GlobalPair &f : fields) {
+        const size_t plane = f.local->plane, total = plane * (size_t)(nkg + f.local->extra);
+        if (!plane) return false;
+        if (f.global->count() < total && !f.global->alloc(total)) return false;
+        fl_memcpy_d2d(f.global->get() + plane * (size_t)slab.own0, f.local->get() + plane * (size_t)G,
+                      plane * (size_t)planes_of(slab.rank, f.local->extra) * sizeof(float));
+        bool known = false;
+        for (auto &t : global_twins_) if (t.first == f.local) { t.second = f.global; known = true; }
+        if (!known) global_twins_.emplace_back(f.local, f.global);
+    }
+    for (int r = 0; r < R; r++) {
+        if (r == slab.rank) continue;
+        for (const GlobalPair &f : fields) {
+            const size_t plane = f.local->plane;
+            peers.push_back(r);
+            send.push_back(f.local->get() + plane * (size_t)G);
+            send_count.push_back(plane * (size_t)planes_of(slab.rank, f.local->extra));
+            recv.push_back(f.global->get() + plane * (size_t)own0_of(r));
+            recv_count.push_back(plane * (size_t)planes_of(r, f.local->extra));
+            global_prev_bytes += (long long)recv_count.back() * 4;
+        }
+    }
+    fl_p2p_exchange((int)peers.size(), peers.data(), send.data(), send_count.data(), recv.data(), recv_count.data());
+    return fl_last_error() == FL_OK;
+}
+
 void gpuMapper::startEventRecord()
 {
     if (!ev_start_) ev_start_ = fl_event_create();

@@ -14,6 +14,7 @@
 #include <initializer_list>
 #include <map>
 #include <tuple>
+#include <utility>
 #include <vector>
 #include "bimocq_gpu.h"
 #include "wall_sheets.hpp"
@@ -226,6 +227,7 @@ public:
     // the border taps can touch, fetched from the ranks that own them.  Call right after the stage-3 operator, with
     // the out_valid that operator was given.  `need`: ghost planes of src known to be correct (the operator's
     // requirement).  No-op on one rank.
+    std::vector<std::pair<const DeviceField *, const DeviceField *>> global_twins_;
     struct WallItem { DeviceField *src, *before, *dst; FieldKind kind; };
     void wallFixup(std::initializer_list<WallItem> items, DeviceField &bx, DeviceField &by, DeviceField &bz,
                    int Dback, int need, float coeff, int out_valid);
@@ -234,6 +236,19 @@ public:
     void wallFixupBegin(std::initializer_list<WallItem> items, int Dback, int need);
     void wallFixupEnd(DeviceField &bx, DeviceField &by, DeviceField &bz, float coeff, int out_valid);
     long long wall_bytes_moved = 0;         // floats received through wallFixup so far x 4 (statistics)
+    // blend != 1 on z-slab ranks in the reference-faithful mode: whole-grid copies of the *Prev fields (include/bimocq_gpu.h:
+    // gpu_advect_vel_double_global), assembled from every rank's owned planes after a re-initialisation -- the only time those
+    // fields change.  globalTwin: the copy registered for a local field, or nullptr (local look-ups).
+    struct GlobalPair { DeviceField *local, *global; };
+    bool assembleGlobal(std::initializer_list<GlobalPair> fields);
+    const float *globalTwin(const DeviceField *local) const
+    {
+        for (const std::pair<const DeviceField *, const DeviceField *> &t : global_twins_)
+            if (t.first == local) return t.second->get();
+        return nullptr;
+    }
+    void dropGlobalTwins() { global_twins_.clear(); }
+    long long global_prev_bytes = 0;        // bytes received by assembleGlobal so far (statistics)
     bool overlap_exchanges = true;          // BQ_OPT_OVERLAP_EXCHANGES
     bool jacobi_ends_first = true;          // BQ_OPT_JACOBI_ENDS_FIRST
     bool jacobi_triples = true;             // BQ_OPT_JACOBI_TRIPLES
@@ -281,12 +296,22 @@ public:
                               float *bx, float *by, float *bz, float *px, float *py, float *pz,
                               bool is_point, float blend) const
     { gpu_advect_vel_double(u, v, w, ut, vt, wt, bx, by, bz, px, py, pz, g.h, g.ni, g.nj, g.nk, is_point, blend); }
+    void advectVelocityDoubleGlobal(float *u, float *v, float *w, const float *ug, const float *vg, const float *wg,
+                                    float *bx, float *by, float *bz, float *px, float *py, float *pz,
+                                    bool is_point, float blend) const
+    {
+        gpu_advect_vel_double_global(u, v, w, const_cast<float *>(ug), const_cast<float *>(vg), const_cast<float *>(wg),
+                                     bx, by, bz, px, py, pz, g.h, g.ni, g.nj, g.nk, is_point, blend);
+    }
     void compensateVelocity(float *u, float *v, float *w, float *du, float *dv, float *dw,
                             float *fx, float *fy, float *fz, float *bx, float *by, float *bz, bool is_point) const;
     void advectField(float *f, float *fi, float *bx, float *by, float *bz, bool is_point) const;
     void advectFieldDouble(float *f, float *fp, float *bx, float *by, float *bz,
                            float *px, float *py, float *pz, bool is_point, float blend) const
     { gpu_advect_field_double(f, fp, bx, by, bz, px, py, pz, g.h, g.ni, g.nj, g.nk, is_point, blend); }
+    void advectFieldDoubleGlobal(float *f, const float *fg, float *bx, float *by, float *bz,
+                                 float *px, float *py, float *pz, bool is_point, float blend) const
+    { gpu_advect_field_double_global(f, const_cast<float *>(fg), bx, by, bz, px, py, pz, g.h, g.ni, g.nj, g.nk, is_point, blend); }
     void compensateField(float *f, float *df, float *fx, float *fy, float *fz,
                          float *bx, float *by, float *bz, bool is_point) const;
     void accumulateVelocity(float *uc, float *vc, float *wc, float *dui, float *dvi, float *dwi,

@@ -221,18 +221,28 @@ void MapperBaseGPU::advectVelocity(DeviceField &U, DeviceField &V, DeviceField &
     gs.producedAll({ &U, &V, &W }, std::min(gpuMapper::minValid({ &U, &V, &W }), gpuMapper::minValid({ &Ui, &Vi, &Wi }) - 1));
 
     const float blend = (TotalReinitCount != 0) ? BlendCoeff : 1.f;
+    // z-slab ranks, zeroed map border: the second look-up may land anywhere below the node (include/bimocq_gpu.h,
+    // gpu_advect_vel_double_global) -- the solver keeps whole-grid copies of the *Prev fields for it
+    const float *ug = blend != 1.f ? gs.globalTwin(&Up) : nullptr, *vg = blend != 1.f ? gs.globalTwin(&Vp) : nullptr,
+                *wg = blend != 1.f ? gs.globalTwin(&Wp) : nullptr;
+    const bool whole = ug && vg && wg;
     if (blend != 1.f) {
         gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
         gs.require({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }, reachField(m.Dback));
-        gs.require({ &Up, &Vp, &Wp }, reachField(m.Dback + m.DbackPrev));
+        if (!whole) gs.require({ &Up, &Vp, &Wp }, reachField(m.Dback + m.DbackPrev));
     }
-    gs.advectVelocityDouble(U, V, W, Up, Vp, Wp, m.BackwardX, m.BackwardY, m.BackwardZ,
-                            m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    if (whole)
+        gs.advectVelocityDoubleGlobal(U, V, W, ug, vg, wg, m.BackwardX, m.BackwardY, m.BackwardZ,
+                                      m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    else
+        gs.advectVelocityDouble(U, V, W, Up, Vp, Wp, m.BackwardX, m.BackwardY, m.BackwardZ,
+                                m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
     if (blend != 1.f)
         gs.producedAll({ &U, &V, &W }, std::min({ gpuMapper::minValid({ &U, &V, &W }),
                                                   gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                                   gpuMapper::minValid({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }) - reachField(m.Dback),
-                                                  gpuMapper::minValid({ &Up, &Vp, &Wp }) - reachField(m.Dback + m.DbackPrev) }));
+                                                  whole ? (int)DeviceField::kAlwaysValid
+                                                        : gpuMapper::minValid({ &Up, &Vp, &Wp }) - reachField(m.Dback + m.DbackPrev) }));
 }
 
 // Mapping.cpp:393-407, same four-stage expansion of gpu_compensate_field (GPU_kernel.cu:676-681)
@@ -281,17 +291,22 @@ void MapperBaseGPU::advectField(DeviceField &f, DeviceField &fInit, DeviceField 
     gs.produced(f, std::min(f.valid, fInit.valid - 1));
 
     const float blend = (TotalReinitCount != 0) ? BlendCoeff : 1.f;
+    const float *fg = blend != 1.f ? gs.globalTwin(&fPrev) : nullptr;       // (advectVelocity: whole-grid copy of the *Prev field)
     if (blend != 1.f) {
         gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
         gs.require({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }, reachField(m.Dback));
-        gs.require({ &fPrev }, reachField(m.Dback + m.DbackPrev));
+        if (!fg) gs.require({ &fPrev }, reachField(m.Dback + m.DbackPrev));
     }
-    gs.advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
-                         m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    if (fg)
+        gs.advectFieldDoubleGlobal(f, fg, m.BackwardX, m.BackwardY, m.BackwardZ,
+                                   m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+    else
+        gs.advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
+                             m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
     if (blend != 1.f)
         gs.produced(f, std::min({ f.valid, gpuMapper::minValid({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }) - kReachMap,
                                   gpuMapper::minValid({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }) - reachField(m.Dback),
-                                  fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
+                                  fg ? (int)DeviceField::kAlwaysValid : fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
 }
 
 // Two scalar fields through the same sequence as advectField, stage by stage, with the batched
@@ -360,17 +375,22 @@ void MapperBaseGPU::advectFields2(DeviceField &f1, DeviceField &f1Init, DeviceFi
     DeviceField *fs[2] = { &f1, &f2 }, *ps[2] = { &f1Prev, &f2Prev };
     for (int a = 0; a < 2; a++) {
         DeviceField &f = *fs[a], &fPrev = *ps[a];
+        const float *fg = blend != 1.f ? gs.globalTwin(&fPrev) : nullptr;   // (advectVelocity: whole-grid copy of the *Prev field)
         if (blend != 1.f) {
             gs.require({ &m.BackwardX, &m.BackwardY, &m.BackwardZ }, kReachMap);
             gs.require({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }, reachField(m.Dback));
-            gs.require({ &fPrev }, reachField(m.Dback + m.DbackPrev));
+            if (!fg) gs.require({ &fPrev }, reachField(m.Dback + m.DbackPrev));
         }
-        gs.advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
-                             m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+        if (fg)
+            gs.advectFieldDoubleGlobal(f, fg, m.BackwardX, m.BackwardY, m.BackwardZ,
+                                       m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
+        else
+            gs.advectFieldDouble(f, fPrev, m.BackwardX, m.BackwardY, m.BackwardZ,
+                                 m.BackwardXPrev, m.BackwardYPrev, m.BackwardZPrev, false, blend);
         if (blend != 1.f)
             gs.produced(f, std::min({ f.valid, back() - kReachMap,
                                       gpuMapper::minValid({ &m.BackwardXPrev, &m.BackwardYPrev, &m.BackwardZPrev }) - reachField(m.Dback),
-                                      fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
+                                      fg ? (int)DeviceField::kAlwaysValid : fPrev.valid - reachField(m.Dback + m.DbackPrev) }));
     }
 }
 

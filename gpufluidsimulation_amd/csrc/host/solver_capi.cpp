@@ -113,6 +113,9 @@ void bq_solver_set_option(bq_solver *s, int option, int value)
         s->solver->mgcg_shared = value != 0;
     } else if (option == BQ_OPT_CONCURRENT_MAPS) {
         s->solver->GpuSolver->concurrent_maps = value != 0;
+    } else if (option == BQ_OPT_WHOLE_GRID_PREV) {
+        s->solver->whole_grid_prev = value != 0;
+        if (!value) s->solver->GpuSolver->dropGlobalTwins();
     } else if (option == BQ_OPT_SHALLOW_BLOCKING_EXCHANGE) {
         s->solver->GpuSolver->shallow_blocking = value < 0 ? 0 : value;
     } else if (option == BQ_OPT_REINIT_MAX_TRAVEL) {
@@ -137,6 +140,7 @@ int bq_solver_get_option(const bq_solver *s, int option)
     case BQ_OPT_JACOBI_ENDS_FIRST:   return s->solver->GpuSolver->jacobi_ends_first ? 1 : 0;
     case BQ_OPT_JACOBI_TRIPLES:      return s->solver->GpuSolver->jacobi_triples ? 1 : 0;
     case BQ_OPT_CONCURRENT_MAPS:     return s->solver->GpuSolver->concurrent_maps ? 1 : 0;
+    case BQ_OPT_WHOLE_GRID_PREV:     return s->solver->whole_grid_prev ? (s->solver->GpuSolver->globalTwin(&s->solver->VelocityUPrev) ? 2 : 1) : 0;
     case BQ_OPT_MGCG_SHARED:         return s->solver->mgcg_shared ? (s->solver->mgcg_shared_ran ? 2 : 1) : 0;    // 2: the last projection took it
     case BQ_OPT_SHALLOW_BLOCKING_EXCHANGE: return s->solver->GpuSolver->shallow_blocking;
     case BQ_OPT_PROFILE_PHASES:      return s->solver->profile_phases ? 1 : 0;

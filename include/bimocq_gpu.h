@@ -613,6 +613,24 @@ void gpu_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const
                                const float *mx, const float *my, const float *mz,
                                float h, int ni, int nj, int nk, int axis, float coeff,
                                const int *xlist, int nxl, const int *ylist, int nyl, const int *zlist, int nzl);
+/* gpu_advect_vel_double / gpu_advect_field_double (GPU_kernel.cu:236-310, 600-638) for a z-slab rank with blend_coeff != 1 in the
+ * reference-faithful mode (zeroed map border).  The kernel's second look-up reads the PREVIOUS backward map at the
+ * position the current one returns; where that lands in a cell with zeroed border nodes (more than 3/4 of a cell towards a wall
+ * from the outermost nodes of the window) all three components come back scaled by the live nodes' weight s in [0, 1], and the
+ * *_prev field is sampled at s * q -- anywhere on the segment from the origin to the node, on any rank's planes, with a
+ * data-dependent s.  No sheet bounds that: these entry points take the *_prev fields of the WHOLE grid (nk_global planes, + 1
+ * for w; plane 0 = global plane 0), which the host solver assembles once per re-initialisation -- the only time they change
+ * (BimocqGPUSolver.cpp:503-527).  Everything else (fields, maps, windows, clamps) as in the local forms; global arrays below
+ * 2 GiB.  Ref: Mapping.cpp:383-390. */
+void gpu_advect_vel_double_global(float *u, float *v, float *w,
+                                  float *uprev_global, float *vprev_global, float *wprev_global,
+                                  float *backward_x, float *backward_y, float *backward_z,
+                                  float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                                  float h, int ni, int nj, int nk, bool is_point, float blend_coeff);
+void gpu_advect_field_double_global(float *field, float *field_prev_global,
+                                    float *backward_x, float *backward_y, float *backward_z,
+                                    float *backward_xprev, float *backward_yprev, float *backward_zprev,
+                                    float h, int ni, int nj, int nk, bool is_point, float blend_coeff);
 
 #ifdef __cplusplus
 }

@@ -117,7 +117,16 @@ enum {
     /* one GPU, 1: updateMapping launches the forward-map update on the library's auxiliary stream beside the backward map's DMC
      * sub-steps (fl_aux_*: disjoint arrays) instead of after them.  Same values.  Default 0: measured at 256^3 and 128^3, the
      * two kernels each fill the chip and gain nothing from running side by side (11.14-11.19 against 11.10-11.15 ms per step). */
-    BQ_OPT_CONCURRENT_MAPS = 12
+    BQ_OPT_CONCURRENT_MAPS = 12,
+    /* z-slab ranks, blend coefficient != 1, reference-faithful map border (BQ_OPT_KEEP_DMC_BORDER = 0), 1 (default): at every
+     * re-initialisation each rank assembles whole-grid copies of the *Prev fields (the only time they change; one message per
+     * peer and field) and the two-level advection samples those (gpu_advect_vel_double_global, include/bimocq_gpu.h): its second
+     * look-up lands anywhere between the origin and the node once it meets the zeroed border cells of the previous backward
+     * map, which no ghost zone or sheet bounds.  Bit-identical to one GPU.  0: local *Prev fields with ghost planes only --
+     * exact as long as no node within a cell of the outermost window nodes is carried more than 3/4 of a cell towards a wall
+     * between two re-initialisations (reads outside the slab return 0 otherwise).  get: 2 = copies are in use.  Costs five
+     * whole-grid float arrays per rank. */
+    BQ_OPT_WHOLE_GRID_PREV = 13
 };
 /* BQ_OPT_PROFILE_PHASES: milliseconds per phase summed over the steps since the last reset -- map update (DMC + RK3,
  * BimocqGPUSolver.cpp:136-139), advection with error compensation (:143-145), sources and forces (:157-177), projection

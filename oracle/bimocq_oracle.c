@@ -338,9 +338,10 @@ static void advect_comp(float *field, const float *field_init, map3 back,
 }
 
 /* GPU_kernel.cu:236-310 doubleAdvect_kernel */
+/* prev_global: temp_field holds every plane of the grid (a z-slab rank's assembled copy, orc_advect_*_double_global) */
 static void double_advect_comp(float *field, const float *temp_field, map3 back, map3 backprev,
                                float h, int ni, int nj, int nk, int dx, int dy, int dz,
-                               int is_point, float blend)
+                               int is_point, float blend, int prev_global)
 {
     nine_t n = nine_setup(h, ni, nj, nk, dx, dy, dz, is_point);
     f3 lo = mk3(h, h, h), hi = mk3(h * (float)ni - h, h * (float)nj - h, h * (float)NKG(nk) - h);
@@ -352,11 +353,13 @@ static void double_advect_comp(float *field, const float *temp_field, map3 back,
                 for (int ii = 0; ii < n.evals; ii++) {
                     f3 mid = clamp3(map_at(back, ni, nj, nk, h, nine_pos(&n, h, i, j, k, ii)), lo, hi);
                     f3 fin = clamp3(map_at(backprev, ni, nj, nk, h, mid), lo, hi);
-                    sum += n.weight * sample(temp_field, n.nbi, n.nbj, n.nbk, h, n.origin, fin);
+                    sum += n.weight * (prev_global ? sample_k(temp_field, n.nbi, n.nbj, NKG(nk) + dz, 0, h, n.origin, fin)
+                                                   : sample(temp_field, n.nbi, n.nbj, n.nbk, h, n.origin, fin));
                 }
                 f3 mid = clamp3(map_at(back, ni, nj, nk, h, nine_pos(&n, h, i, j, k, -1)), lo, hi);
                 f3 fin = clamp3(map_at(backprev, ni, nj, nk, h, mid), lo, hi);
-                float value = sample(temp_field, n.nbi, n.nbj, n.nbk, h, n.origin, fin);
+                float value = prev_global ? sample_k(temp_field, n.nbi, n.nbj, NKG(nk) + dz, 0, h, n.origin, fin)
+                                          : sample(temp_field, n.nbi, n.nbj, n.nbk, h, n.origin, fin);
                 float prev_value = 0.5f * (sum + value);
                 long id = IDX3(i, j, k, n.nbi, n.nbj);
                 field[id] = field[id] * blend + (1.0f - blend) * prev_value;
@@ -494,9 +497,31 @@ void orc_advect_vel_double(float *u, float *v, float *w,
                            float h, int ni, int nj, int nk, int is_point, float blend)
 {
     map3 b = { bx, by, bz }, bp = { bxp, byp, bzp };
-    double_advect_comp(u, utemp, b, bp, h, ni, nj, nk, 1, 0, 0, is_point, blend);
-    double_advect_comp(v, vtemp, b, bp, h, ni, nj, nk, 0, 1, 0, is_point, blend);
-    double_advect_comp(w, wtemp, b, bp, h, ni, nj, nk, 0, 0, 1, is_point, blend);
+    double_advect_comp(u, utemp, b, bp, h, ni, nj, nk, 1, 0, 0, is_point, blend, 0);
+    double_advect_comp(v, vtemp, b, bp, h, ni, nj, nk, 0, 1, 0, is_point, blend, 0);
+    double_advect_comp(w, wtemp, b, bp, h, ni, nj, nk, 0, 0, 1, is_point, blend, 0);
+}
+
+/* the same on a z-slab rank (orc_set_slab) with the *_prev fields of the whole grid: include/bimocq_gpu.h,
+ * gpu_advect_vel_double_global */
+void orc_advect_vel_double_global(float *u, float *v, float *w,
+                                  const float *uprev_g, const float *vprev_g, const float *wprev_g,
+                                  const float *bx, const float *by, const float *bz,
+                                  const float *bxp, const float *byp, const float *bzp,
+                                  float h, int ni, int nj, int nk, int is_point, float blend)
+{
+    map3 b = { bx, by, bz }, bp = { bxp, byp, bzp };
+    double_advect_comp(u, uprev_g, b, bp, h, ni, nj, nk, 1, 0, 0, is_point, blend, 1);
+    double_advect_comp(v, vprev_g, b, bp, h, ni, nj, nk, 0, 1, 0, is_point, blend, 1);
+    double_advect_comp(w, wprev_g, b, bp, h, ni, nj, nk, 0, 0, 1, is_point, blend, 1);
+}
+void orc_advect_field_double_global(float *field, const float *field_prev_g,
+                                    const float *bx, const float *by, const float *bz,
+                                    const float *bxp, const float *byp, const float *bzp,
+                                    float h, int ni, int nj, int nk, int is_point, float blend)
+{
+    map3 b = { bx, by, bz }, bp = { bxp, byp, bzp };
+    double_advect_comp(field, field_prev_g, b, bp, h, ni, nj, nk, 0, 0, 0, is_point, blend, 1);
 }
 
 /* GPU_kernel.cu:620-627 */
@@ -515,7 +540,7 @@ void orc_advect_field_double(float *field, const float *field_prev,
                              float h, int ni, int nj, int nk, int is_point, float blend)
 {
     map3 b = { bx, by, bz }, bp = { bxp, byp, bzp };
-    double_advect_comp(field, field_prev, b, bp, h, ni, nj, nk, 0, 0, 0, is_point, blend);
+    double_advect_comp(field, field_prev, b, bp, h, ni, nj, nk, 0, 0, 0, is_point, blend, 0);
 }
 
 /* GPU_kernel.cu:640-666.  du/dv/dw are read as `init` and then overwritten with the

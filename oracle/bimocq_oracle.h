@@ -126,6 +126,17 @@ void orc_set_plane_window(int k0, int k1, int nk_cells);
 /* z-slab ranks: cumulate_kernel's expression on the wall layers of its window, with the source read from an assembled copy
  * that holds the global planes [src_koff, src_koff + src_nk): dst = before + blend9(coeff * src(map(x))) on the window nodes
  * with i in xlist, j in ylist or GLOBAL plane in zlist (bimocq_oracle.c) */
+/* orc_advect_vel_double / orc_advect_field_double on a z-slab rank (orc_set_slab) with the *_prev fields of the whole grid
+ * (include/bimocq_gpu.h: gpu_advect_vel_double_global) */
+void orc_advect_vel_double_global(float *u, float *v, float *w,
+                                  const float *uprev_g, const float *vprev_g, const float *wprev_g,
+                                  const float *bx, const float *by, const float *bz,
+                                  const float *bxp, const float *byp, const float *bzp,
+                                  float h, int ni, int nj, int nk, int is_point, float blend);
+void orc_advect_field_double_global(float *field, const float *field_prev_g,
+                                    const float *bx, const float *by, const float *bz,
+                                    const float *bxp, const float *byp, const float *bzp,
+                                    float h, int ni, int nj, int nk, int is_point, float blend);
 void orc_accumulate_wall_fixup(const float *src, int src_koff, int src_nk, const float *before, float *dst,
                                const float *mx, const float *my, const float *mz,
                                float h, int ni, int nj, int nk, int axis, float coeff,

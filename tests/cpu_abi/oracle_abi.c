@@ -105,6 +105,13 @@ void gpu_advect_field(float *f, float *fi, float *bx, float *by, float *bz, floa
 void gpu_advect_field_double(float *f, float *fp, float *bx, float *by, float *bz, float *px, float *py, float *pz,
                              float h, int ni, int nj, int nk, bool pt, float blend)
 { orc_advect_field_double(f, fp, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
+void gpu_advect_vel_double_global(float *u, float *v, float *w, float *ug, float *vg, float *wg,
+                                  float *bx, float *by, float *bz, float *px, float *py, float *pz,
+                                  float h, int ni, int nj, int nk, bool pt, float blend)
+{ orc_advect_vel_double_global(u, v, w, ug, vg, wg, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
+void gpu_advect_field_double_global(float *f, float *fg, float *bx, float *by, float *bz, float *px, float *py, float *pz,
+                                    float h, int ni, int nj, int nk, bool pt, float blend)
+{ orc_advect_field_double_global(f, fg, bx, by, bz, px, py, pz, h, ni, nj, nk, pt, blend); }
 void gpu_accumulate_velocity(float *uc, float *vc, float *wc, float *du, float *dv, float *dw,
                              float *fx, float *fy, float *fz, float h, int ni, int nj, int nk, bool pt, float coeff)
 { orc_accumulate_velocity(uc, vc, wc, du, dv, dw, fx, fy, fz, h, ni, nj, nk, pt, coeff); }

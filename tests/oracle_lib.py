@@ -100,6 +100,8 @@ _SIGS = {
     "orc_solve_backwardDMC": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_f]),
     "orc_advect_velocity": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_i]),
     "orc_advect_vel_double": (None, [FP] * 12 + [c_f, c_i, c_i, c_i, c_i, c_f]),
+    "orc_advect_vel_double_global": (None, [FP] * 12 + [c_f, c_i, c_i, c_i, c_i, c_f]),
+    "orc_advect_field_double_global": (None, [FP] * 8 + [c_f, c_i, c_i, c_i, c_i, c_f]),
     "orc_advect_field": (None, [FP] * 5 + [c_f, c_i, c_i, c_i, c_i]),
     "orc_advect_field_double": (None, [FP] * 8 + [c_f, c_i, c_i, c_i, c_i, c_f]),
     "orc_accumulate_velocity": (None, [FP] * 9 + [c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -50,6 +50,11 @@ def main():
     ap.add_argument("--mgcg-shared", type=int, default=1, help="BQ_OPT_MGCG_SHARED: 1 = the multigrid levels shared between the ranks "
                     "where the decomposition allows it, 0 = the replicated solve")
     ap.add_argument("--expect-shared", type=int, default=-1, help="1 / 0: fail unless the multigrid projection did / did not take the shared path")
+    ap.add_argument("--whole-grid-prev", type=int, default=1, help="BQ_OPT_WHOLE_GRID_PREV: whole-grid copies of the *Prev fields for blend != 1")
+    ap.add_argument("--expect-whole-grid-prev", type=int, default=-1, help="1 / 0: fail unless the copies were / were not in use at the end")
+    ap.add_argument("--scene", choices=["default", "wall"], default="default",
+                    help="wall: velocity sources blowing at the x-high and y-high walls inside the upper ranks' slabs, so that with blend < 1 "
+                         "the second look-up of the two-level advection lands in the zeroed border cells of the previous backward map")
     ap.add_argument("--transport", choices=["host", "rccl"], default="host",
                     help="rccl (gpu backend): the library's own RCCL code path (fl_comm_init + ncclSend/ncclRecv); with several "
                          "ranks on one GPU that needs BQ_RCCL_LIBRARY = the tests' stand-in (tests/fake_rccl)")
@@ -106,6 +111,10 @@ def main():
     zmid = 0.5 * nk * h
     em = [(0.5 * ni * h, 0.3 * nj * h, zmid + 0.3 * h, 0.16 * ni * h, 1.0, 2.0, 0.0, 2),
           (0.4 * ni * h, 0.35 * nj * h, 0.22 * nk * h, 0.12 * ni * h, 0.7, 1.0, 0.0, 1)]
+    if a.scene == "wall":
+        zup = (nk - 0.3 * nk / world) * h            # inside the last rank's slab
+        em = [((ni - 5.2) * h, 0.5 * nj * h + 0.37 * h, zup + 0.29 * h, 0.14 * ni * h, 1.0, 2.0, 1.0, 3),
+              (0.45 * ni * h, (nj - 4.6) * h, zmid + 0.31 * h, 0.14 * ni * h, 0.8, 1.0, 1.0, 2)]
     s = solver.BimocqGPUSolver(ni, nj, nk, a.L, a.viscosity, BLEND, lib=hostlib, errlib=abilib, rank=rank, nranks=world, ghost=a.ghost,
                                scheme=a.scheme)
     s.setSmoke(0.05, 1.0, em)
@@ -121,6 +130,7 @@ def main():
     s.setOption(7, a.ends_first)
     s.setOption(10, a.triples)
     s.setOption(11, a.mgcg_shared)
+    s.setOption(13, a.whole_grid_prev)
     if a.backend == "cpu":
         # the oracle library inside the CPU stand-in carries the slab context; the reference run below
         # uses the separately loaded liboracle.so, which stays single-domain
@@ -195,6 +205,11 @@ def main():
         took = s.getOption(11) == 2
         print(f"[rank {rank}] multigrid projection on slabs: {'levels SHARED between the ranks' if took else 'replicated solve'}", flush=True)
         if a.expect_shared >= 0 and took != bool(a.expect_shared):
+            bad += 1
+    if a.expect_whole_grid_prev >= 0:
+        in_use = s.getOption(13) == 2
+        print(f"[rank {rank}] two-level advection: {'whole-grid copies of the *Prev fields' if in_use else 'local *Prev fields'}", flush=True)
+        if in_use != bool(a.expect_whole_grid_prev):
             bad += 1
     moved = np.abs(o.field("v")).max()
     print(f"[rank {rank}/{world}] backend={a.backend} steps={a.steps} exchanges={tr.exchanges} planes={tr.planes_moved} "

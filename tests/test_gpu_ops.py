@@ -106,6 +106,51 @@ def test_advect_velocity_and_field(gm, ni, nj, nk, h, is_point):
     m.check()
 
 
+@pytest.mark.parametrize("ranks,h", [(2, 0.05), (3, 1.0 / 32)])
+def test_advect_double_with_whole_grid_previous_fields_on_a_slab_rank(ranks, h):
+    """gpu_advect_vel_double_global / gpu_advect_field_double_global under fl_set_slab: the *_prev fields are the whole grid's,
+    everything else the rank's local planes.  The case makes the second look-up meet the zeroed border cells of the previous
+    map (tests/blend_slab_case.py), where the local form reads outside the slab; the global form equals the oracle's on every
+    local plane and the single-domain operator on the owned planes -- on a spacing that is and one that is not a power of two."""
+    import blend_slab_case as B
+    import gpufluidsimulation_amd as bq
+    lib = bq.hip_lib()
+    ni, nj, nk, G, blend = 20, 18, 24, 5, 0.6
+    h, back, backp, prev, cur = B.global_case(ni, nj, nk, h)
+    o = oracle()
+    ref = [a.copy() for a in cur]
+    o.orc_advect_vel_double(*map(fp, ref[:3]), *map(fp, prev[:3]), *map(fp, back), *map(fp, backp), h, ni, nj, nk, 0, blend)
+    o.orc_advect_field_double(fp(ref[3]), fp(prev[3]), *map(fp, back), *map(fp, backp), h, ni, nj, nk, 0, blend)
+    pl = B.PLANES(ni, nj)
+    for r in range(ranks):
+        own0, own1 = r * nk // ranks, (r + 1) * nk // ranks
+        nkl = own1 - own0 + 2 * G
+        view = lambda a, c: B.local_view(a, pl[c], B.EXTRA[c], nk, own0, own1, G)
+        lb, lbp = [view(a, 3) for a in back], [view(a, 3) for a in backp]
+        want = [view(cur[c], c) for c in range(4)]
+        o.orc_set_slab(own0 - G, nk, own0, own1, nkl)
+        try:
+            o.orc_advect_vel_double_global(*map(fp, want[:3]), *map(fp, prev[:3]), *map(fp, lb), *map(fp, lbp), h, ni, nj, nkl, 0, blend)
+            o.orc_advect_field_double_global(fp(want[3]), fp(prev[3]), *map(fp, lb), *map(fp, lbp), h, ni, nj, nkl, 0, blend)
+        finally:
+            o.orc_set_slab(0, 0, 0, 0, 0)
+        d = dev(*[view(cur[c], c) for c in range(4)])
+        dprev, dlb, dlbp = dev(*prev), dev(*lb), dev(*lbp)
+        lib.fl_set_slab(own0 - G, nk, own0, own1, nkl)
+        try:
+            lib.gpu_advect_vel_double_global(*[x.ptr for x in d[:3]], *[x.ptr for x in dprev[:3]], *[x.ptr for x in dlb], *[x.ptr for x in dlbp],
+                                             h, ni, nj, nkl, False, blend)
+            lib.gpu_advect_field_double_global(d[3].ptr, dprev[3].ptr, *[x.ptr for x in dlb], *[x.ptr for x in dlbp], h, ni, nj, nkl, False, blend)
+        finally:
+            lib.fl_set_slab(0, 0, 0, 0, 0)
+        bq.check()
+        for c in range(4):
+            got = d[c].numpy()
+            assert F.same(want[c], got), (r, c)
+            assert np.array_equal(B.owned(got, pl[c], B.EXTRA[c], own0, own1, G, True, r == ranks - 1),
+                                  B.owned(ref[c], pl[c], B.EXTRA[c], own0, own1, G, False, r == ranks - 1)), (r, c)
+
+
 @pytest.mark.parametrize("ni,nj,nk,h", GRIDS)
 @pytest.mark.parametrize("blend", [1.0, 0.6])
 def test_advect_double(gm, ni, nj, nk, h, blend):

@@ -79,6 +79,25 @@ def test_two_ranks_on_a_spacing_that_is_not_a_power_of_two(fake):
     assert out.count("mismatches=0") == 2
 
 
+def test_blend_below_one_with_whole_grid_previous_fields_over_the_rccl_branch(fake):
+    """blend 0.6 in the reference-faithful mode (zeroed map border, no BQ_OPT_KEEP_DMC_BORDER): at every re-initialisation the
+    ranks assemble whole-grid copies of the *Prev fields with one point-to-point group (fl_p2p_exchange) and the two-level
+    advection samples those (gpu_advect_*_double_global); sources blowing at the walls inside the upper rank's slab; 2 and 3
+    ranks, bit-identical to the single-domain oracle"""
+    env = dict(os.environ)
+    os.environ["SLAB_TEST_BLEND"] = "0.6"
+    try:
+        rc, out = launch_worker(fake, 2, "--steps", 5, "--scene", "wall", "--expect-whole-grid-prev", 1)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 2 and out.count("whole-grid copies") == 2
+        rc, out = launch_worker(fake, 3, "--dims", 24, 20, 36, "--ghost", 6, "--steps", 4, "--iters", 16, "--dt-cells", 1.0,
+                                "--scene", "wall", "--expect-whole-grid-prev", 1)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 3
+    finally:
+        os.environ.clear(); os.environ.update(env)
+
+
 def test_three_ranks_over_the_rccl_branch(fake):
     """a middle rank with two neighbours; wall sheets between non-neighbours (rank 2 needs planes of rank 0)"""
     rc, out = launch_worker(fake, 3, "--dims", 24, 20, 36, "--ghost", 6, "--steps", 3, "--iters", 16, "--dt-cells", 1.0)

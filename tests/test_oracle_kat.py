@@ -365,3 +365,48 @@ def test_fma_contraction_moves_the_fields_far_less_than_the_tolerance():
         assert float(np.abs(a[k]).max()) > 0.05, k                   # a developed flow, not zeros
         worst = max(worst, float(np.sqrt(np.mean((a[k] - b[k]) ** 2))))
     assert 0.0 < worst < 5e-7, worst                               # it does change bits -- and stays two orders below 1e-5
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_two_level_advection_on_slab_ranks_needs_the_whole_previous_fields(ranks):
+    """blend != 1 (GPU_kernel.cu:236-310) with the reference's zeroed map border: where the current backward map
+    carries a node of the window's outermost layers more than 3/4 of a cell towards a wall, the look-up of the PREVIOUS map meets
+    zeroed border nodes, comes back as s * q with s in [0, 1], and the *_prev field is sampled anywhere between the origin and the
+    node.  A z-slab rank that holds only its own planes (+ ghosts) of the *_prev fields reads zeros there (upper ranks differ
+    from the single domain); with the whole-grid *_prev fields (orc_advect_*_double_global, what the host solver assembles at
+    every re-initialisation) every rank reproduces the single domain bit for bit."""
+    import blend_slab_case as B
+    ni, nj, nk, G, blend = 20, 18, 24, 5, 0.6
+    h, back, backp, prev, cur = B.global_case(ni, nj, nk, 0.05)
+    o = oracle()
+    ref = [a.copy() for a in cur]
+    o.orc_advect_vel_double(*map(fp, ref[:3]), *map(fp, prev[:3]), *map(fp, back), *map(fp, backp), h, ni, nj, nk, 0, blend)
+    o.orc_advect_field_double(fp(ref[3]), fp(prev[3]), *map(fp, back), *map(fp, backp), h, ni, nj, nk, 0, blend)
+    pl = B.PLANES(ni, nj)
+    local_differs = 0
+    for r in range(ranks):
+        own0, own1 = r * nk // ranks, (r + 1) * nk // ranks
+        nkl = own1 - own0 + 2 * G
+        view = lambda a, c: B.local_view(a, pl[c], B.EXTRA[c], nk, own0, own1, G)
+        lb, lbp = [view(a, 3) for a in back], [view(a, 3) for a in backp]
+        lprev = [view(prev[c], c) for c in range(4)]
+        for whole in (False, True):
+            lc = [view(cur[c], c) for c in range(4)]
+            o.orc_set_slab(own0 - G, nk, own0, own1, nkl)
+            try:
+                if whole:
+                    o.orc_advect_vel_double_global(*map(fp, lc[:3]), *map(fp, prev[:3]), *map(fp, lb), *map(fp, lbp), h, ni, nj, nkl, 0, blend)
+                    o.orc_advect_field_double_global(fp(lc[3]), fp(prev[3]), *map(fp, lb), *map(fp, lbp), h, ni, nj, nkl, 0, blend)
+                else:
+                    o.orc_advect_vel_double(*map(fp, lc[:3]), *map(fp, lprev[:3]), *map(fp, lb), *map(fp, lbp), h, ni, nj, nkl, 0, blend)
+                    o.orc_advect_field_double(fp(lc[3]), fp(lprev[3]), *map(fp, lb), *map(fp, lbp), h, ni, nj, nkl, 0, blend)
+            finally:
+                o.orc_set_slab(0, 0, 0, 0, 0)
+            for c in range(4):
+                mine = B.owned(lc[c], pl[c], B.EXTRA[c], own0, own1, G, True, r == ranks - 1)
+                want = B.owned(ref[c], pl[c], B.EXTRA[c], own0, own1, G, False, r == ranks - 1)
+                if whole:
+                    assert np.array_equal(mine, want), (r, c)
+                else:
+                    local_differs += int((mine != want).sum())
+    assert local_differs > 100          # the case does exercise the far reads

@@ -88,6 +88,31 @@ def test_distortion_driven_reinit_on_slabs_cpu():
     assert out.count("mismatches=0") == 3
 
 
+def test_blend_below_one_reference_faithful_on_slabs_cpu():
+    """blend 0.6 WITHOUT BQ_OPT_KEEP_DMC_BORDER: the second look-up of the two-level advection can
+    land anywhere between the origin and the node once it meets the zeroed border cells of the previous backward map
+    (tests/test_oracle_kat.py::test_two_level_advection_on_slab_ranks_needs_the_whole_previous_fields shows the operator
+    needing it), so every rank assembles whole-grid copies of the *Prev fields at each re-initialisation
+    (BQ_OPT_WHOLE_GRID_PREV, default on) and samples those.  Sources blowing at the x-high and y-high walls inside the upper
+    ranks' slabs; 2 and 3 ranks; the copies are checked to be in use and every owned plane equals the single-domain oracle."""
+    env = dict(os.environ)
+    os.environ["SLAB_TEST_BLEND"] = "0.6"
+    try:
+        rc, out = launch(2, "--backend", "cpu", "--steps", 6, "--scene", "wall", "--expect-whole-grid-prev", 1)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 2 and out.count("whole-grid copies") == 2
+        rc, out = launch(3, "--backend", "cpu", "--dims", 24, 20, 36, "--ghost", 6, "--steps", 4, "--iters", 16, "--dt-cells", 1.0,
+                         "--scene", "wall", "--expect-whole-grid-prev", 1)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 3
+        # the local *Prev fields (option 0) stay available: exact while no look-up meets the border cells, as here
+        rc, out = launch(2, "--backend", "cpu", "--steps", 3, "--scene", "wall", "--whole-grid-prev", 0, "--expect-whole-grid-prev", 0)
+        assert rc == 0, out
+        assert out.count("mismatches=0") == 2 and out.count("local *Prev fields") == 2
+    finally:
+        os.environ.clear(); os.environ.update(env)
+
+
 def test_multigrid_projection_replicated_on_slabs_cpu():
     """the fp64 multigrid-CG projection (what the reference's binary ships) on z-slab ranks: every rank assembles the global
     velocity (one point-to-point message per peer and component), runs the single-domain solver on it and takes its planes
