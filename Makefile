@@ -24,7 +24,7 @@ HOST_OBJS   := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(HOST_SRCS))
 
 all: $(PKG)/libbimocq_hip.so $(PKG)/libbimocq_host.so oracle example
 
-KERNEL_HDRS := $(wildcard $(CSRC)/*.h)
+KERNEL_HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc)
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(KERNEL_HDRS) include/bimocq_gpu.h
 	@mkdir -p $(OBJDIR)

@@ -927,7 +927,7 @@ def main():
             line.setdefault("extra", {})["arithmetic_variants"] = {"note": f"failed: {e}"}
         finally:
             lib.fl_set_option(bq._lib.FL_OPT_FAST_LERP, 0)
-            lib.fl_set_option(bq._lib.FL_OPT_FIELD_WINDOW, 0)
+            lib.fl_set_option(bq._lib.FL_OPT_FIELD_WINDOW, -1)
         try:
             big = 512
             s5 = BimocqGPUSolver(big, big, big, 1.0, 0.0, 1.0, device=local_rank, scheme=0)

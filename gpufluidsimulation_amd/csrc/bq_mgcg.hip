@@ -681,6 +681,21 @@ __device__ __forceinline__ D4 res_d4(D4 ce, D4 fr, D4 bk, D4 dn, D4 up, D4 b, bo
     return o;
 }
 
+// mg_poisson_kernel's expression (calc_poisson_kernel, :1075-1085) on the four cells of a lane
+__device__ __forceinline__ D4 poi_d4(D4 ce, D4 fr, D4 bk, D4 dn, D4 up, bool first, bool last)
+{
+    const double leftA = lane_up(ce.a.b);
+    const double rightA = lane_rol(first ? ce.b.a : ce.a.a);
+    const double leftB = lane_ror(last ? ce.a.b : ce.b.b);
+    const double rightB = lane_down(ce.b.a);
+    D4 o;
+    o.a.a = (leftA + ce.a.b + fr.a.a + bk.a.a + dn.a.a + up.a.a) - ce.a.a * 6;
+    o.a.b = (ce.a.a + rightA + fr.a.b + bk.a.b + dn.a.b + up.a.b) - ce.a.b * 6;
+    o.b.a = (leftB + ce.b.b + fr.b.a + bk.b.a + dn.b.a + up.b.a) - ce.b.a * 6;
+    o.b.b = (ce.b.a + rightB + fr.b.b + bk.b.b + dn.b.b + up.b.b) - ce.b.b * 6;
+    return o;
+}
+
 // RES (with S = 3): the third level is not a sweep but the RESIDUAL of the second -- rout = b - A x'' on interior cells
 // (mg_residual_kernel's expression), x'' itself is stored to `out` as the level is made: the last launch of V_Cycle's 32 sweeps
 // and the residual that follows it in one pass over the arrays.
@@ -1805,7 +1820,7 @@ void gpu_multi_grid_conjugate_gradient(float *u, float *v, float *w, double *div
     // updates are out of place: p -> temp1 (update_x) -> p (the V-cycle's add), dir <-> levels[0].b (free while the V-cycle
     // reads `residual` itself as its right-hand side, i.e. in every iteration but the last)
     const bool fused = levelNum >= 1 && mg_fuse_ok(ni, nj, nk, { div, p, dir, residual, temp0, temp1, levels[0].b, levels[0].x });
-    const FuseGeom fg = fused ? fuse_geom(ni, nj, nk) : FuseGeom{};
+    const FuseGeom fg = fused ? fuse_geom_for(ni, nj, nk) : FuseGeom{};
     // the max parts of the fused residual: in the runtime's scratch, behind the 4 KB that mg_dot_finish uses
     double *maxpart = fused ? (double *)scratch(4096 + (size_t)(fg.nblk + fg.nrim) * sizeof(double)) : nullptr;
     if (fused && !maxpart) return;

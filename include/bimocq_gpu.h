@@ -351,7 +351,8 @@ enum {
                                  * vector updates of an outer iteration inside the stencil pass that follows each of them
                                  * (update_x + residual; add + residual + max + dot; update_dir + A dir + dot -- three
                                  * launches for nine passes over the arrays, bq_mgcg_fused.hip.inc) on grids of 2^20 cells
-                                 * and more, 2 on any grid of that row length, 0 never.  Same values; the fused form keeps
+                                 * and more, 2 on any grid of that row length, 0 never (3: as 2 with the wave-per-row
+                                 * form of the kernels on rows of 256 -- the same time, kept for A/B).  Same values; the fused form keeps
                                  * its intermediate vectors in temp1 and levels[0].b, which the reference's caller
                                  * allocates at full size (BimocqGPUSolver.cpp:65-66), and what temp0 / temp1 hold after
                                  * the call differs (both are scratch).                                               */

@@ -113,6 +113,7 @@ def test_mgcg_with_fused_smoothing_on_every_level(hip):
     (256, 9, 7, 1, 2, 11),            # odd row count, one z-chunk, one level
     (512, 8, 10, 2, 3, 3),            # rows of four waves: two partials per row
     (256, 64, 64, 3, 2, None),        # 2^20 cells: fused by default
+    (256, 37, 21, 2, 3, 5),           # rows that do not fill the last block of eight, z-chunks of uneven length
 ])
 def test_mgcg_vector_updates_inside_the_stencil_passes(hip, ni, nj, nk, levels, iters, stale):
     """FL_OPT_MGCG_FUSE: update_x + residual, add + residual + max + dot, update_dir + A dir + dot as three launches
@@ -125,6 +126,10 @@ def test_mgcg_vector_updates_inside_the_stencil_passes(hip, ni, nj, nk, levels, 
         hip.fl_mg_fused_launches()
         test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, stale)
         assert hip.fl_mg_fused_launches() > 0
+        if ni == 256:                 # 3 = the wave-per-row form of the kernels (rows of 256 cells only)
+            hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 3)
+            test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, stale)
+            assert hip.fl_mg_fused_launches() > 0
         hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 0)
         test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, stale)
         assert hip.fl_mg_fused_launches() == 0
