@@ -42,6 +42,8 @@ JACOBI_BYTES_PER_VOXEL = 12.0   # read p + read div + write p'  
 
 from gpufluidsimulation_amd.scenes import SMOKE, collision, leapfrog, rising_smoke     # noqa: E402  (pure Python, no GPU touched)
 
+WATCHDOG = {}                # N > 1: the headline of a finished timed region, for the watchdog (main)
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -379,7 +381,33 @@ def main():
         local_rank %= torch.cuda.device_count()         # debug transport: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dist = None
+    t_start = time.perf_counter()
+
+    def stage(msg):
+        # N > 1: where every rank is, on stderr -- a collective that never returns (real RCCL has no deadlock detection) then
+        # shows as the last line of the rank that entered it and the missing line of the rank that did not
+        if world > 1:
+            print(f"[bench rank {rank}/{world} +{time.perf_counter() - t_start:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
     if world > 1:
+        # ... and a hung run ends itself with every thread's Python stack on stderr (BENCH_WATCHDOG_S seconds, 0 = never)
+        # instead of waiting for the launcher's kill, which says nothing
+        wd = int(os.environ.get("BENCH_WATCHDOG_S", "480"))
+        if wd > 0:
+            import faulthandler
+            import threading
+
+            def watchdog_fired():
+                print(f"[bench rank {rank}/{world}] WATCHDOG: no result after {wd} s -- the Python stacks of this rank follow", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                fb = WATCHDOG.get("headline")
+                if rank == 0 and fb is not None and not WATCHDOG.get("printed"):
+                    # the timed region had finished on every rank: hand out its number rather than nothing
+                    print(json.dumps(fb), flush=True)
+                os._exit(0 if (WATCHDOG.get("printed") or fb is not None) else 3)      # (the headline exists on every rank)
+            timer = threading.Timer(wd, watchdog_fired)
+            timer.daemon = True
+            timer.start()
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # torch.distributed is the CONTROL plane only (rendezvous, the unique id, barriers, the max over ranks of the
@@ -387,6 +415,7 @@ def main():
         # the library's own RCCL communicator over xGMI (csrc/bq_halo.hip), created below from an id that travels over
         # this group.  (One RCCL instance per process: torch's bundled copy is never initialised.)
         dist.init_process_group("gloo")
+        stage("control plane up (gloo)")
 
     import gpufluidsimulation_amd as bq
     from gpufluidsimulation_amd import transport
@@ -433,9 +462,12 @@ def main():
             try:
                 if force_fail:
                     raise RuntimeError("BENCH_FORCE_RCCL_FAILURE=1")
+                stage("RCCL binding self-test (one-rank communicator)")
                 if lib.fl_comm_selftest() != 0:
                     raise RuntimeError(lib.fl_last_error_string().decode(errors="replace"))
+                stage("fl_comm_init: unique id over gloo, ncclCommInitRank, second communicator")
                 transport.init_rccl(lib, dist)
+                stage(f"communicators up: {lib.fl_comm_count()}")
             except Exception as e:              # noqa: BLE001 -- any set-up failure takes the same exit
                 failure = str(e) or type(e).__name__
             ok = torch.tensor([0 if failure else 1], dtype=torch.int32)
@@ -518,14 +550,32 @@ def main():
     for kv in args.fl_opt:
         k, v = kv.split("=")
         lib.fl_set_option(int(k), int(v))
+    stage(f"solver built, {args.warmup} warm-up steps")
     run(args.warmup)
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 1)
     lib.fl_comm_stats(None, 1)
     barrier()
+    stage(f"timed region: {args.steps} steps")
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     el = time.perf_counter() - t0
+    stage(f"timed region done: {el / max(1, args.steps) * 1e3:.3f} ms per step on this rank; diagnostics and knob legs follow")
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        # (test hook: BENCH_HANG_AFTER_TIMED=1 parks every rank here, as a collective that never returns would)
+        # what the watchdog prints if a later leg never returns (the contract's fields only; the full line replaces it)
+        WATCHDOG["headline"] = {
+            "metric": "Mvoxels/s per step (bimocq3D)", "value": round(nx * ny * nz_global * args.steps / el / 1e6, 2), "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"bimocq3D {nx}x{ny}x{nz_global}, {args.jacobi_iters} Jacobi iters, fp32", "parallelism": f"{world} z-slabs",
+                       "note": "WATCHDOG LINE: the timed region finished on every rank, a diagnostics / knob leg after it did not return "
+                               "(stacks on stderr); roofline, cpu_baseline and diagnostics are missing from this line"}}
+        if os.environ.get("BENCH_HANG_AFTER_TIMED") == "1":
+            time.sleep(10 ** 6)
     comm_stats = (C.c_longlong * 4)()
     lib.fl_comm_stats(comm_stats, 0)
     lib.fl_set_option(bq._lib.FL_OPT_PROFILE_JACOBI, 0)
@@ -975,16 +1025,20 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args)
         except Exception as e:                  # never lose the GPU numbers to a host-side hiccup
             line["cpu_baseline"] = {"value": None, "unit": "Mvoxels/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        # (printed BEFORE the communicators are torn down: a teardown that never returns must not cost the measured line)
+        if line["config"]["nonfinite_velocity_seen"]:
+            print("[bench] WARNING: a NaN or an Inf appeared in the velocity field during this run (fl_nonfinite_seen): the "
+                  "timings are those of a broken simulation", file=sys.stderr, flush=True)
+        print(json.dumps(line), flush=True)
+    WATCHDOG["printed"] = True             # (every rank: a watchdog that fires during the teardown exits with 0)
+    stage("result printed; closing the solver and the communicators")
     s.close()
     if dist is not None:
         dist.barrier()
         lib.fl_comm_destroy()
         dist.destroy_process_group()
-    if rank == 0:
-        if line["config"]["nonfinite_velocity_seen"]:
-            print("[bench] WARNING: a NaN or an Inf appeared in the velocity field during this run (fl_nonfinite_seen): the "
-                  "timings are those of a broken simulation", file=sys.stderr, flush=True)
-        print(json.dumps(line), flush=True)
+    stage("done")
     # (no explicit fl_shutdown: the library releases its streams, events and cached graphs itself at process exit --
     # fl_shutdown_all, registered by fl_init and by gpufluidsimulation_amd._lib)
 

@@ -254,6 +254,26 @@ def test_bench_gpus_2_runs_the_rccl_branch(fake, tmp_path):
         assert len(rec) > 100 and stitched.tobytes() == rec.tobytes(), f
 
 
+def test_bench_watchdog_hands_out_the_headline_of_a_run_that_hangs_afterwards(fake):
+    """Real RCCL has no deadlock detection: a collective that never returns would leave `bench.py --gpus N` waiting for the
+    launcher's kill.  N > 1 runs carry a watchdog (BENCH_WATCHDOG_S): when it fires every rank prints its Python stacks, and if
+    the timed region had finished on every rank, rank 0 prints the headline's contract fields and the run exits with 0.
+    BENCH_HANG_AFTER_TIMED=1 parks the ranks right after the timed region."""
+    if "async" in os.path.basename(fake):
+        pytest.skip("one transport is enough")
+    env = dict(os.environ, OMP_NUM_THREADS="4", BQ_RCCL_LIBRARY=fake, BENCH_HANG_AFTER_TIMED="1", BENCH_WATCHDOG_S="75")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "3", "--warmup", "1",
+                        "--jacobi-iters", "40", "--no-cpu-baseline", "--no-extra"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3 and "WATCHDOG LINE" in d["config"]["note"]
+    assert "WATCHDOG" in r.stderr and "timed region done" in r.stderr and "bench.py\", line" in r.stderr      # the stacks name the place
+
+
 def test_bench_gpus_4_on_the_rccl_branch(fake):
     """four self-launched ranks (interior ranks with two neighbours, wall sheets between all pairs), strong scaling of one
     64^3 grid: rc 0, one line, four ranks in the communicator"""
