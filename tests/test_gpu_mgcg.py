@@ -137,6 +137,28 @@ def test_mgcg_vector_updates_inside_the_stencil_passes(hip, ni, nj, nk, levels, 
         hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1)
 
 
+def test_mgcg_fused_vector_updates_on_random_shapes(hip):
+    """seeded sweep for the fused level-0 kernels: rows of 256 and 512 cells, row / plane counts that leave partial row blocks and
+    uneven z-chunks (chunk length forced through FL_OPT_JACOBI_KCHUNK2 in the wave-per-row form), 1-2 levels, 2-4 iterations,
+    stale rim cells; both kernel forms"""
+    import gpufluidsimulation_amd as bq
+    rng = np.random.default_rng(20261005)
+    try:
+        for case in range(10):
+            ni = 512 if case % 5 == 4 else 256
+            nj, nk = int(rng.integers(5, 34)), int(rng.integers(7, 26))
+            levels = 1 if min(nj, nk) < 9 else int(rng.integers(1, 3))
+            iters, mode = int(rng.integers(2, 5)), (3 if (ni == 256 and case % 2) else 2)
+            hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, mode)
+            hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, int(rng.integers(4, 12)) if mode == 3 else 0)
+            hip.fl_mg_fused_launches()
+            test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, 100 + case)
+            assert hip.fl_mg_fused_launches() > 0, (case, ni, nj, nk, levels, iters, mode)
+    finally:
+        hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1)
+
+
 @pytest.mark.parametrize("ni,nj,nk,levels", [(64, 64, 64, 4), (32, 32, 32, 3), (16, 16, 16, 2), (30, 14, 9, 2), (33, 31, 12, 3)])
 def test_mgcg_bottom_of_the_v_cycle_in_one_launch(hip, ni, nj, nk, levels):
     """FL_OPT_MGCG_BOTTOM (default on): the two coarsest levels -- when they fit 4096 and 512 cells -- run as ONE launch
