@@ -387,7 +387,8 @@ def main():
         # N > 1: where every rank is, on stderr -- a collective that never returns (real RCCL has no deadlock detection) then
         # shows as the last line of the rank that entered it and the missing line of the rank that did not
         if world > 1:
-            print(f"[bench rank {rank}/{world} +{time.perf_counter() - t_start:6.1f} s] {msg}", file=sys.stderr, flush=True)
+            sys.stderr.write(f"[bench rank {rank}/{world} +{time.perf_counter() - t_start:6.1f} s] {msg}\n")      # (one write: ranks share the pipe)
+            sys.stderr.flush()
 
     if world > 1:
         # ... and a hung run ends itself with every thread's Python stack on stderr (BENCH_WATCHDOG_S seconds, 0 = never)
