@@ -42,6 +42,13 @@ def fake(request):
     os.environ.pop("BQ_FAKE_RCCL_DELAY_MB", None)
 
 
+def skip_plain_async(fake):
+    """the three heaviest tests run on the blocking stand-in and on the DELAYED stream-ordered one (the stronger of the two
+    stream-ordered forms: a transfer that starts ~100 us after the call exposes a missing stream dependency), not on both"""
+    if "async" in os.path.basename(fake) and not os.environ.get("BQ_FAKE_RCCL_DELAY_MB"):
+        pytest.skip("covered by the delayed stream-ordered stand-in")
+
+
 def launch_worker(fake, nproc, *args, timeout=900):
     env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1", BQ_RCCL_LIBRARY=fake)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
@@ -117,6 +124,7 @@ def test_four_ranks_without_overlap_and_with_viscosity(fake):
 def test_tall_slabs_ends_first_chunks_over_the_rccl_branch(fake):
     """slabs tall enough for the ends-first pressure chunks (the exchange for the next chunk starts while two pair interiors
     of this one are still to run): on the stream-ordered stand-ins a sweep that touched planes in flight would show"""
+    skip_plain_async(fake)
     rc, out = launch_worker(fake, 2, "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 3, "--iters", 60)
     assert rc == 0, out
     assert out.count("mismatches=0") == 2
@@ -137,6 +145,7 @@ def test_reserved_cus_change_no_value_over_the_rccl_branch(fake):
     """FL_OPT_RESERVE_CUS = 8 / 16: the compute stream is recreated with a CU mask (248 / 240 of the 256 compute units, the
     Jacobi launchers size their grids for them) so that RCCL's send / recv kernels find free CUs; tall slabs, so that the
     ends-first pressure chunks and the fused plane-range launches run under the mask.  Every field equals the oracle's."""
+    skip_plain_async(fake)
     rc, out = launch_worker(fake, 2, "--dims", 32, 32, 96, "--L", 1.0, "--ghost", 8, "--steps", 3, "--iters", 60, "--reserve-cus", 8)
     assert rc == 0, out
     assert out.count("mismatches=0") == 2 and "comm profile" in out
@@ -166,6 +175,7 @@ def test_multigrid_levels_shared_between_the_ranks(fake, nranks, dims):
     and solved replicated.  Planes of 1024 / 512 cells (multiples of the 256-cell dot blocks), 48 / 32 planes per rank, three
     shared levels.  Every field equals the single-domain oracle's bit for bit, BiMocq and the reference binary's default
     (MAC_REFLECTION + multigrid-CG); with the option off the replicated solve runs and gives the same."""
+    skip_plain_async(fake)
     common = ["--dims", *dims, "--L", 1.0, "--ghost", 8, "--steps", 2, "--iters", 3, "--dt-cells", 1.0, "--projection-kind", 1]
     rc, out = launch_worker(fake, nranks, *common, "--expect-shared", 1)
     assert rc == 0, out
@@ -263,7 +273,7 @@ def test_bench_watchdog_hands_out_the_headline_of_a_run_that_hangs_afterwards(fa
     BENCH_HANG_AFTER_TIMED=1 parks the ranks right after the timed region."""
     if "async" in os.path.basename(fake):
         pytest.skip("one transport is enough")
-    env = dict(os.environ, OMP_NUM_THREADS="4", BQ_RCCL_LIBRARY=fake, BENCH_HANG_AFTER_TIMED="1", BENCH_WATCHDOG_S="75")
+    env = dict(os.environ, OMP_NUM_THREADS="4", BQ_RCCL_LIBRARY=fake, BENCH_HANG_AFTER_TIMED="1", BENCH_WATCHDOG_S="300")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "3", "--warmup", "1",
