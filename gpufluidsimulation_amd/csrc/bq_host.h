@@ -39,7 +39,7 @@ struct Runtime {
     int         opt_mgcg_tile = 1;          // FL_OPT_MGCG_TILE: LDS tile smoother on the coarse levels of the V-cycle
     int         opt_profile_comm = 0;       // FL_OPT_PROFILE_COMM: time the compute stream's waits on the halo stream
     int         opt_mgcg_bottom = 1;        // FL_OPT_MGCG_BOTTOM: the two coarsest V-cycle levels in one launch
-    int         opt_mgcg_fuse = 1;          // FL_OPT_MGCG_FUSE: level-0 vector updates inside the stencil passes (bq_mgcg_fused.hip.inc)
+    int         opt_mgcg_fuse = -1;         // FL_OPT_MGCG_FUSE: level-0 vector updates inside the stencil passes (bq_mgcg_fused.hip.inc); -1 = not vouched for: off
     int         opt_comm_check = 0;         // FL_OPT_COMM_CHECK: ledger of communicator calls (bq_halo.hip)
     int         opt_field_window = -1;      // FL_OPT_FIELD_WINDOW: -1 auto (on with FL_OPT_FAST_LERP), 0 off, 1 on, k > 1 planes per block
     int         opt_reserve_cus = 0;        // FL_OPT_RESERVE_CUS: CUs the compute stream leaves to the halo stream's RCCL kernels

@@ -461,7 +461,7 @@ void fl_set_option(int option, int value)
     case FL_OPT_MGCG_TILE:       g_rt.opt_mgcg_tile = value < 0 ? 0 : value; break;
     case FL_OPT_PROFILE_COMM:    g_rt.opt_profile_comm = value != 0; break;
     case FL_OPT_MGCG_BOTTOM:     g_rt.opt_mgcg_bottom = value != 0; break;
-    case FL_OPT_MGCG_FUSE:       g_rt.opt_mgcg_fuse = value < 0 ? 0 : (value > 3 ? 3 : value); break;
+    case FL_OPT_MGCG_FUSE:       g_rt.opt_mgcg_fuse = value < 0 ? -1 : (value > 3 ? 3 : value); break;
     case FL_OPT_FIELD_WINDOW:    g_rt.opt_field_window = value < 0 ? -1 : value; break;
     case FL_OPT_COMM_CHECK:      g_rt.opt_comm_check = value != 0; break;
     case FL_OPT_RESERVE_CUS: {

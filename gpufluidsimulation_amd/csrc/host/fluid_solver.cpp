@@ -335,6 +335,9 @@ void BimocqGPUSolver::setTravelLimit(int cells)
 bool BimocqGPUSolver::allocMgcg()
 {
     if (mg.ready) return true;
+    // temp1 and levels[0].b below are full-size arrays: the operator may keep its fused level-0 vectors in them
+    // (include/bimocq_gpu.h, FL_OPT_MGCG_FUSE; -1 = nobody has set the option)
+    if (fl_get_option(FL_OPT_MGCG_FUSE) < 0) fl_set_option(FL_OPT_MGCG_FUSE, 1);
     // a z-slab rank solves on the WHOLE grid (projectionMgcgSlabs): global plane count
     const bool slabs = GpuSolver->slab.on && GpuSolver->slab.nranks > 1;
     const int nk_all = slabs ? GpuSolver->slab.nkg : g.nk;

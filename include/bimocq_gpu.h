@@ -347,15 +347,18 @@ enum {
                                  * ranks; the host solver calls it at the end of every step while the option is on.  A
                                  * debugging aid for the first runs on real links: a mismatch latches FL_ERR_COMM instead of
                                  * hanging or silently pairing the wrong messages.  Default 0.                        */
-    FL_OPT_MGCG_FUSE       = 20,/* gpu_multi_grid_conjugate_gradient on rows of 256 or 512 cells: 1 (default) runs the level-0
-                                 * vector updates of an outer iteration inside the stencil pass that follows each of them
-                                 * (update_x + residual; add + residual + max + dot; update_dir + A dir + dot -- three
-                                 * launches for nine passes over the arrays, bq_mgcg_fused.hip.inc) on grids of 2^20 cells
-                                 * and more, 2 on any grid of that row length, 0 never (3: as 2 with the wave-per-row
-                                 * form of the kernels on rows of 256 -- the same time, kept for A/B).  Same values; the fused form keeps
-                                 * its intermediate vectors in temp1 and levels[0].b, which the reference's caller
-                                 * allocates at full size (BimocqGPUSolver.cpp:65-66), and what temp0 / temp1 hold after
-                                 * the call differs (both are scratch).                                               */
+    FL_OPT_MGCG_FUSE       = 20,/* gpu_multi_grid_conjugate_gradient on rows of 256 or 512 cells: 1 runs the level-0 vector updates of
+                                 * an outer iteration inside the stencil pass that follows each of them (update_x + residual;
+                                 * add + residual + max + dot; update_dir + A dir + dot -- three launches for nine passes over
+                                 * the arrays, bq_mgcg_fused.hip.inc) on grids of 2^20 cells and more, 2 on any grid of that row
+                                 * length, 0 never (3: as 2 with the wave-per-row form of the kernels on rows of 256 -- the same
+                                 * time, kept for A/B).  Same values.  The fused form keeps its intermediate vectors in temp1
+                                 * and levels[0].b, i.e. it needs BOTH to be full-size arrays (ni nj nk doubles) -- as the
+                                 * reference's caller allocates them (BimocqGPUSolver.cpp:65-66) but more than the reference's
+                                 * kernels themselves touch of temp1; what temp0 / temp1 hold after the call differs (both are
+                                 * scratch).  Hence the default is -1 = off until a caller says so: setting 1 is the caller's
+                                 * word that its arrays have that size.  The host solver of this package (csrc/host), which
+                                 * allocates them, sets 1 unless the option has been set before.                      */
     FL_OPT_MAP_QUARTER_FP32 = 13 /* 0 (default): every lerp of the structured map look-up follows the double-rounding
                                  * contract.  1: the caller vouches that every value of the map arrays it passes to the
                                  * 9-point operators is 0 or lies in [h/256, 1024 h] (gpu_maps_quarter_safe checks a map

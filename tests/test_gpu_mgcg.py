@@ -134,7 +134,7 @@ def test_mgcg_vector_updates_inside_the_stencil_passes(hip, ni, nj, nk, levels, 
         test_mgcg_matches_oracle(hip, ni, nj, nk, levels, iters, 0.5, stale)
         assert hip.fl_mg_fused_launches() == 0
     finally:
-        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1)
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, -1)
 
 
 def test_mgcg_fused_vector_updates_on_random_shapes(hip):
@@ -156,7 +156,7 @@ def test_mgcg_fused_vector_updates_on_random_shapes(hip):
             assert hip.fl_mg_fused_launches() > 0, (case, ni, nj, nk, levels, iters, mode)
     finally:
         hip.fl_set_option(bq._lib.FL_OPT_JACOBI_KCHUNK2, 0)
-        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1)
+        hip.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, -1)
 
 
 @pytest.mark.parametrize("ni,nj,nk,levels", [(64, 64, 64, 4), (32, 32, 32, 3), (16, 16, 16, 2), (30, 14, 9, 2), (33, 31, 12, 3)])

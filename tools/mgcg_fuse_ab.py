@@ -44,7 +44,7 @@ def main():
                 s.advance(frame, dt); frame += 1
             lib.fl_sync()
             out.setdefault(mode, []).append(round((time.perf_counter() - t0) / a.steps * 1e3, 3))
-    lib.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, 1)
+    lib.fl_set_option(bq._lib.FL_OPT_MGCG_FUSE, -1)
     s._check()
     s.close()
     print(json.dumps({"size": n, "mg_iters": a.iters, "ms_per_step": {"fuse_off": out[0], "wave_per_row": out[1], "two_rows_per_thread": out[3]}}))
