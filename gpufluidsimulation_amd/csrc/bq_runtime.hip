@@ -190,6 +190,14 @@ void fl_shutdown(void)
     (void)hipStreamSynchronize(g_rt.compute);
     (void)hipStreamSynchronize(g_rt.halo);
     (void)hipStreamSynchronize(g_rt.copy);
+    // ORDER MATTERS: a stream created with a CU mask (the copy stream by default; the compute stream with FL_OPT_RESERVE_CUS) is
+    // destroyed while the unmasked streams still exist.  Destroyed after them, hipStreamDestroy of the masked stream can sit in
+    // the runtime's queue-destroy ioctl for ever while the runtime's event thread waits for a lock the call holds (ROCm 7.2; seen
+    // at the exit of tools/jacobi_tune.py --n 128 with seven variants, `tools/batches/r04_zu.sh`: masked stream last -> hang,
+    // first -> exit in 1 s, no mask -> exit in 1 s; tests/test_gpu_runtime.py keeps the case).
+    (void)hipStreamDestroy(g_rt.copy);
+    g_rt.copy = nullptr;
+    if (g_rt.opt_reserve_cus > 0 && !g_rt.compute_main && !g_rt.aux) { (void)hipStreamDestroy(g_rt.compute); g_rt.compute = nullptr; }
     bq::mgcg_release_state(g_rt);
     bq::halo_release_state(g_rt);
     bq::project_release_state(g_rt);
@@ -204,10 +212,8 @@ void fl_shutdown(void)
     if (g_rt.aux_fork) { (void)hipEventDestroy(g_rt.aux_fork); g_rt.aux_fork = nullptr; }
     if (g_rt.aux_done) { (void)hipEventDestroy(g_rt.aux_done); g_rt.aux_done = nullptr; }
     g_rt.aux_pending = false;
-    (void)hipStreamDestroy(g_rt.compute);
+    if (g_rt.compute) (void)hipStreamDestroy(g_rt.compute);
     (void)hipStreamDestroy(g_rt.halo);
-    (void)hipStreamDestroy(g_rt.copy);
-    g_rt.copy = nullptr;
     g_rt.scratch = nullptr; g_rt.scratch_bytes = 0;
     g_rt.pinned = nullptr; g_rt.pinned_bytes = 0;
     g_rt.compute = nullptr; g_rt.halo = nullptr;

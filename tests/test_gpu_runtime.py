@@ -109,6 +109,22 @@ def test_python_child_with_masked_copy_stream_exits_cleanly():
     assert "SIGSEGV" not in r.stdout and "dumped core" not in r.stdout, r.stdout[-2000:]
 
 
+def test_masked_stream_is_destroyed_before_the_others():
+    """A process that hung at exit for ever (round 4, tools/batches/r04_zy.sh ... r04_zu.sh): seven sweep-kernel variants at 128^3
+    through tools/jacobi_tune.py, then the interpreter's exit -> fl_shutdown_all -> hipStreamDestroy of the CU-masked copy stream
+    AFTER the compute and halo streams: the call sat in the runtime's queue-destroy ioctl while the runtime's event thread waited
+    for a lock it held.  With the masked stream destroyed first (or no mask) the same process ends within a second."""
+    import subprocess
+    import sys
+    try:
+        r = _run([sys.executable, "tools/jacobi_tune.py", "--n", "128", "--reps", "7",
+                  "--variants", "5:2:4,4:0:8,4:0:12,4:0:16,4:6:8,4:6:16,4:2:4"], timeout=90)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("the child printed its table and never exited:\n" + ((e.stdout or b"").decode(errors="replace")[-1500:] if isinstance(e.stdout, bytes) else str(e.stdout)[-1500:]))
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count("us/sweep") == 7, r.stdout[-2000:]
+
+
 def test_python_child_exits_cleanly_under_the_profiler(tmp_path):
     """the very command shape of the two round-3 traces: rocprofv3 --kernel-trace around a child that never calls
     fl_shutdown, copy stream CU-masked (the default)"""
